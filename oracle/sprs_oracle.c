@@ -1,0 +1,90 @@
+/* TEST INFRASTRUCTURE ONLY — CPU oracle for the sprsolve Krylov hot path.
+ *
+ * This is a plain-C restatement of the reference's algorithm (cxzheng/sprsolve v0.1.4,
+ * `parallel` feature without `mkl`): CSR/CSC SpMV (src/mat.rs:68-152), the eight BLAS-1
+ * fallbacks (src/vecalg.rs:556-605), the Jacobi preconditioner (src/precond.rs:20-52) and the
+ * BiCGStab / MINRES / CSMINRES recurrences (src/bicg_stab.rs, src/minres.rs, src/cs_minres.rs).
+ *
+ * It is the checker for tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ * Nothing in the product path (sprsolve_amd/, include/) may link, import or call it.
+ *
+ * Parity pin: the reference itself cannot be built here (Rust nightly + un-vendored git
+ * dependencies, no toolchain), so this oracle is pinned against every known-answer test the
+ * reference's own test modules hold for this path (src/mat.rs:207-280, src/mkl_mat.rs:341-463,
+ * src/vecalg.rs:612-841, and the exact solutions implied by the tests/ directory) — see
+ * tests/golden/ and tests/test_oracle_golden.py.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <math.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "scalar.h"
+
+/* status codes — identical to include/sprsolve_hip.h (which maps 1:1 onto
+ * SolverError, src/error.rs:7-22) */
+#define ORC_OK 0
+#define ORC_INCOMPATIBLE_RHS 1
+#define ORC_INCOMPATIBLE_X 2
+#define ORC_INSUFFICIENT_ITER 3
+#define ORC_BREAKDOWN 4
+#define ORC_INVALID_PRECOND 5
+#define ORC_DIM_MISMATCH 6
+
+#define ORC_CAT2_(a, b) a##b
+#define ORC_CAT2(a, b) ORC_CAT2_(a, b)
+#define ORC_CAT3_(a, b, c) a##b##c
+#define ORC_CAT3(a, b, c) ORC_CAT3_(a, b, c)
+
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* f64 instantiation */
+#define T double
+#define SP d_
+#define SFX_US _d
+#define SFX_IS_COMPLEX 0
+#include "krylov_tmpl.h"
+#undef T
+#undef SP
+#undef SFX_US
+#undef SFX_IS_COMPLEX
+
+/* Complex<f64> instantiation */
+#define T orc_c64
+#define SP z_
+#define SFX_US _z
+#define SFX_IS_COMPLEX 1
+#include "krylov_tmpl.h"
+#undef T
+#undef SP
+#undef SFX_US
+#undef SFX_IS_COMPLEX
+
+/* precond.rs:20-29 with V = Complex<f64>: one()/v through the complex division formula */
+void orc_diag_inv_complex(int64_t n, const orc_c64 *diag, orc_c64 *dinv) {
+    for (int64_t i = 0; i < n; ++i) dinv[i] = z_div(z_one(), diag[i]);
+}
+
+/* vecalg.rs:570-575 with S = f64, T = Complex<f64> (`Complex * f64`, used by
+ * vecalg.rs:746-757): y += x * a with a real */
+void orc_axpy_zd(int64_t n, double a, const orc_c64 *x, orc_c64 *y) {
+    for (int64_t i = 0; i < n; ++i) y[i] = z_add(y[i], z_mulr(x[i], a));
+}

@@ -1,0 +1,97 @@
+"""Pins the CPU oracle (oracle/sprs_oracle.c) against every known-answer test the reference
+holds for the hot path.  CPU only."""
+import numpy as np
+import pytest
+
+import _golden as G
+
+
+@pytest.mark.parametrize("case", G.load("spmv_kat.json")["cases"], ids=lambda c: c["name"])
+def test_spmv_kat(oracle, case):
+    indptr, indices, data, x, exp = G.spmv_case(case)
+    if case["storage"] == "CSC":
+        y = oracle.spmv_csc(case["shape"][0], indptr, indices, data, x)
+    else:
+        y = oracle.spmv(indptr, indices, data, x)
+        yp = oracle.spmv(indptr, indices, data, x, parallel=True)
+        assert np.array_equal(y.view(np.float64), yp.view(np.float64)), "row-parallel bits differ from serial"
+    assert np.all(np.abs(y - exp) < case["eps"] * (np.sqrt(2) if case.get("complex") else 1))
+    if case.get("complex"):
+        assert np.all(np.abs(y.real - exp.real) < case["eps"]) and np.all(np.abs(y.imag - exp.imag) < case["eps"])
+
+
+def test_mul_vec_dot_kat(oracle):
+    """src/mkl_mat.rs:432-463: mul_vec_dot(x, y) == conj_dot(x, A x)."""
+    spec = G.load("spmv_kat.json")
+    case = [c for c in spec["cases"] if c["name"] == spec["mul_vec_dot"]["case"]][0]
+    indptr, indices, data, x, exp = G.spmv_case(case)
+    y, d = oracle.spmv_dot(indptr, indices, data, x)
+    assert np.all(np.abs(y - exp) < 2e-8)
+    e = oracle.conj_dot(x, y)
+    assert d == e
+    assert abs(d - np.vdot(x, y)) < 1e-14
+
+
+def _run_vecalg(orc, case):
+    dt = case["dtype"]
+    op = case["op"]
+    x = G.vec(case["x"], dt)
+    if op == "norm2":
+        return orc.norm2(x)
+    if op in ("dot", "conj_dot"):
+        return getattr(orc, op)(x, G.vec(case["y"], dt))
+    if op == "scale":
+        return orc.scale(G.scalar(case["a"], dt), x)
+    if op == "rscale":
+        return orc.rscale(case["a"], x)
+    if op == "conj":
+        return orc.conj(x)
+    if op == "axpy":
+        y = G.vec(case["y"], dt)
+        a = float(case["a_real"]) if "a_real" in case else G.scalar(case["a"], dt)
+        return orc.axpy(a, x, y)
+    if op == "axpy_repeat":
+        y = G.vec(case["y"], dt)
+        for _ in range(case["repeat"]):
+            orc.axpy(G.scalar(case["a"], dt), x, y)
+        return y
+    raise KeyError(op)
+
+
+@pytest.mark.parametrize("case", G.load("vecalg_kat.json")["cases"], ids=lambda c: c["name"])
+def test_vecalg_kat(oracle, case):
+    dt = case["dtype"]
+    eps = case.get("eps", 1e-13)
+    if case["op"] == "axpby_sequence":
+        x = G.vec(case["x"], dt); y = G.vec(case["y"], dt)
+        for st in case["steps"]:
+            for _ in range(st["repeat"]):
+                oracle.axpby(G.scalar(st["a"], dt), x, G.scalar(st["b"], dt), y)
+            assert np.all(np.abs(y - st["expected_fill"]) <= eps)
+        return
+    got = _run_vecalg(oracle, case)
+    if "expected" in case:
+        assert abs(got - G.scalar(case["expected"], dt)) <= eps
+    elif "expected_fill" in case:
+        assert np.all(np.abs(got - G.scalar(case["expected_fill"], dt)) <= eps)
+    else:
+        exp = G.vec({"array": case["expected_array"]}, dt)
+        assert np.all(np.abs(got - exp) <= eps)
+
+
+@pytest.mark.parametrize("case", G.load("solver_kat.json")["cases"], ids=lambda c: c["name"])
+def test_solver_kat(oracle, case):
+    """The reference asserts only Ok; we additionally assert the exact solution its
+    construction implies."""
+    p = G.solver_problem(case)
+    fn = getattr(oracle, case["solver"])
+    x0 = np.zeros_like(p["rhs"])
+    r = fn(p["indptr"], p["indices"], p["data"], p["rhs"], x0, case["max_iter"], case["tol"],
+           precond_diag=p["diag"])
+    assert r.status == oracle.OK, r
+    err = np.max(np.abs(r.x - p["exact"]))
+    scale = max(1.0, np.max(np.abs(p["exact"])))
+    assert err / scale < 1e-9, (r, err)
+    # true residual
+    res = np.linalg.norm(oracle.spmv(p["indptr"], p["indices"], p["data"], r.x) - p["rhs"]) / np.linalg.norm(p["rhs"])
+    assert res < 1e-10, res
