@@ -1,0 +1,219 @@
+/* sprsolve_hip.h — C ABI of the MI355X (gfx950) backend for sprsolve's Krylov hot path.
+ *
+ * This is the drop-in boundary.  It exports exactly what a Rust FFI for the
+ * path would bind: an opaque device CSR operator that implements the `MatVecMul` trait
+ * (reference src/mat.rs:12-37; in-tree precedent for an opaque backend handle:
+ * src/mkl_mat.rs:15-149,322-333), the BLAS-1 kernels of src/vecalg.rs on device vectors, the
+ * Jacobi preconditioner of src/precond.rs, and the three solver objects with the reference's
+ * `new` / `solve` / `precond_solve` signatures (src/bicg_stab.rs:25,35,204; src/minres.rs:21,31,
+ * 178; src/cs_minres.rs:19,29).  Plain pointers and sizes only; nothing throws or aborts
+ * across this boundary.  The reference-side binding is shown in INTEGRATION.md.
+ *
+ * Suffix convention:  _d = f64,  _z = Complex<f64> (layout {re, im} = num_complex::Complex<f64>
+ * repr(C) = double2),  _zd = complex vector with a real scalar/diagonal.
+ * "host" pointers are ordinary CPU memory; "dev" pointers are HIP device memory on the
+ * context's GPU.  All calls are blocking from the caller's view unless stated otherwise.
+ */
+#ifndef SPRSOLVE_HIP_H
+#define SPRSOLVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { double re, im; } sprs_c64;
+
+/* Status codes. 1..5 map 1:1 onto reference src/error.rs:7-22 `SolverError`; 6 is the
+ * `panic!("Dimension mismatch")` of src/mat.rs:50-52,58-60 and src/precond.rs:39-41. */
+enum {
+    SPRS_OK = 0,
+    SPRS_INCOMPATIBLE_RHS_SIZE = 1, /* IncompatibleMatrixFormat("Input vec dimension doesn't match the matrix size") bicg_stab.rs:44-48 */
+    SPRS_INCOMPATIBLE_X_SIZE = 2,   /* IncompatibleMatrixFormat("Input and output vec dimension do not match")       bicg_stab.rs:49-53 */
+    SPRS_INSUFFICIENT_ITER = 3,     /* InsufficientIterNum(max_iter)  bicg_stab.rs:199  (*its_out = max_iter) */
+    SPRS_BREAKDOWN = 4,             /* BreakDown(its)                 bicg_stab.rs:164-167 (*its_out = its) */
+    SPRS_INVALID_PRECOND = 5,       /* InvalidPreconditioner(..)      minres.rs:236-244,279-287 (*its_out = its, *res_out = re(beta^2)) */
+    SPRS_DIM_MISMATCH = 6,          /* panic!("Dimension mismatch")   mat.rs:50-52 */
+    SPRS_INVALID_ARGUMENT = 7,      /* null handle, index out of i32 range, malformed CSR */
+    SPRS_ERR_HIP = 100,             /* a HIP runtime call failed; see sprs_last_error() */
+    SPRS_ERR_RCCL = 101,            /* an RCCL call failed */
+    SPRS_ERR_NO_DEVICE = 102        /* no usable gfx950 device */
+};
+
+typedef struct sprs_ctx sprs_ctx;           /* one GPU + one HIP stream + reduction scratch */
+typedef struct sprs_csr sprs_csr;           /* device CSR operator: impl MatVecMul (mat.rs:47-153) */
+typedef struct sprs_diag sprs_diag;         /* DiagPrecond<T,V>              (precond.rs:6-63)  */
+typedef struct sprs_bicgstab sprs_bicgstab; /* BiCGStab<T,M>                 (bicg_stab.rs:17-31) */
+typedef struct sprs_minres sprs_minres;     /* MinRes<T,M>                   (minres.rs:13-27)    */
+typedef struct sprs_csminres sprs_csminres; /* CSMinRes<T,M>                 (cs_minres.rs:11-25) */
+
+/* ---------------------------------------------------------------- context */
+/* device: HIP device ordinal.  stream: an existing hipStream_t to run on (e.g. the caller's
+ * framework stream), or NULL to create a private one. */
+int sprs_ctx_create(int device, void *stream, sprs_ctx **out);
+int sprs_ctx_destroy(sprs_ctx *ctx);               /* NULL is a no-op */
+int sprs_ctx_sync(sprs_ctx *ctx);
+const char *sprs_last_error(const sprs_ctx *ctx);  /* text of the last SPRS_ERR_* on this ctx */
+const char *sprs_status_str(int status);
+int sprs_version(void);
+/* tuning knobs (defaults chosen for MI355X): key = "grid" (blocks of the streaming kernels),
+ * "xcd_chunk" (1: contiguous row-block chunk per XCD), "poll" (iterations between host polls) */
+int sprs_ctx_set(sprs_ctx *ctx, const char *key, int64_t value);
+int64_t sprs_ctx_get(const sprs_ctx *ctx, const char *key);
+
+/* device memory for callers that have no HIP of their own (a Rust host) */
+int sprs_malloc(sprs_ctx *ctx, size_t bytes, void **dev_out);
+int sprs_free(sprs_ctx *ctx, void *dev);
+int sprs_memcpy_h2d(sprs_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+int sprs_memcpy_d2h(sprs_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+int sprs_memcpy_d2d(sprs_ctx *ctx, void *dev_dst, const void *dev_src, size_t bytes); /* ptr::copy_nonoverlapping, bicg_stab.rs:78 */
+int sprs_memset_zero(sprs_ctx *ctx, void *dev, size_t bytes);                          /* iter_mut().for_each(zero), minres.rs:86-88 */
+
+/* ---------------------------------------------------------------- CSR operator (MatVecMul) */
+/* Create from host arrays (copied to HBM; the caller keeps its own copy — cf. MklMat::new,
+ * mkl_mat.rs:32-74).  Index types of mat.rs:196-199: i32 natively; i64 covers u32/u64/usize by
+ * narrowing with a range check (SPRS_INVALID_ARGUMENT if anything exceeds i32).
+ * `storage_csc` != 0: the arrays are CSC (mat.rs:130-142); converted to CSR once at creation. */
+int sprs_csr_create_d(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *row_ptr,
+                      const int32_t *col_idx, const double *val, int storage_csc, sprs_csr **out);
+int sprs_csr_create_z(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *row_ptr,
+                      const int32_t *col_idx, const sprs_c64 *val, int storage_csc, sprs_csr **out);
+int sprs_csr_create_i64_d(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t *row_ptr,
+                          const int64_t *col_idx, const double *val, int storage_csc, sprs_csr **out);
+int sprs_csr_create_i64_z(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t *row_ptr,
+                          const int64_t *col_idx, const sprs_c64 *val, int storage_csc, sprs_csr **out);
+/* Create from arrays already resident in HBM (CSR, i32).  adopt == 0: copied; adopt != 0: the
+ * handle references the caller's arrays, which must outlive it (no copy of multi-GB matrices). */
+int sprs_csr_create_dev_d(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *dev_row_ptr,
+                          const int32_t *dev_col_idx, const double *dev_val, int adopt, sprs_csr **out);
+int sprs_csr_create_dev_z(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *dev_row_ptr,
+                          const int32_t *dev_col_idx, const sprs_c64 *dev_val, int adopt, sprs_csr **out);
+int sprs_csr_destroy(sprs_csr *A); /* Drop, mkl_mat.rs:322-333; NULL is a no-op */
+int64_t sprs_csr_rows(const sprs_csr *A);
+int64_t sprs_csr_cols(const sprs_csr *A);
+int64_t sprs_csr_nnz(const sprs_csr *A);
+
+/* MatVecMul::mul_vec / mul_vec_dot (mat.rs:49-64): host slices, checked — returns
+ * SPRS_DIM_MISMATCH where the reference panics.  y = A x ; *dot_out = conj(x) . y */
+int sprs_mul_vec_d(const sprs_csr *A, const double *x_host, size_t x_len, double *y_host, size_t y_len);
+int sprs_mul_vec_z(const sprs_csr *A, const sprs_c64 *x_host, size_t x_len, sprs_c64 *y_host, size_t y_len);
+int sprs_mul_vec_dot_d(const sprs_csr *A, const double *x_host, size_t x_len, double *y_host, size_t y_len, double *dot_out);
+int sprs_mul_vec_dot_z(const sprs_csr *A, const sprs_c64 *x_host, size_t x_len, sprs_c64 *y_host, size_t y_len, sprs_c64 *dot_out);
+/* MatVecMul::mul_vec_unchecked / mul_vec_dot_unchecked (mat.rs:68-152) on device vectors:
+ * no dimension check, no PCIe traffic.  x_dev has ncols elements, y_dev nrows. */
+int sprs_mul_vec_dev_d(const sprs_csr *A, const double *x_dev, double *y_dev);
+int sprs_mul_vec_dev_z(const sprs_csr *A, const sprs_c64 *x_dev, sprs_c64 *y_dev);
+int sprs_mul_vec_dot_dev_d(const sprs_csr *A, const double *x_dev, double *y_dev, double *dot_out);
+int sprs_mul_vec_dot_dev_z(const sprs_csr *A, const sprs_c64 *x_dev, sprs_c64 *y_dev, sprs_c64 *dot_out);
+/* Launch `reps` back-to-back SpMVs bracketed by HIP events on the context's stream and
+ * return the mean device time of one launch in milliseconds (roofline measurement). */
+int sprs_mul_vec_dev_timed_d(const sprs_csr *A, const double *x_dev, double *y_dev, int reps, double *ms_per_launch);
+int sprs_mul_vec_dev_timed_z(const sprs_csr *A, const sprs_c64 *x_dev, sprs_c64 *y_dev, int reps, double *ms_per_launch);
+
+/* ---------------------------------------------------------------- vecalg (src/vecalg.rs) on device vectors */
+int sprs_dot_d(sprs_ctx *ctx, size_t n, const double *x, const double *y, double *out);            /* vecalg.rs:24,556  sum x*y (no conj) */
+int sprs_dot_z(sprs_ctx *ctx, size_t n, const sprs_c64 *x, const sprs_c64 *y, sprs_c64 *out);
+int sprs_conj_dot_d(sprs_ctx *ctx, size_t n, const double *x, const double *y, double *out);       /* vecalg.rs:51,563  sum conj(x)*y */
+int sprs_conj_dot_z(sprs_ctx *ctx, size_t n, const sprs_c64 *x, const sprs_c64 *y, sprs_c64 *out);
+int sprs_norm2_d(sprs_ctx *ctx, size_t n, const double *x, double *out);                           /* vecalg.rs:63,601  sqrt(sum |x|^2), unscaled */
+int sprs_norm2_z(sprs_ctx *ctx, size_t n, const sprs_c64 *x, double *out);
+int sprs_scale_d(sprs_ctx *ctx, size_t n, double a, double *x);                                    /* vecalg.rs:74,592  x *= a */
+int sprs_scale_z(sprs_ctx *ctx, size_t n, sprs_c64 a, sprs_c64 *x);
+int sprs_rscale_d(sprs_ctx *ctx, size_t n, double a, double *x);                                   /* vecalg.rs:86,596  x = x.mul_real(a) */
+int sprs_rscale_z(sprs_ctx *ctx, size_t n, double a, sprs_c64 *x);
+int sprs_conj_d(sprs_ctx *ctx, size_t n, const double *in, double *out);                           /* vecalg.rs:96,577  out = conj(in) */
+int sprs_conj_z(sprs_ctx *ctx, size_t n, const sprs_c64 *in, sprs_c64 *out);
+int sprs_axpy_d(sprs_ctx *ctx, size_t n, double a, const double *x, double *y);                    /* vecalg.rs:109,570 y += x*a */
+int sprs_axpy_z(sprs_ctx *ctx, size_t n, sprs_c64 a, const sprs_c64 *x, sprs_c64 *y);
+int sprs_axpy_zd(sprs_ctx *ctx, size_t n, double a, const sprs_c64 *x, sprs_c64 *y);               /* S = f64, T = Complex<f64> (vecalg.rs:746-757) */
+int sprs_axpby_d(sprs_ctx *ctx, size_t n, double a, const double *x, double b, double *y);         /* vecalg.rs:135,585 y = x*a + y*b */
+int sprs_axpby_z(sprs_ctx *ctx, size_t n, sprs_c64 a, const sprs_c64 *x, sprs_c64 b, sprs_c64 *y);
+
+/* ---------------------------------------------------------------- Jacobi preconditioner (src/precond.rs) */
+/* DiagPrecond::new(diag): stores 1/diag (precond.rs:20-29; no zero check, as in the reference). */
+int sprs_diag_precond_create_d(sprs_ctx *ctx, size_t n, const double *diag_host, sprs_diag **out);    /* DiagPrecond<f64,f64> */
+int sprs_diag_precond_create_zd(sprs_ctx *ctx, size_t n, const double *diag_host, sprs_diag **out);   /* DiagPrecond<Complex64,f64>       (tests/test_complex_solve.rs:44) */
+int sprs_diag_precond_create_z(sprs_ctx *ctx, size_t n, const sprs_c64 *diag_host, sprs_diag **out);  /* DiagPrecond<Complex64,Complex64> (tests/test_complex_solve2.rs:10) */
+int sprs_diag_precond_destroy(sprs_diag *P);
+/* MatVecMul::mul_vec for DiagPrecond (precond.rs:37-52): host slices, checked */
+int sprs_diag_mul_vec_d(const sprs_diag *P, const double *in_host, size_t in_len, double *out_host, size_t out_len);
+int sprs_diag_mul_vec_z(const sprs_diag *P, const sprs_c64 *in_host, size_t in_len, sprs_c64 *out_host, size_t out_len);
+/* mul_vec_unchecked on device vectors */
+int sprs_diag_mul_vec_dev_d(const sprs_diag *P, const double *in_dev, double *out_dev);
+int sprs_diag_mul_vec_dev_z(const sprs_diag *P, const sprs_c64 *in_dev, sprs_c64 *out_dev);
+
+/* ---------------------------------------------------------------- solvers */
+/* Common contract (bicg_stab.rs:35-41):  rhs read-only, x in/out (initial guess -> solution),
+ * returns a status; on SPRS_OK (*its_out, *res_out) is the reference's Ok((iters, rel_residual)).
+ * `*_solve_*`      : rhs/x are host slices (one H2D + one D2H per solve, all iteration state in HBM).
+ * `*_solve_dev_*`  : rhs/x are device vectors (nothing crosses PCIe).
+ * The solver borrows A (and the preconditioner) — they must outlive it (bicg_stab.rs:18) — and
+ * owns its 7n/8n-element workspace, reused across solves (bicg_stab.rs:28).  One in-flight solve
+ * per solver handle (`&mut self`). */
+int sprs_bicgstab_create_d(const sprs_csr *A, size_t size, sprs_bicgstab **out);   /* BiCGStab::new  bicg_stab.rs:25 */
+int sprs_bicgstab_create_z(const sprs_csr *A, size_t size, sprs_bicgstab **out);
+int sprs_bicgstab_destroy(sprs_bicgstab *S);
+int sprs_bicgstab_solve_d(sprs_bicgstab *S, const double *rhs, size_t rhs_len, double *x, size_t x_len,
+                          size_t max_iter, double tol, size_t *its_out, double *res_out);            /* bicg_stab.rs:35-200 */
+int sprs_bicgstab_solve_z(sprs_bicgstab *S, const sprs_c64 *rhs, size_t rhs_len, sprs_c64 *x, size_t x_len,
+                          size_t max_iter, double tol, size_t *its_out, double *res_out);
+int sprs_bicgstab_precond_solve_d(sprs_bicgstab *S, const sprs_diag *P, const double *rhs, size_t rhs_len, double *x,
+                                  size_t x_len, size_t max_iter, double tol, size_t *its_out, double *res_out); /* bicg_stab.rs:204-366 */
+int sprs_bicgstab_precond_solve_z(sprs_bicgstab *S, const sprs_diag *P, const sprs_c64 *rhs, size_t rhs_len, sprs_c64 *x,
+                                  size_t x_len, size_t max_iter, double tol, size_t *its_out, double *res_out);
+int sprs_bicgstab_solve_dev_d(sprs_bicgstab *S, const sprs_diag *P_or_null, const double *rhs_dev, size_t rhs_len,
+                              double *x_dev, size_t x_len, size_t max_iter, double tol, size_t *its_out, double *res_out);
+int sprs_bicgstab_solve_dev_z(sprs_bicgstab *S, const sprs_diag *P_or_null, const sprs_c64 *rhs_dev, size_t rhs_len,
+                              sprs_c64 *x_dev, size_t x_len, size_t max_iter, double tol, size_t *its_out, double *res_out);
+
+int sprs_minres_create_d(const sprs_csr *A, size_t size, sprs_minres **out);       /* MinRes::new  minres.rs:21 */
+int sprs_minres_create_z(const sprs_csr *A, size_t size, sprs_minres **out);
+int sprs_minres_destroy(sprs_minres *S);
+int sprs_minres_solve_d(sprs_minres *S, const double *rhs, size_t rhs_len, double *x, size_t x_len,
+                        size_t max_iter, double tol, size_t *its_out, double *res_out);              /* minres.rs:31-172 */
+int sprs_minres_solve_z(sprs_minres *S, const sprs_c64 *rhs, size_t rhs_len, sprs_c64 *x, size_t x_len,
+                        size_t max_iter, double tol, size_t *its_out, double *res_out);
+int sprs_minres_precond_solve_d(sprs_minres *S, const sprs_diag *P, const double *rhs, size_t rhs_len, double *x,
+                                size_t x_len, size_t max_iter, double tol, size_t *its_out, double *res_out); /* minres.rs:178-341 */
+int sprs_minres_precond_solve_z(sprs_minres *S, const sprs_diag *P, const sprs_c64 *rhs, size_t rhs_len, sprs_c64 *x,
+                                size_t x_len, size_t max_iter, double tol, size_t *its_out, double *res_out);
+int sprs_minres_solve_dev_d(sprs_minres *S, const sprs_diag *P_or_null, const double *rhs_dev, size_t rhs_len,
+                            double *x_dev, size_t x_len, size_t max_iter, double tol, size_t *its_out, double *res_out);
+int sprs_minres_solve_dev_z(sprs_minres *S, const sprs_diag *P_or_null, const sprs_c64 *rhs_dev, size_t rhs_len,
+                            sprs_c64 *x_dev, size_t x_len, size_t max_iter, double tol, size_t *its_out, double *res_out);
+
+int sprs_csminres_create_z(const sprs_csr *A, size_t size, sprs_csminres **out);   /* CSMinRes::new  cs_minres.rs:19 */
+int sprs_csminres_create_d(const sprs_csr *A, size_t size, sprs_csminres **out);   /* generic over T: real T degenerates to MINRES arithmetic */
+int sprs_csminres_destroy(sprs_csminres *S);
+int sprs_csminres_solve_z(sprs_csminres *S, const sprs_c64 *rhs, size_t rhs_len, sprs_c64 *x, size_t x_len,
+                          size_t max_iter, double tol, size_t *its_out, double *res_out);            /* cs_minres.rs:29-158 */
+int sprs_csminres_solve_d(sprs_csminres *S, const double *rhs, size_t rhs_len, double *x, size_t x_len,
+                          size_t max_iter, double tol, size_t *its_out, double *res_out);
+int sprs_csminres_solve_dev_z(sprs_csminres *S, const sprs_c64 *rhs_dev, size_t rhs_len, sprs_c64 *x_dev, size_t x_len,
+                              size_t max_iter, double tol, size_t *its_out, double *res_out);
+int sprs_csminres_solve_dev_d(sprs_csminres *S, const double *rhs_dev, size_t rhs_len, double *x_dev, size_t x_len,
+                              size_t max_iter, double tol, size_t *its_out, double *res_out);
+
+/* ---------------------------------------------------------------- solver options / instrumentation
+ * `solver` is any of the three solver handle types. */
+enum { SPRS_SOLVER_BICGSTAB = 1, SPRS_SOLVER_MINRES = 2, SPRS_SOLVER_CSMINRES = 3 };
+/* mode 0 (default): fused kernels, device-resident scalars, lazy host polling.
+ * mode 1: "literal" — the reference's op list one kernel per op, every scalar consumed on the
+ *         host exactly where the reference consumes it (bicg_stab.rs:122-197). */
+int sprs_solver_set_mode(void *solver, int kind, int mode);
+/* Per-iteration scalar trace (8 doubles per row: BiCGStab [its, r_norm, rho, alpha, w]; MINRES [its, beta, alpha, c, s, res_norm]): the solver
+ * synchronises every iteration while a trace buffer is set.  rows_out: rows written by the last solve. */
+int sprs_solver_set_trace(void *solver, int kind, double *trace_host, size_t capacity_rows);
+int sprs_solver_trace_rows(const void *solver, int kind, size_t *rows_out);
+/* Device-time profile of the last solve: total milliseconds and launch count of the SpMV
+ * kernel measured with HIP events on the solver's stream (enable != 0 to collect). */
+int sprs_solver_set_profile(void *solver, int kind, int enable);
+int sprs_solver_get_profile(const void *solver, int kind, double *spmv_ms_total, int64_t *spmv_launches,
+                            double *solve_ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPRSOLVE_HIP_H */

@@ -1,0 +1,249 @@
+// BLAS-1 kernels of the hot path (reference src/vecalg.rs:556-605, src/precond.rs:20-52) as
+// stand-alone launches.  HBM-bound streaming kernels: 16 bytes per lane per access, grid-stride,
+// two-stage deterministic reductions (wavefront butterfly -> LDS -> one partial per workgroup ->
+// fixed-order final pass).  The fused solver kernels in krylov.hip reuse the same arithmetic.
+#include "device.hpp"
+
+namespace sprs {
+
+// ------------------------------------------------------------------ element-wise functors
+template <class T, class S>
+struct AxpyF {  // vecalg.rs:570-575  y += x * a
+    S a; const T *x; T *y;
+    template <int PK> __device__ __forceinline__ void run(int64_t i) const {
+        auto xv = ldp<T, PK>(x, i); auto yv = ldp<T, PK>(y, i);
+#pragma unroll
+        for (int e = 0; e < PK; ++e) yv.v[e] = sadd(yv.v[e], smulv(xv.v[e], a));
+        stp<T, PK>(y, i, yv);
+    }
+};
+template <class T>
+struct AxpbyF {  // vecalg.rs:585-590  y = x*a + y*b
+    T a, b; const T *x; T *y;
+    template <int PK> __device__ __forceinline__ void run(int64_t i) const {
+        auto xv = ldp<T, PK>(x, i); auto yv = ldp<T, PK>(y, i);
+#pragma unroll
+        for (int e = 0; e < PK; ++e) yv.v[e] = sadd(smul(xv.v[e], a), smul(yv.v[e], b));
+        stp<T, PK>(y, i, yv);
+    }
+};
+template <class T>
+struct ScaleF {  // vecalg.rs:592-595  v *= a
+    T a; T *x;
+    template <int PK> __device__ __forceinline__ void run(int64_t i) const {
+        auto xv = ldp<T, PK>(x, i);
+#pragma unroll
+        for (int e = 0; e < PK; ++e) xv.v[e] = smul(xv.v[e], a);
+        stp<T, PK>(x, i, xv);
+    }
+};
+template <class T>
+struct RscaleF {  // vecalg.rs:596-599  v = v.mul_real(a)
+    double a; T *x;
+    template <int PK> __device__ __forceinline__ void run(int64_t i) const {
+        auto xv = ldp<T, PK>(x, i);
+#pragma unroll
+        for (int e = 0; e < PK; ++e) xv.v[e] = smulr(xv.v[e], a);
+        stp<T, PK>(x, i, xv);
+    }
+};
+template <class T>
+struct ConjF {  // vecalg.rs:577-583  out = conj(in)
+    const T *in; T *out;
+    template <int PK> __device__ __forceinline__ void run(int64_t i) const {
+        auto xv = ldp<T, PK>(in, i);
+#pragma unroll
+        for (int e = 0; e < PK; ++e) xv.v[e] = sconj(xv.v[e]);
+        stp<T, PK>(out, i, xv);
+    }
+};
+template <class T, class V>
+struct DiagApplyF {  // precond.rs:48-52  out = in * diag_inv   (V may be real while T is complex)
+    const V *d; const T *in; T *out;
+    template <int PK> __device__ __forceinline__ void run(int64_t i) const {
+        auto xv = ldp<T, PK>(in, i); auto dv = ldp<V, PK>(d, i);
+#pragma unroll
+        for (int e = 0; e < PK; ++e) xv.v[e] = smulv(xv.v[e], dv.v[e]);
+        stp<T, PK>(out, i, xv);
+    }
+};
+template <class V>
+struct DiagInvF {  // precond.rs:22-24  diag_inv = one / v
+    const V *d; V *o;
+    template <int PK> __device__ __forceinline__ void run(int64_t i) const {
+#pragma unroll
+        for (int e = 0; e < PK; ++e) o[i * PK + e] = sinv(d[i * PK + e]);
+    }
+};
+
+template <int PK, class F>
+__global__ __launch_bounds__(BLOCK) void ew_kernel(int64_t n, F f) {
+    SPRS_FOREACH_PACK(n, PK, i) f.template run<PK>(i);
+    if (PK > 1) {
+        int64_t i = (n / PK) * PK + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+        if (i < n) f.template run<1>(i);
+    }
+}
+
+template <class T, class F>
+static int launch_ew(sprs_ctx *c, size_t n, bool all_aligned, F f) {
+    if (n == 0) return SPRS_OK;
+    constexpr int PKW = pack_width<T>::value;
+    const int pk = (all_aligned && PKW > 1) ? PKW : 1;
+    int64_t work = ((int64_t)n / pk + BLOCK - 1) / BLOCK;
+    int g = grid_for(c);
+    if (work < g) g = (int)(work < 1 ? 1 : work);
+    if (pk == PKW && PKW > 1)
+        hipLaunchKernelGGL((ew_kernel<PKW, F>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, f);
+    else
+        hipLaunchKernelGGL((ew_kernel<1, F>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, f);
+    SPRS_HIP_TRY(c, hipGetLastError());
+    return SPRS_OK;
+}
+
+template <class T, class S>
+int launch_axpy(sprs_ctx *c, size_t n, S a, const T *x, T *y) {
+    return launch_ew<T>(c, n, aligned16(x) && aligned16(y), AxpyF<T, S>{a, x, y});
+}
+template <class T>
+int launch_axpby(sprs_ctx *c, size_t n, T a, const T *x, T b, T *y) {
+    return launch_ew<T>(c, n, aligned16(x) && aligned16(y), AxpbyF<T>{a, b, x, y});
+}
+template <class T>
+int launch_scale(sprs_ctx *c, size_t n, T a, T *x) {
+    return launch_ew<T>(c, n, aligned16(x), ScaleF<T>{a, x});
+}
+template <class T>
+int launch_rscale(sprs_ctx *c, size_t n, double a, T *x) {
+    return launch_ew<T>(c, n, aligned16(x), RscaleF<T>{a, x});
+}
+template <class T>
+int launch_conj(sprs_ctx *c, size_t n, const T *in, T *out) {
+    return launch_ew<T>(c, n, aligned16(in) && aligned16(out), ConjF<T>{in, out});
+}
+template <class T, class V>
+int launch_diag_apply(sprs_ctx *c, size_t n, const V *dinv, const T *in, T *out) {
+    return launch_ew<T>(c, n, aligned16(dinv) && aligned16(in) && aligned16(out), DiagApplyF<T, V>{dinv, in, out});
+}
+template <class V>
+int launch_diag_inv(sprs_ctx *c, size_t n, const V *diag, V *dinv) {
+    return launch_ew<V>(c, n, true, DiagInvF<V>{diag, dinv});
+}
+
+// ------------------------------------------------------------------ reductions
+template <class T, bool CONJ, int PK>
+__global__ __launch_bounds__(BLOCK) void dot_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ y,
+                                                    T *__restrict__ part) {
+    __shared__ T smem[NWAVE];
+    T acc = szero<T>();
+    SPRS_FOREACH_PACK(n, PK, i) {
+        auto xv = ldp<T, PK>(x, i); auto yv = ldp<T, PK>(y, i);
+#pragma unroll
+        for (int e = 0; e < PK; ++e) acc = sadd(acc, smul(CONJ ? sconj(xv.v[e]) : xv.v[e], yv.v[e]));
+    }
+    if (PK > 1) {
+        int64_t i = (n / PK) * PK + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+        if (i < n) acc = sadd(acc, smul(CONJ ? sconj(x[i]) : x[i], y[i]));
+    }
+    acc = block_sum(acc, smem);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+template <class T, int PK>
+__global__ __launch_bounds__(BLOCK) void nrm2sq_kernel(int64_t n, const T *__restrict__ x, double *__restrict__ part) {
+    __shared__ double smem[NWAVE];
+    double acc = 0.0;
+    SPRS_FOREACH_PACK(n, PK, i) {
+        auto xv = ldp<T, PK>(x, i);
+#pragma unroll
+        for (int e = 0; e < PK; ++e) acc = acc + ssq(xv.v[e]);
+    }
+    if (PK > 1) {
+        int64_t i = (n / PK) * PK + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+        if (i < n) acc = acc + ssq(x[i]);
+    }
+    acc = block_sum(acc, smem);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+template <class T>
+__global__ __launch_bounds__(BLOCK) void finalize_kernel(const T *__restrict__ part, int P, T *__restrict__ out) {
+    __shared__ T smem[NWAVE];
+    T v = reduce_partials(part, P, smem);
+    if (threadIdx.x == 0) out[0] = v;
+}
+
+template <class T>
+int reduce_partials_host(sprs_ctx *c, const T *part, int P, T *out) {
+    T *d_out = reinterpret_cast<T *>(c->d_scal);
+    hipLaunchKernelGGL((finalize_kernel<T>), dim3(1), dim3(BLOCK), 0, c->stream, part, P, d_out);
+    SPRS_HIP_TRY(c, hipGetLastError());
+    SPRS_HIP_TRY(c, hipMemcpyAsync(c->h_scal, d_out, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_scal, sizeof(T));
+    return SPRS_OK;
+}
+
+static int red_grid(sprs_ctx *c, size_t n, int pk) {
+    int64_t work = ((int64_t)n / pk + BLOCK - 1) / BLOCK;
+    int g = grid_for(c);
+    if (work < g) g = (int)(work < 1 ? 1 : work);
+    return g;
+}
+
+template <class T>
+int dot_host(sprs_ctx *c, size_t n, const T *x, const T *y, bool conj, T *out) {
+    constexpr int PKW = pack_width<T>::value;
+    const bool al = aligned16(x) && aligned16(y);
+    const int pk = (al && PKW > 1) ? PKW : 1;
+    const int g = red_grid(c, n, pk);
+    T *part = reinterpret_cast<T *>(c->d_part);
+#define SPRS_LAUNCH_DOT(CJ, PKV) \
+    hipLaunchKernelGGL((dot_kernel<T, CJ, PKV>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, x, y, part)
+    if (pk == 1) { if (conj) SPRS_LAUNCH_DOT(true, 1); else SPRS_LAUNCH_DOT(false, 1); }
+    else         { if (conj) SPRS_LAUNCH_DOT(true, PKW); else SPRS_LAUNCH_DOT(false, PKW); }
+#undef SPRS_LAUNCH_DOT
+    SPRS_HIP_TRY(c, hipGetLastError());
+    return reduce_partials_host<T>(c, part, g, out);
+}
+
+template <class T>
+int norm2_host(sprs_ctx *c, size_t n, const T *x, double *out) {
+    constexpr int PKW = pack_width<T>::value;
+    const int pk = (aligned16(x) && PKW > 1) ? PKW : 1;
+    const int g = red_grid(c, n, pk);
+    double *part = c->d_part;
+    if (pk == 1) hipLaunchKernelGGL((nrm2sq_kernel<T, 1>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, x, part);
+    else hipLaunchKernelGGL((nrm2sq_kernel<T, PKW>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, x, part);
+    SPRS_HIP_TRY(c, hipGetLastError());
+    double s = 0.0;
+    SPRS_TRY(reduce_partials_host<double>(c, part, g, &s));
+    *out = sqrt(s);  // vecalg.rs:604
+    return SPRS_OK;
+}
+
+// ------------------------------------------------------------------ explicit instantiations
+template int launch_axpy<double, double>(sprs_ctx *, size_t, double, const double *, double *);
+template int launch_axpy<cplx, cplx>(sprs_ctx *, size_t, cplx, const cplx *, cplx *);
+template int launch_axpy<cplx, double>(sprs_ctx *, size_t, double, const cplx *, cplx *);
+template int launch_axpby<double>(sprs_ctx *, size_t, double, const double *, double, double *);
+template int launch_axpby<cplx>(sprs_ctx *, size_t, cplx, const cplx *, cplx, cplx *);
+template int launch_scale<double>(sprs_ctx *, size_t, double, double *);
+template int launch_scale<cplx>(sprs_ctx *, size_t, cplx, cplx *);
+template int launch_rscale<double>(sprs_ctx *, size_t, double, double *);
+template int launch_rscale<cplx>(sprs_ctx *, size_t, double, cplx *);
+template int launch_conj<double>(sprs_ctx *, size_t, const double *, double *);
+template int launch_conj<cplx>(sprs_ctx *, size_t, const cplx *, cplx *);
+template int launch_diag_apply<double, double>(sprs_ctx *, size_t, const double *, const double *, double *);
+template int launch_diag_apply<cplx, double>(sprs_ctx *, size_t, const double *, const cplx *, cplx *);
+template int launch_diag_apply<cplx, cplx>(sprs_ctx *, size_t, const cplx *, const cplx *, cplx *);
+template int launch_diag_inv<double>(sprs_ctx *, size_t, const double *, double *);
+template int launch_diag_inv<cplx>(sprs_ctx *, size_t, const cplx *, cplx *);
+template int dot_host<double>(sprs_ctx *, size_t, const double *, const double *, bool, double *);
+template int dot_host<cplx>(sprs_ctx *, size_t, const cplx *, const cplx *, bool, cplx *);
+template int norm2_host<double>(sprs_ctx *, size_t, const double *, double *);
+template int norm2_host<cplx>(sprs_ctx *, size_t, const cplx *, double *);
+template int reduce_partials_host<double>(sprs_ctx *, const double *, int, double *);
+template int reduce_partials_host<cplx>(sprs_ctx *, const cplx *, int, cplx *);
+
+}  // namespace sprs

@@ -1,0 +1,670 @@
+// extern "C" surface of libsprsolve_hip.so — see include/sprsolve_hip.h for the contract and
+// the reference interface each entry point replaces.  Nothing here throws.
+#include <new>
+#include <string>
+
+#include "krylov.hpp"
+
+using namespace sprs;
+
+static_assert(sizeof(sprs_c64) == sizeof(cplx), "Complex<f64> layout");
+
+#define SPRS_GUARD_BEGIN try {
+#define SPRS_GUARD_END                         \
+    }                                          \
+    catch (const std::bad_alloc &) {           \
+        return SPRS_ERR_HIP;                   \
+    }                                          \
+    catch (...) {                              \
+        return SPRS_ERR_HIP;                   \
+    }
+
+extern "C" {
+
+// ------------------------------------------------------------------------------ context
+int sprs_version(void) { return 100; }
+
+const char *sprs_status_str(int s) {
+    switch (s) {
+        case SPRS_OK: return "Ok";
+        case SPRS_INCOMPATIBLE_RHS_SIZE: return "Incompatible input matrix format: Input vec dimension doesn't match the matrix size";
+        case SPRS_INCOMPATIBLE_X_SIZE: return "Incompatible input matrix format: Input and output vec dimension do not match";
+        case SPRS_INSUFFICIENT_ITER: return "Insufficient interation #";
+        case SPRS_BREAKDOWN: return "Solver break down";
+        case SPRS_INVALID_PRECOND: return "Invalid preconditioner";
+        case SPRS_DIM_MISMATCH: return "Dimension mismatch";
+        case SPRS_INVALID_ARGUMENT: return "Invalid argument";
+        case SPRS_ERR_HIP: return "HIP runtime error";
+        case SPRS_ERR_RCCL: return "RCCL error";
+        case SPRS_ERR_NO_DEVICE: return "No usable GPU device";
+        default: return "Unknown status";
+    }
+}
+
+int sprs_ctx_create(int device, void *stream, sprs_ctx **out) {
+    SPRS_GUARD_BEGIN
+    if (!out) return SPRS_INVALID_ARGUMENT;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SPRS_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return SPRS_ERR_NO_DEVICE;
+    sprs_ctx *c = new sprs_ctx();
+    c->device = device;
+    auto fail = [&](int st) { delete c; return st; };
+    if (hipSetDevice(device) != hipSuccess) return fail(SPRS_ERR_NO_DEVICE);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(SPRS_ERR_HIP);
+        c->own_stream = true;
+    }
+    // 4 workgroups of 256 lanes per CU: enough loads in flight to saturate HBM while the
+    // number of reduction partials (== grid) stays small enough for the fused prologues
+    c->grid = ((c->num_cu * 4 + 7) / 8) * 8;
+    if (c->grid > MAX_GRID) c->grid = MAX_GRID;
+    if (hipMalloc((void **)&c->d_part, sizeof(double) * 2 * MAX_GRID) != hipSuccess) return fail(SPRS_ERR_HIP);
+    if (hipMalloc((void **)&c->d_scal, 256) != hipSuccess) return fail(SPRS_ERR_HIP);
+    if (hipHostMalloc((void **)&c->h_scal, 256, hipHostMallocDefault) != hipSuccess) return fail(SPRS_ERR_HIP);
+    *out = c;
+    return SPRS_OK;
+    SPRS_GUARD_END
+}
+
+int sprs_ctx_destroy(sprs_ctx *c) {
+    if (!c) return SPRS_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_part) (void)hipFree(c->d_part);
+    if (c->d_scal) (void)hipFree(c->d_scal);
+    if (c->h_scal) (void)hipHostFree(c->h_scal);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SPRS_OK;
+}
+
+int sprs_ctx_sync(sprs_ctx *c) {
+    if (!c) return SPRS_INVALID_ARGUMENT;
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPRS_OK;
+}
+
+const char *sprs_last_error(const sprs_ctx *c) { return c ? c->err : "null context"; }
+
+int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
+    if (!c || !key) return SPRS_INVALID_ARGUMENT;
+    std::string k(key);
+    if (k == "grid") { if (value < 8 || value > MAX_GRID) return SPRS_INVALID_ARGUMENT; c->grid = (int)(value & ~7); }
+    else if (k == "xcd_chunk") c->xcd_chunk = value ? 1 : 0;
+    else if (k == "poll") { if (value < 1) return SPRS_INVALID_ARGUMENT; c->poll = (int)value; }
+    else return SPRS_INVALID_ARGUMENT;
+    return SPRS_OK;
+}
+int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
+    if (!c || !key) return -1;
+    std::string k(key);
+    if (k == "grid") return c->grid;
+    if (k == "xcd_chunk") return c->xcd_chunk;
+    if (k == "poll") return c->poll;
+    if (k == "num_cu") return c->num_cu;
+    if (k == "device") return c->device;
+    return -1;
+}
+
+int sprs_malloc(sprs_ctx *c, size_t bytes, void **dev_out) {
+    if (!c || !dev_out) return SPRS_INVALID_ARGUMENT;
+    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    SPRS_HIP_TRY(c, hipMalloc(dev_out, bytes ? bytes : 16));
+    return SPRS_OK;
+}
+int sprs_free(sprs_ctx *c, void *dev) {
+    if (!c) return SPRS_INVALID_ARGUMENT;
+    if (!dev) return SPRS_OK;
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    SPRS_HIP_TRY(c, hipFree(dev));
+    return SPRS_OK;
+}
+int sprs_memcpy_h2d(sprs_ctx *c, void *d, const void *h, size_t bytes) {
+    if (!c) return SPRS_INVALID_ARGUMENT;
+    SPRS_HIP_TRY(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPRS_OK;
+}
+int sprs_memcpy_d2h(sprs_ctx *c, void *h, const void *d, size_t bytes) {
+    if (!c) return SPRS_INVALID_ARGUMENT;
+    SPRS_HIP_TRY(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPRS_OK;
+}
+int sprs_memcpy_d2d(sprs_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c) return SPRS_INVALID_ARGUMENT;
+    SPRS_HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return SPRS_OK;
+}
+int sprs_memset_zero(sprs_ctx *c, void *d, size_t bytes) {
+    if (!c) return SPRS_INVALID_ARGUMENT;
+    SPRS_HIP_TRY(c, hipMemsetAsync(d, 0, bytes, c->stream));
+    return SPRS_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------ CSR operator
+namespace {
+
+template <class I>
+bool narrow_check(const I *a, int64_t n, int64_t lo, int64_t hi) {
+    for (int64_t i = 0; i < n; ++i)
+        if ((int64_t)a[i] < lo || (int64_t)a[i] > hi) return false;
+    return true;
+}
+
+// Build the device CSR from host arrays (CSR or CSC, any integer index type).
+template <class T, class I>
+int csr_create_host(sprs_ctx *c, int64_t nrows, int64_t ncols, int64_t nnz, const I *ptr, const I *idx, const T *val,
+                    int storage_csc, sprs_csr **out) {
+    if (!c || !out || nrows < 0 || ncols < 0 || nnz < 0) return SPRS_INVALID_ARGUMENT;
+    if (!ptr || (nnz > 0 && (!idx || !val))) return SPRS_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (nrows >= INT32_MAX || ncols >= INT32_MAX || nnz >= INT32_MAX) return SPRS_INVALID_ARGUMENT;
+    const int64_t nouter = storage_csc ? ncols : nrows, ninner = storage_csc ? nrows : ncols;
+    // validate: the kernels index x and y with these arrays
+    if ((int64_t)ptr[0] != 0 || (int64_t)ptr[nouter] != nnz) return SPRS_INVALID_ARGUMENT;
+    for (int64_t i = 0; i < nouter; ++i)
+        if ((int64_t)ptr[i + 1] < (int64_t)ptr[i]) return SPRS_INVALID_ARGUMENT;
+    if (!narrow_check(idx, nnz, 0, ninner - 1)) return SPRS_INVALID_ARGUMENT;
+
+    std::vector<int32_t> rp((size_t)nrows + 1), ci((size_t)nnz);
+    std::vector<T> vv;
+    const T *vsrc = val;
+    if (!storage_csc) {
+        for (int64_t i = 0; i <= nrows; ++i) rp[i] = (int32_t)ptr[i];
+        for (int64_t k = 0; k < nnz; ++k) ci[k] = (int32_t)idx[k];
+    } else {
+        // CSC -> CSR, stable in column order: per row the terms keep the order in which the
+        // reference's serial scatter (mat.rs:135-141) adds them, so y has the same bits.
+        vv.resize((size_t)nnz);
+        std::fill(rp.begin(), rp.end(), 0);
+        for (int64_t k = 0; k < nnz; ++k) rp[(size_t)idx[k] + 1]++;
+        for (int64_t i = 0; i < nrows; ++i) rp[i + 1] += rp[i];
+        std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
+        for (int64_t col = 0; col < ncols; ++col)
+            for (int64_t k = (int64_t)ptr[col]; k < (int64_t)ptr[col + 1]; ++k) {
+                int32_t dst = fill[(size_t)idx[k]]++;
+                ci[dst] = (int32_t)col;
+                vv[dst] = val[k];
+            }
+        vsrc = vv.data();
+    }
+    sprs_csr *A = new sprs_csr();
+    A->ctx = c; A->is_complex = is_complex<T>::value ? 1 : 0;
+    A->nrows = nrows; A->ncols = ncols; A->nnz = nnz; A->owns_arrays = true;
+    auto fail = [&](int st) { sprs_csr_destroy(A); return st; };
+    if (hipSetDevice(c->device) != hipSuccess) return fail(SPRS_ERR_HIP);
+    if (hipMalloc((void **)&A->row_ptr, sizeof(int32_t) * ((size_t)nrows + 1)) != hipSuccess) return fail(SPRS_ERR_HIP);
+    if (hipMalloc((void **)&A->col_idx, sizeof(int32_t) * (size_t)(nnz ? nnz : 1)) != hipSuccess) return fail(SPRS_ERR_HIP);
+    if (hipMalloc((void **)&A->val, sizeof(T) * (size_t)(nnz ? nnz : 1)) != hipSuccess) return fail(SPRS_ERR_HIP);
+    if (hipMemcpyAsync(A->row_ptr, rp.data(), sizeof(int32_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail(SPRS_ERR_HIP);
+    if (nnz) {
+        if (hipMemcpyAsync(A->col_idx, ci.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail(SPRS_ERR_HIP);
+        if (hipMemcpyAsync(A->val, vsrc, sizeof(T) * (size_t)nnz, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail(SPRS_ERR_HIP);
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(SPRS_ERR_HIP);
+    int st = build_rowblocks(A, rp.data());
+    if (st != SPRS_OK) return fail(st);
+    *out = A;
+    return SPRS_OK;
+}
+
+template <class T>
+int csr_create_dev(sprs_ctx *c, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *d_rp, const int32_t *d_ci,
+                   const T *d_val, int adopt, sprs_csr **out) {
+    if (!c || !out || !d_rp || nrows < 0 || ncols < 0 || nnz < 0) return SPRS_INVALID_ARGUMENT;
+    if (nnz > 0 && (!d_ci || !d_val)) return SPRS_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (nrows >= INT32_MAX || ncols >= INT32_MAX || nnz >= INT32_MAX) return SPRS_INVALID_ARGUMENT;
+    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<int32_t> rp((size_t)nrows + 1);
+    SPRS_HIP_TRY(c, hipMemcpyAsync(rp.data(), d_rp, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, c->stream));
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (rp[0] != 0 || rp[(size_t)nrows] != nnz) return SPRS_INVALID_ARGUMENT;
+    for (int64_t i = 0; i < nrows; ++i)
+        if (rp[i + 1] < rp[i]) return SPRS_INVALID_ARGUMENT;
+    sprs_csr *A = new sprs_csr();
+    A->ctx = c; A->is_complex = is_complex<T>::value ? 1 : 0;
+    A->nrows = nrows; A->ncols = ncols; A->nnz = nnz;
+    auto fail = [&](int st) { sprs_csr_destroy(A); return st; };
+    if (adopt) {
+        A->owns_arrays = false;
+        A->row_ptr = const_cast<int32_t *>(d_rp); A->col_idx = const_cast<int32_t *>(d_ci);
+        A->val = const_cast<T *>(d_val);
+    } else {
+        A->owns_arrays = true;
+        if (hipMalloc((void **)&A->row_ptr, sizeof(int32_t) * ((size_t)nrows + 1)) != hipSuccess) return fail(SPRS_ERR_HIP);
+        if (hipMalloc((void **)&A->col_idx, sizeof(int32_t) * (size_t)(nnz ? nnz : 1)) != hipSuccess) return fail(SPRS_ERR_HIP);
+        if (hipMalloc((void **)&A->val, sizeof(T) * (size_t)(nnz ? nnz : 1)) != hipSuccess) return fail(SPRS_ERR_HIP);
+        if (hipMemcpyAsync(A->row_ptr, d_rp, sizeof(int32_t) * ((size_t)nrows + 1), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return fail(SPRS_ERR_HIP);
+        if (nnz) {
+            if (hipMemcpyAsync(A->col_idx, d_ci, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return fail(SPRS_ERR_HIP);
+            if (hipMemcpyAsync(A->val, d_val, sizeof(T) * (size_t)nnz, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return fail(SPRS_ERR_HIP);
+        }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(SPRS_ERR_HIP);
+    }
+    int st = build_rowblocks(A, rp.data());
+    if (st != SPRS_OK) return fail(st);
+    *out = A;
+    return SPRS_OK;
+}
+
+template <class T>
+int ensure_tmp(const sprs_csr *Ac) {
+    sprs_csr *A = const_cast<sprs_csr *>(Ac);
+    sprs_ctx *c = A->ctx;
+    const size_t m = (size_t)(A->nrows > A->ncols ? A->nrows : A->ncols) + 2;
+    if (!A->x_tmp) SPRS_HIP_TRY(c, hipMalloc(&A->x_tmp, sizeof(T) * m));
+    if (!A->y_tmp) SPRS_HIP_TRY(c, hipMalloc(&A->y_tmp, sizeof(T) * m));
+    if (!A->part) SPRS_HIP_TRY(c, hipMalloc((void **)&A->part, sizeof(double) * 2 * MAX_GRID));
+    return SPRS_OK;
+}
+
+// MatVecMul::mul_vec / mul_vec_dot over host slices (mat.rs:49-64)
+template <class T>
+int mul_vec_host(const sprs_csr *A, const T *x, size_t x_len, T *y, size_t y_len, T *dot_out) {
+    if (!A || !x || !y) return SPRS_INVALID_ARGUMENT;
+    if (A->is_complex != (is_complex<T>::value ? 1 : 0)) return SPRS_INVALID_ARGUMENT;
+    if ((size_t)A->ncols != x_len || x_len != y_len) return SPRS_DIM_MISMATCH;   // mat.rs:50-52
+    sprs_ctx *c = A->ctx;
+    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    SPRS_TRY(ensure_tmp<T>(A));
+    T *dx = (T *)A->x_tmp, *dy = (T *)A->y_tmp;
+    SPRS_HIP_TRY(c, hipMemcpyAsync(dx, x, sizeof(T) * x_len, hipMemcpyHostToDevice, c->stream));
+    T *part = (T *)A->part;
+    SPRS_TRY(launch_spmv<T>(A, dx, dy, dot_out ? 1 : 0, dx, part, nullptr, nullptr));
+    const size_t ncopy = (size_t)A->nrows < y_len ? (size_t)A->nrows : y_len;
+    SPRS_HIP_TRY(c, hipMemcpyAsync(y, dy, sizeof(T) * ncopy, hipMemcpyDeviceToHost, c->stream));
+    if (dot_out) SPRS_TRY(reduce_partials_host<T>(c, part, spmv_num_partials(A), dot_out));   // mat.rs:151
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPRS_OK;
+}
+
+template <class T>
+int mul_vec_dev(const sprs_csr *A, const T *dx, T *dy, T *dot_out) {
+    if (!A || !dx || !dy) return SPRS_INVALID_ARGUMENT;
+    if (A->is_complex != (is_complex<T>::value ? 1 : 0)) return SPRS_INVALID_ARGUMENT;
+    sprs_ctx *c = A->ctx;
+    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    if (!dot_out) return launch_spmv<T>(A, dx, dy, 0, nullptr, nullptr, nullptr, nullptr);
+    SPRS_TRY(ensure_tmp<T>(A));
+    T *part = (T *)A->part;
+    SPRS_TRY(launch_spmv<T>(A, dx, dy, 1, dx, part, nullptr, nullptr));
+    return reduce_partials_host<T>(c, part, spmv_num_partials(A), dot_out);
+}
+
+template <class T>
+int mul_vec_timed(const sprs_csr *A, const T *dx, T *dy, int reps, double *ms) {
+    if (!A || !dx || !dy || !ms || reps < 1) return SPRS_INVALID_ARGUMENT;
+    if (A->is_complex != (is_complex<T>::value ? 1 : 0)) return SPRS_INVALID_ARGUMENT;
+    sprs_ctx *c = A->ctx;
+    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    hipEvent_t e0, e1;
+    SPRS_HIP_TRY(c, hipEventCreate(&e0));
+    SPRS_HIP_TRY(c, hipEventCreate(&e1));
+    SPRS_HIP_TRY(c, hipEventRecord(e0, c->stream));
+    for (int i = 0; i < reps; ++i) SPRS_TRY(launch_spmv<T>(A, dx, dy, 0, nullptr, nullptr, nullptr, nullptr));
+    SPRS_HIP_TRY(c, hipEventRecord(e1, c->stream));
+    SPRS_HIP_TRY(c, hipEventSynchronize(e1));
+    float t = 0.f;
+    SPRS_HIP_TRY(c, hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms = (double)t / reps;
+    return SPRS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sprs_csr_create_d(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int32_t *rp, const int32_t *ci, const double *v, int csc, sprs_csr **out) {
+    SPRS_GUARD_BEGIN return csr_create_host<double, int32_t>(c, nr, nc, nnz, rp, ci, v, csc, out); SPRS_GUARD_END
+}
+int sprs_csr_create_z(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int32_t *rp, const int32_t *ci, const sprs_c64 *v, int csc, sprs_csr **out) {
+    SPRS_GUARD_BEGIN return csr_create_host<cplx, int32_t>(c, nr, nc, nnz, rp, ci, (const cplx *)v, csc, out); SPRS_GUARD_END
+}
+int sprs_csr_create_i64_d(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int64_t *rp, const int64_t *ci, const double *v, int csc, sprs_csr **out) {
+    SPRS_GUARD_BEGIN return csr_create_host<double, int64_t>(c, nr, nc, nnz, rp, ci, v, csc, out); SPRS_GUARD_END
+}
+int sprs_csr_create_i64_z(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int64_t *rp, const int64_t *ci, const sprs_c64 *v, int csc, sprs_csr **out) {
+    SPRS_GUARD_BEGIN return csr_create_host<cplx, int64_t>(c, nr, nc, nnz, rp, ci, (const cplx *)v, csc, out); SPRS_GUARD_END
+}
+int sprs_csr_create_dev_d(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int32_t *rp, const int32_t *ci, const double *v, int adopt, sprs_csr **out) {
+    SPRS_GUARD_BEGIN return csr_create_dev<double>(c, nr, nc, nnz, rp, ci, v, adopt, out); SPRS_GUARD_END
+}
+int sprs_csr_create_dev_z(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int32_t *rp, const int32_t *ci, const sprs_c64 *v, int adopt, sprs_csr **out) {
+    SPRS_GUARD_BEGIN return csr_create_dev<cplx>(c, nr, nc, nnz, rp, ci, (const cplx *)v, adopt, out); SPRS_GUARD_END
+}
+
+int sprs_csr_destroy(sprs_csr *A) {
+    if (!A) return SPRS_OK;
+    if (A->ctx) { (void)hipSetDevice(A->ctx->device); (void)hipStreamSynchronize(A->ctx->stream); }
+    if (A->owns_arrays) {
+        if (A->row_ptr) (void)hipFree(A->row_ptr);
+        if (A->col_idx) (void)hipFree(A->col_idx);
+        if (A->val) (void)hipFree(A->val);
+    }
+    if (A->rowblk) (void)hipFree(A->rowblk);
+    if (A->x_tmp) (void)hipFree(A->x_tmp);
+    if (A->y_tmp) (void)hipFree(A->y_tmp);
+    if (A->part) (void)hipFree(A->part);
+    delete A;
+    return SPRS_OK;
+}
+int64_t sprs_csr_rows(const sprs_csr *A) { return A ? A->nrows : -1; }
+int64_t sprs_csr_cols(const sprs_csr *A) { return A ? A->ncols : -1; }
+int64_t sprs_csr_nnz(const sprs_csr *A) { return A ? A->nnz : -1; }
+
+int sprs_mul_vec_d(const sprs_csr *A, const double *x, size_t xl, double *y, size_t yl) {
+    SPRS_GUARD_BEGIN return mul_vec_host<double>(A, x, xl, y, yl, nullptr); SPRS_GUARD_END
+}
+int sprs_mul_vec_z(const sprs_csr *A, const sprs_c64 *x, size_t xl, sprs_c64 *y, size_t yl) {
+    SPRS_GUARD_BEGIN return mul_vec_host<cplx>(A, (const cplx *)x, xl, (cplx *)y, yl, nullptr); SPRS_GUARD_END
+}
+int sprs_mul_vec_dot_d(const sprs_csr *A, const double *x, size_t xl, double *y, size_t yl, double *d) {
+    SPRS_GUARD_BEGIN if (!d) return SPRS_INVALID_ARGUMENT; return mul_vec_host<double>(A, x, xl, y, yl, d); SPRS_GUARD_END
+}
+int sprs_mul_vec_dot_z(const sprs_csr *A, const sprs_c64 *x, size_t xl, sprs_c64 *y, size_t yl, sprs_c64 *d) {
+    SPRS_GUARD_BEGIN if (!d) return SPRS_INVALID_ARGUMENT; return mul_vec_host<cplx>(A, (const cplx *)x, xl, (cplx *)y, yl, (cplx *)d); SPRS_GUARD_END
+}
+int sprs_mul_vec_dev_d(const sprs_csr *A, const double *x, double *y) { return mul_vec_dev<double>(A, x, y, nullptr); }
+int sprs_mul_vec_dev_z(const sprs_csr *A, const sprs_c64 *x, sprs_c64 *y) { return mul_vec_dev<cplx>(A, (const cplx *)x, (cplx *)y, nullptr); }
+int sprs_mul_vec_dot_dev_d(const sprs_csr *A, const double *x, double *y, double *d) {
+    if (!d) return SPRS_INVALID_ARGUMENT;
+    return mul_vec_dev<double>(A, x, y, d);
+}
+int sprs_mul_vec_dot_dev_z(const sprs_csr *A, const sprs_c64 *x, sprs_c64 *y, sprs_c64 *d) {
+    if (!d) return SPRS_INVALID_ARGUMENT;
+    return mul_vec_dev<cplx>(A, (const cplx *)x, (cplx *)y, (cplx *)d);
+}
+int sprs_mul_vec_dev_timed_d(const sprs_csr *A, const double *x, double *y, int reps, double *ms) { return mul_vec_timed<double>(A, x, y, reps, ms); }
+int sprs_mul_vec_dev_timed_z(const sprs_csr *A, const sprs_c64 *x, sprs_c64 *y, int reps, double *ms) {
+    return mul_vec_timed<cplx>(A, (const cplx *)x, (cplx *)y, reps, ms);
+}
+
+// ------------------------------------------------------------------------------ vecalg
+#define SPRS_CHK(c) do { if (!(c)) return SPRS_INVALID_ARGUMENT; } while (0)
+static inline cplx cz(sprs_c64 a) { return cplx{a.re, a.im}; }
+
+int sprs_dot_d(sprs_ctx *c, size_t n, const double *x, const double *y, double *o) { SPRS_CHK(c && o); return dot_host<double>(c, n, x, y, false, o); }
+int sprs_dot_z(sprs_ctx *c, size_t n, const sprs_c64 *x, const sprs_c64 *y, sprs_c64 *o) { SPRS_CHK(c && o); return dot_host<cplx>(c, n, (const cplx *)x, (const cplx *)y, false, (cplx *)o); }
+int sprs_conj_dot_d(sprs_ctx *c, size_t n, const double *x, const double *y, double *o) { SPRS_CHK(c && o); return dot_host<double>(c, n, x, y, true, o); }
+int sprs_conj_dot_z(sprs_ctx *c, size_t n, const sprs_c64 *x, const sprs_c64 *y, sprs_c64 *o) { SPRS_CHK(c && o); return dot_host<cplx>(c, n, (const cplx *)x, (const cplx *)y, true, (cplx *)o); }
+int sprs_norm2_d(sprs_ctx *c, size_t n, const double *x, double *o) { SPRS_CHK(c && o); return norm2_host<double>(c, n, x, o); }
+int sprs_norm2_z(sprs_ctx *c, size_t n, const sprs_c64 *x, double *o) { SPRS_CHK(c && o); return norm2_host<cplx>(c, n, (const cplx *)x, o); }
+int sprs_scale_d(sprs_ctx *c, size_t n, double a, double *x) { SPRS_CHK(c); return launch_scale<double>(c, n, a, x); }
+int sprs_scale_z(sprs_ctx *c, size_t n, sprs_c64 a, sprs_c64 *x) { SPRS_CHK(c); return launch_scale<cplx>(c, n, cz(a), (cplx *)x); }
+int sprs_rscale_d(sprs_ctx *c, size_t n, double a, double *x) { SPRS_CHK(c); return launch_rscale<double>(c, n, a, x); }
+int sprs_rscale_z(sprs_ctx *c, size_t n, double a, sprs_c64 *x) { SPRS_CHK(c); return launch_rscale<cplx>(c, n, a, (cplx *)x); }
+int sprs_conj_d(sprs_ctx *c, size_t n, const double *in, double *out) { SPRS_CHK(c); return launch_conj<double>(c, n, in, out); }
+int sprs_conj_z(sprs_ctx *c, size_t n, const sprs_c64 *in, sprs_c64 *out) { SPRS_CHK(c); return launch_conj<cplx>(c, n, (const cplx *)in, (cplx *)out); }
+int sprs_axpy_d(sprs_ctx *c, size_t n, double a, const double *x, double *y) { SPRS_CHK(c); return launch_axpy<double, double>(c, n, a, x, y); }
+int sprs_axpy_z(sprs_ctx *c, size_t n, sprs_c64 a, const sprs_c64 *x, sprs_c64 *y) { SPRS_CHK(c); return launch_axpy<cplx, cplx>(c, n, cz(a), (const cplx *)x, (cplx *)y); }
+int sprs_axpy_zd(sprs_ctx *c, size_t n, double a, const sprs_c64 *x, sprs_c64 *y) { SPRS_CHK(c); return launch_axpy<cplx, double>(c, n, a, (const cplx *)x, (cplx *)y); }
+int sprs_axpby_d(sprs_ctx *c, size_t n, double a, const double *x, double b, double *y) { SPRS_CHK(c); return launch_axpby<double>(c, n, a, x, b, y); }
+int sprs_axpby_z(sprs_ctx *c, size_t n, sprs_c64 a, const sprs_c64 *x, sprs_c64 b, sprs_c64 *y) { SPRS_CHK(c); return launch_axpby<cplx>(c, n, cz(a), (const cplx *)x, cz(b), (cplx *)y); }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------ Jacobi preconditioner
+namespace {
+template <class V>
+int diag_create(sprs_ctx *c, size_t n, const V *diag_host, int t_complex, sprs_diag **out) {
+    if (!c || !out || (!diag_host && n)) return SPRS_INVALID_ARGUMENT;
+    *out = nullptr;
+    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    sprs_diag *P = new sprs_diag();
+    P->ctx = c; P->n = n; P->t_complex = t_complex; P->v_complex = is_complex<V>::value ? 1 : 0;
+    auto fail = [&](int st) { sprs_diag_precond_destroy(P); return st; };
+    V *tmp = nullptr;
+    const size_t np = ((n + 31) & ~(size_t)31) + 32;
+    if (hipMalloc(&P->dinv, sizeof(V) * np) != hipSuccess) return fail(SPRS_ERR_HIP);
+    if (hipMalloc((void **)&tmp, sizeof(V) * np) != hipSuccess) return fail(SPRS_ERR_HIP);
+    int st = SPRS_OK;
+    if (hipMemcpyAsync(tmp, diag_host, sizeof(V) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) st = SPRS_ERR_HIP;
+    if (st == SPRS_OK) st = launch_diag_inv<V>(c, n, tmp, (V *)P->dinv);   // precond.rs:22-24
+    if (st == SPRS_OK && hipStreamSynchronize(c->stream) != hipSuccess) st = SPRS_ERR_HIP;
+    (void)hipFree(tmp);
+    if (st != SPRS_OK) return fail(st);
+    *out = P;
+    return SPRS_OK;
+}
+
+template <class T>
+int diag_apply_dev(const sprs_diag *P, const T *in, T *out) {
+    if (!P || !in || !out) return SPRS_INVALID_ARGUMENT;
+    if (P->t_complex != (is_complex<T>::value ? 1 : 0)) return SPRS_INVALID_ARGUMENT;
+    if (P->v_complex) {
+        if constexpr (is_complex<T>::value) return launch_diag_apply<cplx, cplx>(P->ctx, P->n, (const cplx *)P->dinv, in, out);
+        else return SPRS_INVALID_ARGUMENT;
+    }
+    return launch_diag_apply<T, double>(P->ctx, P->n, (const double *)P->dinv, in, out);
+}
+
+template <class T>
+int diag_apply_host(const sprs_diag *Pc, const T *in, size_t in_len, T *out, size_t out_len) {
+    if (!Pc || !in || !out) return SPRS_INVALID_ARGUMENT;
+    if (Pc->n != in_len || Pc->n != out_len) return SPRS_DIM_MISMATCH;     // precond.rs:39-41
+    sprs_diag *P = const_cast<sprs_diag *>(Pc);
+    sprs_ctx *c = P->ctx;
+    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    if (!P->in_tmp) SPRS_HIP_TRY(c, hipMalloc(&P->in_tmp, sizeof(T) * (P->n + 2)));
+    if (!P->out_tmp) SPRS_HIP_TRY(c, hipMalloc(&P->out_tmp, sizeof(T) * (P->n + 2)));
+    SPRS_HIP_TRY(c, hipMemcpyAsync(P->in_tmp, in, sizeof(T) * in_len, hipMemcpyHostToDevice, c->stream));
+    SPRS_TRY(diag_apply_dev<T>(P, (const T *)P->in_tmp, (T *)P->out_tmp));
+    SPRS_HIP_TRY(c, hipMemcpyAsync(out, P->out_tmp, sizeof(T) * out_len, hipMemcpyDeviceToHost, c->stream));
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPRS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int sprs_diag_precond_create_d(sprs_ctx *c, size_t n, const double *d, sprs_diag **out) { SPRS_GUARD_BEGIN return diag_create<double>(c, n, d, 0, out); SPRS_GUARD_END }
+int sprs_diag_precond_create_zd(sprs_ctx *c, size_t n, const double *d, sprs_diag **out) { SPRS_GUARD_BEGIN return diag_create<double>(c, n, d, 1, out); SPRS_GUARD_END }
+int sprs_diag_precond_create_z(sprs_ctx *c, size_t n, const sprs_c64 *d, sprs_diag **out) { SPRS_GUARD_BEGIN return diag_create<cplx>(c, n, (const cplx *)d, 1, out); SPRS_GUARD_END }
+int sprs_diag_precond_destroy(sprs_diag *P) {
+    if (!P) return SPRS_OK;
+    if (P->ctx) { (void)hipSetDevice(P->ctx->device); (void)hipStreamSynchronize(P->ctx->stream); }
+    if (P->dinv) (void)hipFree(P->dinv);
+    if (P->in_tmp) (void)hipFree(P->in_tmp);
+    if (P->out_tmp) (void)hipFree(P->out_tmp);
+    delete P;
+    return SPRS_OK;
+}
+int sprs_diag_mul_vec_d(const sprs_diag *P, const double *in, size_t il, double *out, size_t ol) { SPRS_GUARD_BEGIN return diag_apply_host<double>(P, in, il, out, ol); SPRS_GUARD_END }
+int sprs_diag_mul_vec_z(const sprs_diag *P, const sprs_c64 *in, size_t il, sprs_c64 *out, size_t ol) { SPRS_GUARD_BEGIN return diag_apply_host<cplx>(P, (const cplx *)in, il, (cplx *)out, ol); SPRS_GUARD_END }
+int sprs_diag_mul_vec_dev_d(const sprs_diag *P, const double *in, double *out) { return diag_apply_dev<double>(P, in, out); }
+int sprs_diag_mul_vec_dev_z(const sprs_diag *P, const sprs_c64 *in, sprs_c64 *out) { return diag_apply_dev<cplx>(P, (const cplx *)in, (cplx *)out); }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------ solvers
+namespace {
+
+template <class H, template <class> class S, class Mk>
+int solver_create(const sprs_csr *A, size_t size, int want_complex, H **out, Mk mk) {
+    if (!A || !out) return SPRS_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (A->is_complex != want_complex) return SPRS_INVALID_ARGUMENT;
+    // the solvers multiply size-vectors by A in place: the reference leaves a mismatch to UB
+    // (mul_vec_unchecked); we refuse it here rather than index out of bounds on the GPU
+    if ((int64_t)size != A->nrows || (int64_t)size != A->ncols) return SPRS_DIM_MISMATCH;
+    H *h = new H();
+    h->is_complex = want_complex;
+    int st;
+    if (want_complex) { auto *s = new S<cplx>(); h->impl = s; st = mk(s); }
+    else { auto *s = new S<double>(); h->impl = s; st = mk(s); }
+    if (st != SPRS_OK) {
+        if (want_complex) { auto *s = (S<cplx> *)h->impl; s->destroy(); delete s; }
+        else { auto *s = (S<double> *)h->impl; s->destroy(); delete s; }
+        delete h;
+        return st;
+    }
+    *out = h;
+    return SPRS_OK;
+}
+
+template <class H, template <class> class S>
+int solver_destroy(H *h) {
+    if (!h) return SPRS_OK;
+    if (h->is_complex) { auto *s = (S<cplx> *)h->impl; (void)hipStreamSynchronize(s->ctx->stream); s->destroy(); delete s; }
+    else { auto *s = (S<double> *)h->impl; (void)hipStreamSynchronize(s->ctx->stream); s->destroy(); delete s; }
+    delete h;
+    return SPRS_OK;
+}
+
+// host-slice solve: copy rhs/x in, run the device solve, copy x back
+template <class T, class SolverT>
+int solve_host(SolverT *s, const sprs_diag *P, const T *rhs, size_t rl, T *x, size_t xl, size_t max_iter, double tol,
+               size_t *its, double *res) {
+    if (!s || !rhs || !x) return SPRS_INVALID_ARGUMENT;
+    return s->solve_host(rhs, rl, x, xl, [&](T *drhs, T *dx) {
+        return s->solve_dev(P, drhs, rl, dx, xl, max_iter, tol, its, res);
+    });
+}
+
+// device-vector solve; stage through aligned buffers when the caller's vectors are not 16-byte aligned
+template <class T, class SolverT>
+int solve_dev(SolverT *s, const sprs_diag *P, const T *rhs, size_t rl, T *x, size_t xl, size_t max_iter, double tol,
+              size_t *its, double *res) {
+    if (!s || !rhs || !x) return SPRS_INVALID_ARGUMENT;
+    if (rl != s->n) return SPRS_INCOMPATIBLE_RHS_SIZE;
+    if (xl != s->n) return SPRS_INCOMPATIBLE_X_SIZE;
+    sprs_ctx *c = s->ctx;
+    const bool al = ((reinterpret_cast<uintptr_t>(rhs) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+    if (al) return s->solve_dev(P, rhs, rl, x, xl, max_iter, tol, its, res);
+    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    if (!s->rhs_buf) SPRS_HIP_TRY(c, hipMalloc((void **)&s->rhs_buf, sizeof(T) * s->stride));
+    if (!s->x_buf) SPRS_HIP_TRY(c, hipMalloc((void **)&s->x_buf, sizeof(T) * s->stride));
+    SPRS_HIP_TRY(c, hipMemcpyAsync(s->rhs_buf, rhs, sizeof(T) * rl, hipMemcpyDeviceToDevice, c->stream));
+    SPRS_HIP_TRY(c, hipMemcpyAsync(s->x_buf, x, sizeof(T) * xl, hipMemcpyDeviceToDevice, c->stream));
+    int st = s->solve_dev(P, s->rhs_buf, rl, s->x_buf, xl, max_iter, tol, its, res);
+    if (st >= SPRS_ERR_HIP) return st;
+    SPRS_HIP_TRY(c, hipMemcpyAsync(x, s->x_buf, sizeof(T) * xl, hipMemcpyDeviceToDevice, c->stream));
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return st;
+}
+
+template <class T, class H> BicgStab<T> *bi(H *h) { return (h && h->is_complex == (is_complex<T>::value ? 1 : 0)) ? (BicgStab<T> *)h->impl : nullptr; }
+template <class T, class H> MinRes<T> *mr(H *h) { return (h && h->is_complex == (is_complex<T>::value ? 1 : 0)) ? (MinRes<T> *)h->impl : nullptr; }
+
+}  // namespace
+
+extern "C" {
+
+int sprs_bicgstab_create_d(const sprs_csr *A, size_t n, sprs_bicgstab **out) { SPRS_GUARD_BEGIN return solver_create<sprs_bicgstab, BicgStab>(A, n, 0, out, [&](auto *s) { return s->create(A, n); }); SPRS_GUARD_END }
+int sprs_bicgstab_create_z(const sprs_csr *A, size_t n, sprs_bicgstab **out) { SPRS_GUARD_BEGIN return solver_create<sprs_bicgstab, BicgStab>(A, n, 1, out, [&](auto *s) { return s->create(A, n); }); SPRS_GUARD_END }
+int sprs_bicgstab_destroy(sprs_bicgstab *S) { return solver_destroy<sprs_bicgstab, BicgStab>(S); }
+
+int sprs_bicgstab_solve_d(sprs_bicgstab *S, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN return solve_host<double>(bi<double>(S), nullptr, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+int sprs_bicgstab_solve_z(sprs_bicgstab *S, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN return solve_host<cplx>(bi<cplx>(S), nullptr, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+int sprs_bicgstab_precond_solve_d(sprs_bicgstab *S, const sprs_diag *P, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN if (!P) return SPRS_INVALID_ARGUMENT; return solve_host<double>(bi<double>(S), P, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+int sprs_bicgstab_precond_solve_z(sprs_bicgstab *S, const sprs_diag *P, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN if (!P) return SPRS_INVALID_ARGUMENT; return solve_host<cplx>(bi<cplx>(S), P, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+int sprs_bicgstab_solve_dev_d(sprs_bicgstab *S, const sprs_diag *P, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN return solve_dev<double>(bi<double>(S), P, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+int sprs_bicgstab_solve_dev_z(sprs_bicgstab *S, const sprs_diag *P, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN return solve_dev<cplx>(bi<cplx>(S), P, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+
+int sprs_minres_create_d(const sprs_csr *A, size_t n, sprs_minres **out) { SPRS_GUARD_BEGIN return solver_create<sprs_minres, MinRes>(A, n, 0, out, [&](auto *s) { return s->create(A, n, false); }); SPRS_GUARD_END }
+int sprs_minres_create_z(const sprs_csr *A, size_t n, sprs_minres **out) { SPRS_GUARD_BEGIN return solver_create<sprs_minres, MinRes>(A, n, 1, out, [&](auto *s) { return s->create(A, n, false); }); SPRS_GUARD_END }
+int sprs_minres_destroy(sprs_minres *S) { return solver_destroy<sprs_minres, MinRes>(S); }
+int sprs_minres_solve_d(sprs_minres *S, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN return solve_host<double>(mr<double>(S), nullptr, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+int sprs_minres_solve_z(sprs_minres *S, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN return solve_host<cplx>(mr<cplx>(S), nullptr, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+int sprs_minres_precond_solve_d(sprs_minres *S, const sprs_diag *P, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN if (!P) return SPRS_INVALID_ARGUMENT; return solve_host<double>(mr<double>(S), P, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+int sprs_minres_precond_solve_z(sprs_minres *S, const sprs_diag *P, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN if (!P) return SPRS_INVALID_ARGUMENT; return solve_host<cplx>(mr<cplx>(S), P, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+int sprs_minres_solve_dev_d(sprs_minres *S, const sprs_diag *P, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN return solve_dev<double>(mr<double>(S), P, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+int sprs_minres_solve_dev_z(sprs_minres *S, const sprs_diag *P, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN return solve_dev<cplx>(mr<cplx>(S), P, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+
+int sprs_csminres_create_z(const sprs_csr *A, size_t n, sprs_csminres **out) { SPRS_GUARD_BEGIN return solver_create<sprs_csminres, MinRes>(A, n, 1, out, [&](auto *s) { return s->create(A, n, true); }); SPRS_GUARD_END }
+int sprs_csminres_create_d(const sprs_csr *A, size_t n, sprs_csminres **out) { SPRS_GUARD_BEGIN return solver_create<sprs_csminres, MinRes>(A, n, 0, out, [&](auto *s) { return s->create(A, n, true); }); SPRS_GUARD_END }
+int sprs_csminres_destroy(sprs_csminres *S) { return solver_destroy<sprs_csminres, MinRes>(S); }
+int sprs_csminres_solve_z(sprs_csminres *S, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN return solve_host<cplx>(mr<cplx>(S), nullptr, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+int sprs_csminres_solve_d(sprs_csminres *S, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN return solve_host<double>(mr<double>(S), nullptr, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+int sprs_csminres_solve_dev_z(sprs_csminres *S, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN return solve_dev<cplx>(mr<cplx>(S), nullptr, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+int sprs_csminres_solve_dev_d(sprs_csminres *S, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
+    SPRS_GUARD_BEGIN return solve_dev<double>(mr<double>(S), nullptr, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
+}
+
+// ------------------------------------------------------------------------------ options / instrumentation
+// Every solver impl derives from KrylovBase<T>; pick the right instantiation from the handle.
+#define SPRS_WITH_BASE(solver, kind, body)                                                    \
+    do {                                                                                      \
+        if (!(solver)) return SPRS_INVALID_ARGUMENT;                                          \
+        int cx; void *impl;                                                                   \
+        if ((kind) == SPRS_SOLVER_BICGSTAB) { auto *h = (sprs_bicgstab *)(solver); cx = h->is_complex; impl = h->impl; } \
+        else if ((kind) == SPRS_SOLVER_MINRES) { auto *h = (sprs_minres *)(solver); cx = h->is_complex; impl = h->impl; } \
+        else if ((kind) == SPRS_SOLVER_CSMINRES) { auto *h = (sprs_csminres *)(solver); cx = h->is_complex; impl = h->impl; } \
+        else return SPRS_INVALID_ARGUMENT;                                                    \
+        if ((kind) == SPRS_SOLVER_BICGSTAB) {                                                 \
+            if (cx) { KrylovBase<cplx> *b = (BicgStab<cplx> *)impl; body; }                   \
+            else { KrylovBase<double> *b = (BicgStab<double> *)impl; body; }                  \
+        } else {                                                                              \
+            if (cx) { KrylovBase<cplx> *b = (MinRes<cplx> *)impl; body; }                     \
+            else { KrylovBase<double> *b = (MinRes<double> *)impl; body; }                    \
+        }                                                                                     \
+    } while (0)
+
+int sprs_solver_set_mode(void *solver, int kind, int mode) {
+    if (mode != 0 && mode != 1) return SPRS_INVALID_ARGUMENT;
+    SPRS_WITH_BASE(solver, kind, b->mode = mode);
+    return SPRS_OK;
+}
+int sprs_solver_set_trace(void *solver, int kind, double *trace_host, size_t cap) {
+    SPRS_WITH_BASE(solver, kind, { b->trace = trace_host; b->trace_cap = trace_host ? cap : 0; b->trace_rows = 0; });
+    return SPRS_OK;
+}
+int sprs_solver_trace_rows(const void *solver, int kind, size_t *rows_out) {
+    if (!rows_out) return SPRS_INVALID_ARGUMENT;
+    SPRS_WITH_BASE(const_cast<void *>(solver), kind, *rows_out = b->trace_rows);
+    return SPRS_OK;
+}
+int sprs_solver_set_profile(void *solver, int kind, int enable) {
+    SPRS_WITH_BASE(solver, kind, b->profile = enable ? 1 : 0);
+    return SPRS_OK;
+}
+int sprs_solver_get_profile(const void *solver, int kind, double *spmv_ms, int64_t *launches, double *solve_ms) {
+    SPRS_WITH_BASE(const_cast<void *>(solver), kind, {
+        if (spmv_ms) *spmv_ms = b->stats.spmv_ms;
+        if (launches) *launches = b->stats.spmv_launches;
+        if (solve_ms) *solve_ms = b->stats.solve_ms;
+    });
+    return SPRS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// Internal declarations shared by the translation units of libsprsolve_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/sprsolve_hip.h"
+#include "scalar.hpp"
+
+namespace sprs {
+
+constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
+constexpr int MAX_GRID = 4096; // upper bound of the streaming-kernel grid (= max partials per reduction)
+
+// device-side status word of a running solve
+enum : int { ST_RUNNING = 0, ST_CONVERGED = 1, ST_RESTART = 2, ST_BREAKDOWN = 3, ST_INVALID_PC = 4 };
+
+}  // namespace sprs
+
+struct sprs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+    int grid = 1024;     // blocks launched by streaming / reduction kernels (multiple of 8)
+    int xcd_chunk = 1;   // SpMV: give each XCD a contiguous chunk of row blocks
+    int poll = 16;       // iterations between host polls of the device status word
+    double *d_part = nullptr;  // reduction partials for the stand-alone vecalg entry points
+    double *d_scal = nullptr;  // small device result buffer
+    double *h_scal = nullptr;  // pinned host mirror
+    mutable char err[512] = {0};
+};
+
+#define SPRS_HIP_TRY(ctx, expr)                                                                     \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess) {                                                                    \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,  \
+                     hipGetErrorString(e__));                                                       \
+            return SPRS_ERR_HIP;                                                                    \
+        }                                                                                           \
+    } while (0)
+
+#define SPRS_TRY(expr)                       \
+    do {                                     \
+        int s__ = (expr);                    \
+        if (s__ != SPRS_OK) return s__;      \
+    } while (0)
+
+struct sprs_csr {
+    sprs_ctx *ctx = nullptr;
+    int is_complex = 0;
+    int64_t nrows = 0, ncols = 0, nnz = 0;
+    int32_t *row_ptr = nullptr;  // device
+    int32_t *col_idx = nullptr;  // device
+    void *val = nullptr;         // device, T
+    bool owns_arrays = true;
+    int32_t *rowblk = nullptr;   // device: n_rowblk+1 row starts, bit31 set on vector-mode blocks
+    int32_t n_rowblk = 0;
+    // scratch for the host-slice trait entry points (lazily allocated)
+    void *x_tmp = nullptr, *y_tmp = nullptr;
+    double *part = nullptr;      // partials for mul_vec_dot
+};
+
+struct sprs_diag {
+    sprs_ctx *ctx = nullptr;
+    int t_complex = 0;  // T
+    int v_complex = 0;  // V
+    size_t n = 0;
+    void *dinv = nullptr;  // device, V
+    void *in_tmp = nullptr, *out_tmp = nullptr;
+};
+
+namespace sprs {
+
+// ---- spmv.hip
+// y = A x.  dot_mode 0: none; 1: part0[b] = sum conj(u_i) y_i; 2: part0 = sum conj(y_i) y_i, part1 = sum conj(y_i) u_i.
+// status (device int*, may be null): kernels return immediately when *status != 0.
+// conj_x: gather conj(x[col]) instead of x[col] (CSMINRES: A * conj(q), cs_minres.rs:99-101, without materialising conj(q)).
+template <class T>
+int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status,
+                bool conj_x = false);
+int build_rowblocks(sprs_csr *A, const int32_t *host_row_ptr);
+int spmv_num_partials(const sprs_csr *A);  // workgroups launch_spmv uses == partials it writes
+
+// ---- blas1.hip  (all on ctx->stream, asynchronous)
+template <class T, class S> int launch_axpy(sprs_ctx *c, size_t n, S a, const T *x, T *y);
+template <class T> int launch_axpby(sprs_ctx *c, size_t n, T a, const T *x, T b, T *y);
+template <class T> int launch_scale(sprs_ctx *c, size_t n, T a, T *x);
+template <class T> int launch_rscale(sprs_ctx *c, size_t n, double a, T *x);
+template <class T> int launch_conj(sprs_ctx *c, size_t n, const T *in, T *out);
+template <class T, class V> int launch_diag_apply(sprs_ctx *c, size_t n, const V *dinv, const T *in, T *out);
+template <class V> int launch_diag_inv(sprs_ctx *c, size_t n, const V *diag, V *dinv);
+// reductions: blocking, result returned to the host
+template <class T> int dot_host(sprs_ctx *c, size_t n, const T *x, const T *y, bool conj, T *out);
+template <class T> int norm2_host(sprs_ctx *c, size_t n, const T *x, double *out);
+// reduce `P` partials of T (or of double when T_is_real_partials) with the library's fixed order; blocking
+template <class T> int reduce_partials_host(sprs_ctx *c, const T *part, int P, T *out);
+
+inline int grid_for(const sprs_ctx *c) {
+    int g = c->grid;
+    if (g < 8) g = 8;
+    if (g > MAX_GRID) g = MAX_GRID;
+    return g & ~7;
+}
+
+}  // namespace sprs

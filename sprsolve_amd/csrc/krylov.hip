@@ -1,0 +1,965 @@
+// Krylov recurrences (host side, C++) over device-resident vectors and scalars.
+//
+// Reference: src/bicg_stab.rs:35-366, src/minres.rs:31-341, src/cs_minres.rs:29-158.
+//
+// Two execution modes per solver (sprs_solver_set_mode):
+//  * fused (default): the reference's 13 (BiCGStab) / 11 (MINRES) full-vector passes per
+//    iteration are regrouped into 5 / 3 kernels.  Every scalar of the recurrence (rho, alpha, w,
+//    beta, Givens c/s, ...) lives in HBM: a kernel that needs the result of a dot product
+//    re-reduces that product's per-workgroup partials in its prologue (same partials, same
+//    order in every workgroup => bit-identical scalars everywhere) and workgroup 0 records the
+//    scalar for later kernels.  The host never waits for a scalar; it polls a status word
+//    every `poll` iterations.  After convergence / breakdown / restart-request every later
+//    kernel returns at its first instruction, so x, r and the iteration number are exactly the
+//    reference's at the moment of the event.
+//    The arithmetic of every element keeps the reference's rounding sequence (e.g.
+//    y = (v*(-beta*w) + y*beta) + r*1, bicg_stab.rs:155-156); only the summation order of the
+//    dot products / norms differs from the reference's serial fold.
+//  * literal: one kernel per reference op, scalars consumed on the host where the reference
+//    consumes them.  Slow (5 host syncs per iteration); kept as the on-GPU cross-check.
+#include "krylov.hpp"
+
+#include <cfloat>
+#include <cmath>
+
+#include "device.hpp"
+
+namespace sprs {
+
+static constexpr double EPS = DBL_EPSILON;  // T::Real::epsilon()
+
+// ======================================================================= fused kernel skeleton
+template <int PK, class F>
+__global__ __launch_bounds__(BLOCK) void fused_kernel(int64_t n, F f) {
+    if (!f.prologue()) return;
+    SPRS_FOREACH_PACK(n, PK, i) f.template run<PK>(i);
+    if (PK > 1) {
+        int64_t i = (n / PK) * PK + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+        if (i < n) f.template run<1>(i);
+    }
+    f.epilogue();
+}
+
+template <class T, class F>
+static int launch_fused(sprs_ctx *c, size_t n, int grid, F f) {
+    constexpr int PKW = pack_width<T>::value;
+    hipLaunchKernelGGL((fused_kernel<PKW, F>), dim3(grid), dim3(BLOCK), 0, c->stream, (int64_t)n, f);
+    SPRS_HIP_TRY(c, hipGetLastError());
+    return SPRS_OK;
+}
+
+__device__ __forceinline__ bool first_thread() { return blockIdx.x == 0 && threadIdx.x == 0; }
+
+// ======================================================================= BiCGStab kernels
+// K1  bicg_stab.rs:123-156 (+ :321-328 with a preconditioner)
+//   r_norm = norm2(r); converged?  rho = r0.r; restart?  beta = (rho/rho_old)*(alpha/w)
+//   p = v*(-beta*w) + p*beta ;  p += r*1 ;  [y = M^-1 p]
+template <class T, class V, bool PC>
+struct BicgK1 {
+    BicgState<T> *S; const double *partN; const T *partRho; int P; int mode;
+    const T *v; const T *r; T *p; const V *dinv; T *y;
+    T a, beta;
+    __device__ __forceinline__ bool prologue() {
+        __shared__ double smD[NWAVE];
+        __shared__ T smT[NWAVE];
+        if (S->status != ST_RUNNING) return false;
+        T rho; double r_norm;
+        if (mode == 0) {
+            r_norm = sqrt(reduce_partials(partN, P, smD));          // :123
+            if (r_norm <= S->tol2) {                                // :124
+                if (first_thread()) { S->r_norm = r_norm; S->status = ST_CONVERGED; }
+                return false;
+            }
+            rho = reduce_partials(partRho, P, smT);                 // :128
+            if (sabs(rho) < S->r0_norm_tol) {                       // :131 -> host runs :132-145
+                if (first_thread()) { S->r_norm = r_norm; S->status = ST_RESTART; }
+                return false;
+            }
+        } else {  // resumed after the host-side restart: rho, r0_norm_tol already updated
+            rho = S->rho; r_norm = S->r_norm;
+        }
+        const T w = S->w;
+        beta = smul(sdiv(rho, S->rho_old), sdiv(S->alpha, w));      // :146
+        a = smul(sneg(beta), w);                                    // :155  -beta * w
+        if (first_thread()) { S->rho = rho; S->r_norm = r_norm; S->beta = beta; }
+        return true;
+    }
+    template <int PK> __device__ __forceinline__ void run(int64_t i) const {
+        auto vv = ldp<T, PK>(v, i); auto pv = ldp<T, PK>(p, i); auto rv = ldp<T, PK>(r, i);
+        Pack<T, PK> yv;
+        [[maybe_unused]] Pack<V, PK> dv;
+        if (PC) dv = ldp<V, PK>(dinv, i);
+#pragma unroll
+        for (int e = 0; e < PK; ++e) {
+            T t = sadd(smul(vv.v[e], a), smul(pv.v[e], beta));      // :155 axpby
+            t = sadd(t, smul(rv.v[e], sone<T>()));                  // :156 axpy(one, r, p)
+            pv.v[e] = t;
+            if (PC) yv.v[e] = smulv(t, dv.v[e]);                    // :328
+        }
+        stp<T, PK>(p, i, pv);
+        if (PC) stp<T, PK>(y, i, yv);
+    }
+    __device__ __forceinline__ void epilogue() const {}
+};
+
+// K3  bicg_stab.rs:163-172 (+ :343):  alpha = rho / (r0.v) ; r -= alpha*v ; [z = M^-1 r]
+template <class T, class V, bool PC>
+struct BicgK3 {
+    BicgState<T> *S; const T *partB; int P; int check_breakdown;
+    const T *v; T *r; const V *dinv; T *z;
+    T na;
+    __device__ __forceinline__ bool prologue() {
+        __shared__ T smT[NWAVE];
+        if (S->status != ST_RUNNING) return false;
+        const T tmp = reduce_partials(partB, P, smT);               // :163
+        if (check_breakdown && sabs(tmp) <= 0.0) {                  // :164-167
+            if (first_thread()) S->status = ST_BREAKDOWN;
+            return false;
+        }
+        const T alpha = sdiv(S->rho, tmp);                          // :169
+        na = sneg(alpha);
+        if (first_thread()) S->alpha = alpha;
+        return true;
+    }
+    template <int PK> __device__ __forceinline__ void run(int64_t i) const {
+        auto vv = ldp<T, PK>(v, i); auto rv = ldp<T, PK>(r, i);
+        Pack<T, PK> zv;
+        [[maybe_unused]] Pack<V, PK> dv;
+        if (PC) dv = ldp<V, PK>(dinv, i);
+#pragma unroll
+        for (int e = 0; e < PK; ++e) {
+            rv.v[e] = sadd(rv.v[e], smul(vv.v[e], na));             // :172
+            if (PC) zv.v[e] = smulv(rv.v[e], dv.v[e]);              // :343
+        }
+        stp<T, PK>(r, i, rv);
+        if (PC) stp<T, PK>(z, i, zv);
+    }
+    __device__ __forceinline__ void epilogue() const {}
+};
+
+// K5  bicg_stab.rs:178-196:  w = (t.t > 0) ? t.r / t.t : 0 ; x -= alpha*y ; x -= w*s ; r -= w*t
+//     + partials of norm2(r)^2 and r0.r for the next iteration's K1 (:123,:128)
+template <class T, bool PC>
+struct BicgK5 {
+    BicgState<T> *S; const T *partTT; const T *partTR; int P;
+    const T *y; const T *z; const T *t; const T *r0; T *x; T *r; double *partN; T *partRho;
+    T na, nw, w;
+    double accN; T accR;
+    __device__ __forceinline__ bool prologue() {
+        __shared__ T smT[NWAVE];
+        if (S->status != ST_RUNNING) return false;
+        const T tt = reduce_partials(partTT, P, smT);               // :178
+        const T tr = reduce_partials(partTR, P, smT);               // :183
+        w = (sre(tt) > 0.0) ? sdiv(tr, tt) : szero<T>();            // :179-186
+        na = sneg(S->alpha); nw = sneg(w);
+        accN = 0.0; accR = szero<T>();
+        return true;
+    }
+    template <int PK> __device__ __forceinline__ void run(int64_t i) {
+        auto xv = ldp<T, PK>(x, i); auto yv = ldp<T, PK>(y, i); auto rv = ldp<T, PK>(r, i);
+        auto tv = ldp<T, PK>(t, i); auto qv = ldp<T, PK>(r0, i);
+        [[maybe_unused]] Pack<T, PK> zv;
+        if (PC) zv = ldp<T, PK>(z, i);
+#pragma unroll
+        for (int e = 0; e < PK; ++e) {
+            T xx = sadd(xv.v[e], smul(yv.v[e], na));                // :188
+            xx = sadd(xx, smul(PC ? zv.v[e] : rv.v[e], nw));        // :191 / :357
+            xv.v[e] = xx;
+            const T rr = sadd(rv.v[e], smul(tv.v[e], nw));          // :196
+            rv.v[e] = rr;
+            accN = accN + ssq(rr);
+            accR = sadd(accR, smul(sconj(qv.v[e]), rr));
+        }
+        stp<T, PK>(x, i, xv);
+        stp<T, PK>(r, i, rv);
+    }
+    __device__ __forceinline__ void epilogue() {
+        __shared__ double smD[NWAVE];
+        __shared__ T smT[NWAVE];
+        const double sN = block_sum(accN, smD);
+        const T sR = block_sum(accR, smT);
+        if (threadIdx.x == 0) { partN[blockIdx.x] = sN; partRho[blockIdx.x] = sR; }
+        if (first_thread()) { S->w = w; S->rho_old = S->rho; S->its = S->its + 1; }
+    }
+};
+
+// ======================================================================= MINRES kernels
+// M2  minres.rs:117-120 (+ :276-278):  v_new -= beta*v_old ; v_new -= alpha*v ;
+//     partials of |v_new|^2   or, preconditioned,  w_new = M^-1 v_new and conj(v_new).w_new
+template <class T, class V, bool PC>
+struct MinresM2 {
+    MinresDev<T> *D; int par; const T *partAlpha; int P;
+    const T *v_old; const T *v; T *v_new; const V *dinv; T *w_new; double *partBeta; T *partBeta2;
+    T nb, na; double accD; T accT;
+    __device__ __forceinline__ bool prologue() {
+        __shared__ T smT[NWAVE];
+        if (D->status != ST_RUNNING) return false;
+        const T alpha = reduce_partials(partAlpha, P, smT);         // :116
+        nb = sfromr<T>(-D->st[par].beta);                           // :117 T::from_real(-beta)
+        na = sneg(alpha);                                           // :118
+        accD = 0.0; accT = szero<T>();
+        if (first_thread()) D->st[par].alpha = alpha;
+        return true;
+    }
+    template <int PK> __device__ __forceinline__ void run(int64_t i) {
+        auto nv = ldp<T, PK>(v_new, i); auto ov = ldp<T, PK>(v_old, i); auto cv = ldp<T, PK>(v, i);
+        Pack<T, PK> wv;
+        [[maybe_unused]] Pack<V, PK> dv;
+        if (PC) dv = ldp<V, PK>(dinv, i);
+#pragma unroll
+        for (int e = 0; e < PK; ++e) {
+            T t = sadd(nv.v[e], smul(ov.v[e], nb));                 // :117
+            t = sadd(t, smul(cv.v[e], na));                         // :118
+            nv.v[e] = t;
+            if (PC) {
+                wv.v[e] = smulv(t, dv.v[e]);                        // :276
+                accT = sadd(accT, smul(sconj(t), wv.v[e]));         // :278
+            } else {
+                accD = accD + ssq(t);                               // :120
+            }
+        }
+        stp<T, PK>(v_new, i, nv);
+        if (PC) stp<T, PK>(w_new, i, wv);
+    }
+    __device__ __forceinline__ void epilogue() {
+        __shared__ double smD[NWAVE];
+        __shared__ T smT[NWAVE];
+        if (PC) {
+            const T s = block_sum(accT, smT);
+            if (threadIdx.x == 0) partBeta2[blockIdx.x] = s;
+        } else {
+            const double s = block_sum(accD, smD);
+            if (threadIdx.x == 0) partBeta[blockIdx.x] = s;
+        }
+    }
+};
+
+// M3  minres.rs:120-168 (cs_minres.rs:106-154 with SAUNDERS):  beta_new, normalise v_new
+//     [and w_new], Givens rotation, p = q - r2*p_old - r3*p_oold, p *= 1/r1, x += c*eta*beta_1*p,
+//     res_norm *= |s| ; converged?  eta *= -s
+template <class T, bool PC, bool SAUNDERS>
+struct MinresM3 {
+    MinresDev<T> *D; int par; long long its; const double *partBeta; const T *partBeta2; int P;
+    T *v_new; T *w_new; const T *q; const T *p_old; const T *p_oold; T *p; T *x;
+    double inv, r1_inv, beta_new, s_new; T nr2, nr3, coef, c_new;
+    __device__ __forceinline__ bool prologue() {
+        __shared__ double smD[NWAVE];
+        __shared__ T smT[NWAVE];
+        if (D->status != ST_RUNNING) return false;
+        const MinresState<T> &S = D->st[par];
+        if (PC) {
+            const T b2 = reduce_partials(partBeta2, P, smT);        // :278
+            if (sre(b2) < EPS || sim(b2) > EPS * sre(b2)) {         // :279-287
+                if (first_thread()) { D->st[par].pc_re = sre(b2); D->its = its; D->status = ST_INVALID_PC; }
+                return false;
+            }
+            beta_new = sqrt(sre(b2));                               // :288
+        } else {
+            beta_new = sqrt(reduce_partials(partBeta, P, smD));     // :120
+        }
+        inv = 1.0 / beta_new;                                       // :121 / :289
+        const double beta = S.beta;
+        const T c = S.c, c_old = S.c_old, alpha = S.alpha;
+        const double s = S.s, s_old = S.s_old;
+        const double r3 = s_old * beta;                                                    // :132
+        const T tr = smulr(SAUNDERS ? sconj(c_old) : c_old, beta);                         // :133 / cs:120
+        const T r2 = sadd(smulr(alpha, s), smul(c, tr));                                   // :134
+        const T r1_hat = ssub(smul(SAUNDERS ? sconj(c) : c, alpha), smulr(tr, s));         // :136 / cs:122
+        r1_inv = 1.0 / sqrt(ssq(r1_hat) + beta_new * beta_new);                            // :139-140
+        c_new = smulr(SAUNDERS ? sconj(r1_hat) : r1_hat, r1_inv);                          // :147 / cs:133
+        s_new = beta_new * r1_inv;                                                         // :148
+        nr2 = sneg(r2); nr3 = sfromr<T>(-r3);
+        coef = smulr(smul(c_new, S.eta), S.beta_one);                                      // :162
+        return true;
+    }
+    template <int PK> __device__ __forceinline__ void run(int64_t i) const {
+        auto nv = ldp<T, PK>(v_new, i);
+        auto qv = ldp<T, PK>(q, i); auto po = ldp<T, PK>(p_old, i); auto poo = ldp<T, PK>(p_oold, i);
+        auto xv = ldp<T, PK>(x, i);
+        [[maybe_unused]] Pack<T, PK> wv;
+        if (PC) wv = ldp<T, PK>(w_new, i);
+        Pack<T, PK> pv;
+#pragma unroll
+        for (int e = 0; e < PK; ++e) {
+            nv.v[e] = smulr(nv.v[e], inv);                          // :121 / :290
+            if (PC) wv.v[e] = smulr(wv.v[e], inv);                  // :291
+            T t = SAUNDERS ? sconj(qv.v[e]) : qv.v[e];              // :156 p = v  (cs:142 p = conj(q))
+            t = sadd(t, smul(po.v[e], nr2));                        // :158
+            t = sadd(t, smul(poo.v[e], nr3));                       // :159
+            t = smulr(t, r1_inv);                                   // :160
+            pv.v[e] = t;
+            xv.v[e] = sadd(xv.v[e], smul(t, coef));                 // :162
+        }
+        stp<T, PK>(v_new, i, nv);
+        if (PC) stp<T, PK>(w_new, i, wv);
+        stp<T, PK>(p, i, pv);
+        stp<T, PK>(x, i, xv);
+    }
+    __device__ __forceinline__ void epilogue() const {
+        if (!first_thread()) return;
+        const MinresState<T> &S = D->st[par];
+        MinresState<T> N;
+        N.c_old = S.c; N.s_old = S.s;                               // :142-143
+        N.c = c_new; N.s = s_new;                                   // :147-148
+        N.alpha = S.alpha;
+        N.beta = beta_new; N.beta_one = S.beta_one; N.threshold = S.threshold;
+        N.res_norm = S.res_norm * fabs(s_new);                      // :164
+        N.eta = smulr(S.eta, -s_new);                               // :168
+        N.pc_re = 0.0; N.pad0 = 0.0;
+        D->st[par ^ 1] = N;
+        if (N.res_norm < S.threshold) { D->its = its; D->status = ST_CONVERGED; }   // :165-167
+    }
+};
+
+// ======================================================================= KrylovBase
+template <class T>
+int KrylovBase<T>::init(const sprs_csr *A_, size_t size, int nvec_) {
+    A = A_; ctx = A_->ctx; n = size; nvec = nvec_;
+    stride = (n + 31) & ~(size_t)31;
+    if (stride == 0) stride = 32;
+    SPRS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    SPRS_HIP_TRY(ctx, hipMalloc((void **)&work, sizeof(T) * stride * (size_t)nvec));
+    SPRS_HIP_TRY(ctx, hipMemsetAsync(work, 0, sizeof(T) * stride * (size_t)nvec, ctx->stream));   // vec![T::zero(); size*7]
+    SPRS_HIP_TRY(ctx, hipMalloc((void **)&part, sizeof(T) * MAX_GRID * 8));
+    SPRS_HIP_TRY(ctx, hipMalloc((void **)&partD, sizeof(double) * MAX_GRID * 4));
+    SPRS_HIP_TRY(ctx, hipMemsetAsync(part, 0, sizeof(T) * MAX_GRID * 8, ctx->stream));
+    SPRS_HIP_TRY(ctx, hipMemsetAsync(partD, 0, sizeof(double) * MAX_GRID * 4, ctx->stream));
+    SPRS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SPRS_OK;
+}
+
+template <class T>
+void KrylovBase<T>::destroy() {
+    if (work) (void)hipFree(work);
+    if (rhs_buf) (void)hipFree(rhs_buf);
+    if (x_buf) (void)hipFree(x_buf);
+    if (part) (void)hipFree(part);
+    if (partD) (void)hipFree(partD);
+    for (auto e : ev) (void)hipEventDestroy(e);
+    ev.clear();
+    work = rhs_buf = x_buf = part = nullptr; partD = nullptr;
+}
+
+template <class T>
+int KrylovBase<T>::ew_grid() const {
+    constexpr int PKW = pack_width<T>::value;
+    int64_t workb = ((int64_t)n / PKW + BLOCK - 1) / BLOCK;
+    int g = grid_for(ctx);
+    if (workb < g) g = (int)(workb < 1 ? 1 : workb);
+    return g;
+}
+
+template <class T>
+int KrylovBase<T>::spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, const int *status, bool conj_x) {
+    if (!profile) return launch_spmv<T>(A, x, y, dot, u, p0, p1, status, conj_x);
+    if (ev_used + 2 > ev.size()) {
+        for (int k = 0; k < 2; ++k) {
+            hipEvent_t e;
+            SPRS_HIP_TRY(ctx, hipEventCreate(&e));
+            ev.push_back(e);
+        }
+    }
+    SPRS_HIP_TRY(ctx, hipEventRecord(ev[ev_used], ctx->stream));
+    int st = launch_spmv<T>(A, x, y, dot, u, p0, p1, status, conj_x);
+    SPRS_HIP_TRY(ctx, hipEventRecord(ev[ev_used + 1], ctx->stream));
+    ev_used += 2;
+    return st;
+}
+
+template <class T>
+int KrylovBase<T>::begin_solve() {
+    SPRS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    trace_rows = 0;
+    stats = SolverStats();
+    if (profile) {
+        if (ev.size() < 2) {
+            for (int k = 0; k < 2; ++k) {
+                hipEvent_t e;
+                SPRS_HIP_TRY(ctx, hipEventCreate(&e));
+                ev.push_back(e);
+            }
+        }
+        ev_used = 2;  // ev[0], ev[1] bracket the whole solve
+        SPRS_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+    }
+    return SPRS_OK;
+}
+
+template <class T>
+int KrylovBase<T>::end_solve() {
+    if (!profile) return SPRS_OK;
+    SPRS_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
+    SPRS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    SPRS_HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[0], ev[1]));
+    stats.solve_ms = ms;
+    for (size_t k = 2; k + 1 < ev_used; k += 2) {
+        SPRS_HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+        stats.spmv_ms += ms;
+        stats.spmv_launches += 1;
+    }
+    return SPRS_OK;
+}
+
+template <class T>
+void KrylovBase<T>::trace_row(double a0, double a1, T b, T c, T d) {
+    if (!trace || trace_rows >= trace_cap) return;
+    double *t = trace + 8 * trace_rows;
+    t[0] = a0; t[1] = a1;
+    t[2] = sre(b); t[3] = sim(b); t[4] = sre(c); t[5] = sim(c); t[6] = sre(d); t[7] = sim(d);
+    ++trace_rows;
+}
+
+// small helpers on the context stream
+template <class T>
+static int dcopy(sprs_ctx *c, T *dst, const T *src, size_t n) {
+    SPRS_HIP_TRY(c, hipMemcpyAsync(dst, src, sizeof(T) * n, hipMemcpyDeviceToDevice, c->stream));
+    return SPRS_OK;
+}
+template <class T>
+static int dzero(sprs_ctx *c, T *dst, size_t n) {
+    SPRS_HIP_TRY(c, hipMemsetAsync(dst, 0, sizeof(T) * n, c->stream));
+    return SPRS_OK;
+}
+
+// ======================================================================= BiCGStab host
+template <class T>
+int BicgStab<T>::create(const sprs_csr *A, size_t size) {
+    SPRS_TRY(this->init(A, size, 7));   // bicg_stab.rs:28 workspace 7n
+    SPRS_HIP_TRY(this->ctx, hipMalloc((void **)&d_state, sizeof(BicgState<T>)));
+    SPRS_HIP_TRY(this->ctx, hipHostMalloc((void **)&h_state, sizeof(BicgState<T>), hipHostMallocDefault));
+    return SPRS_OK;
+}
+template <class T>
+void BicgStab<T>::destroy() {
+    if (d_state) (void)hipFree(d_state);
+    if (h_state) (void)hipHostFree(h_state);
+    d_state = h_state = nullptr;
+    KrylovBase<T>::destroy();
+}
+
+template <class T>
+template <class V>
+int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out, double *res_out) {
+    sprs_ctx *c = this->ctx;
+    const size_t n = this->n;
+    const bool pc = dinv != nullptr;
+    *its_out = 0; *res_out = 0.0;
+
+    double rhs_norm = 0.0;
+    SPRS_TRY(norm2_host<T>(c, n, rhs, &rhs_norm));                  // :55
+    if (rhs_norm <= EPS) {                                          // :56-60
+        SPRS_TRY(dzero(c, x, n));
+        *its_out = 0; *res_out = rhs_norm;
+        return SPRS_OK;
+    }
+    const double tol2 = tol * rhs_norm;                             // :61
+
+    // :64-69 / :234-241
+    T *r = this->vec(0), *r0 = this->vec(1), *y = this->vec(2);
+    T *p = pc ? this->vec(3) : y;
+    T *v = pc ? this->vec(4) : this->vec(3);
+    T *t = pc ? this->vec(5) : this->vec(4);
+    T *z = pc ? this->vec(6) : nullptr;
+    const T *sz = pc ? z : r;
+
+    SPRS_TRY(this->spmv(x, r, 0, nullptr, nullptr, nullptr, nullptr));      // :73
+    SPRS_TRY((launch_axpy<T, T>(c, n, sneg(sone<T>()), rhs, r)));           // :75
+    SPRS_TRY(dcopy(c, r0, r, n));                                           // :78
+    double r0_norm = 0.0;
+    SPRS_TRY(norm2_host<T>(c, n, r0, &r0_norm));                            // :80
+    if (r0_norm <= tol2) {                                                  // :81-83
+        *its_out = 0; *res_out = r0_norm / rhs_norm;
+        return SPRS_OK;
+    }
+    double r0_norm_tol = r0_norm * EPS;                                     // :84
+    r0_norm_tol = r0_norm_tol * r0_norm_tol;                                // :85
+
+    BicgState<T> &H = *h_state;
+    memset(&H, 0, sizeof(H));
+    H.rho = sfromr<T>(r0_norm * r0_norm);                                   // :88
+    H.rho_old = H.rho;
+    H.r_norm = r0_norm; H.r0_norm_tol = r0_norm_tol; H.tol2 = tol2;
+    H.its = 0; H.status = ST_RUNNING;
+    SPRS_HIP_TRY(c, hipMemcpyAsync(d_state, &H, sizeof(H), hipMemcpyHostToDevice, c->stream));
+    const int *d_status = &d_state->status;
+
+    const int G = this->ew_grid();
+    const int GS = spmv_num_partials(this->A);
+    double *partN = this->dslot(0);
+    T *partRho = this->pslot(0), *partB = this->pslot(1), *partTT = this->pslot(2), *partTR = this->pslot(3);
+
+    auto K2 = [&]() { return this->spmv(y, v, 1, r0, partB, nullptr, d_status); };          // :93/:160  v = A y ; r0.v
+    auto K3 = [&](int check) {
+        if (pc) return launch_fused<T>(c, n, G, BicgK3<T, V, true>{d_state, partB, GS, check, v, r, dinv, z, T()});
+        return launch_fused<T>(c, n, G, BicgK3<T, V, false>{d_state, partB, GS, check, v, r, dinv, z, T()});
+    };
+    auto K4 = [&]() { return this->spmv(sz, t, 2, r, partTT, partTR, d_status); };          // :104/:175 t = A s ; t.t, t.r
+    auto K5 = [&]() {
+        if (pc) return launch_fused<T>(c, n, G, BicgK5<T, true>{d_state, partTT, partTR, GS, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()});
+        return launch_fused<T>(c, n, G, BicgK5<T, false>{d_state, partTT, partTR, GS, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()});
+    };
+    auto K1 = [&](int mode) {
+        if (pc) return launch_fused<T>(c, n, G, BicgK1<T, V, true>{d_state, partN, partRho, G, mode, v, r, p, dinv, y, T(), T()});
+        return launch_fused<T>(c, n, G, BicgK1<T, V, false>{d_state, partN, partRho, G, mode, v, r, p, dinv, y, T(), T()});
+    };
+    auto fetch = [&]() -> int {
+        SPRS_HIP_TRY(c, hipMemcpyAsync(&H, d_state, sizeof(H), hipMemcpyDeviceToHost, c->stream));
+        SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return (int)SPRS_OK;
+    };
+
+    // ---- unrolled first iteration (:87-120 / :258-293)
+    if (pc) {
+        SPRS_TRY(dcopy(c, p, r, n));                                        // :261
+        SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, p, y)));              // :262
+    } else {
+        SPRS_TRY(dcopy(c, y, r, n));                                        // :91
+    }
+    SPRS_TRY(K2()); SPRS_TRY(K3(0)); SPRS_TRY(K4()); SPRS_TRY(K5());
+    const bool tracing = this->trace != nullptr;
+    if (tracing) {
+        SPRS_TRY(fetch());
+        this->trace_row(0.0, r0_norm, H.rho, H.alpha, H.w);
+    }
+
+    // ---- main loop (:122-197)
+    const size_t poll = tracing ? 1 : (size_t)(c->poll < 1 ? 1 : c->poll);
+    size_t its = 1, since_poll = 0;
+    int resume_mode = 0;
+    while (true) {
+        const bool done_enqueue = its >= max_iter;
+        if (!done_enqueue) {
+            SPRS_TRY(K1(resume_mode)); resume_mode = 0;
+            SPRS_TRY(K2()); SPRS_TRY(K3(1)); SPRS_TRY(K4()); SPRS_TRY(K5());
+            ++its; ++since_poll;
+        }
+        if (done_enqueue || since_poll >= poll) {
+            since_poll = 0;
+            SPRS_TRY(fetch());
+            if (H.status == ST_CONVERGED) {                                 // :124-126
+                *its_out = (size_t)H.its; *res_out = H.r_norm / rhs_norm;
+                return SPRS_OK;
+            }
+            if (H.status == ST_BREAKDOWN) {                                 // :164-167
+                *its_out = (size_t)H.its;
+                return SPRS_BREAKDOWN;
+            }
+            if (H.status == ST_RESTART) {                                   // :131-145, executed at iteration H.its
+                SPRS_TRY(this->spmv(x, r, 0, nullptr, nullptr, nullptr, nullptr));  // :134
+                SPRS_TRY((launch_axpy<T, T>(c, n, sneg(sone<T>()), rhs, r)));       // :137
+                SPRS_TRY(dcopy(c, r0, r, n));                                       // :140
+                double rn = 0.0;
+                SPRS_TRY(norm2_host<T>(c, n, r, &rn));                              // :142
+                H.rho = sfromr<T>(rn * rn);                                         // :143
+                H.r0_norm_tol = sre(H.rho) * EPS * EPS;                             // :144
+                H.status = ST_RUNNING;
+                SPRS_HIP_TRY(c, hipMemcpyAsync(d_state, &H, sizeof(H), hipMemcpyHostToDevice, c->stream));
+                its = (size_t)H.its;       // every kernel after the request was a no-op: redo from here
+                resume_mode = 1;
+                continue;
+            }
+            if (tracing && !done_enqueue) this->trace_row((double)(H.its - 1), H.r_norm, H.rho, H.alpha, H.w);
+            if (done_enqueue) break;
+        }
+    }
+    *its_out = max_iter;                                                    // :199
+    return SPRS_INSUFFICIENT_ITER;
+}
+
+// literal mode: the reference's op list, one kernel per op, host-consumed scalars
+template <class T>
+template <class V>
+int BicgStab<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out,
+                             double *res_out) {
+    sprs_ctx *c = this->ctx;
+    const size_t n = this->n;
+    const bool pc = dinv != nullptr;
+    *its_out = 0; *res_out = 0.0;
+    double rhs_norm = 0.0;
+    SPRS_TRY(norm2_host<T>(c, n, rhs, &rhs_norm));
+    if (rhs_norm <= EPS) { SPRS_TRY(dzero(c, x, n)); *res_out = rhs_norm; return SPRS_OK; }
+    const double tol2 = tol * rhs_norm;
+    T *r = this->vec(0), *r0 = this->vec(1), *y = this->vec(2);
+    T *p = pc ? this->vec(3) : y;
+    T *v = pc ? this->vec(4) : this->vec(3);
+    T *t = pc ? this->vec(5) : this->vec(4);
+    T *z = pc ? this->vec(6) : nullptr;
+    const T *sz = pc ? z : r;
+    auto mv = [&](const T *in, T *out) { return this->spmv(in, out, 0, nullptr, nullptr, nullptr, nullptr); };
+    auto cdot = [&](const T *a, const T *b, T *o) { return dot_host<T>(c, n, a, b, true, o); };
+    auto axpy = [&](T a, const T *xx, T *yy) { return launch_axpy<T, T>(c, n, a, xx, yy); };
+
+    SPRS_TRY(mv(x, r));
+    SPRS_TRY(axpy(sneg(sone<T>()), rhs, r));
+    SPRS_TRY(dcopy(c, r0, r, n));
+    double r0_norm = 0.0;
+    SPRS_TRY(norm2_host<T>(c, n, r0, &r0_norm));
+    if (r0_norm <= tol2) { *res_out = r0_norm / rhs_norm; return SPRS_OK; }
+    double r0_norm_tol = r0_norm * EPS;
+    r0_norm_tol = r0_norm_tol * r0_norm_tol;
+    T rho = sfromr<T>(r0_norm * r0_norm);
+    if (pc) { SPRS_TRY(dcopy(c, p, r, n)); SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, p, y))); }
+    else SPRS_TRY(dcopy(c, y, r, n));
+    SPRS_TRY(mv(y, v));
+    T tmp;
+    SPRS_TRY(cdot(r0, v, &tmp));
+    T alpha = sdiv(rho, tmp);
+    SPRS_TRY(axpy(sneg(alpha), v, r));
+    if (pc) SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, r, z)));
+    SPRS_TRY(mv(sz, t));
+    SPRS_TRY(cdot(t, t, &tmp));
+    T w = szero<T>();
+    if (sre(tmp) > 0.0) { T tr; SPRS_TRY(cdot(t, r, &tr)); w = sdiv(tr, tmp); }
+    SPRS_TRY(axpy(sneg(alpha), y, x));
+    SPRS_TRY(axpy(sneg(w), sz, x));
+    SPRS_TRY(axpy(sneg(w), t, r));
+    this->trace_row(0.0, r0_norm, rho, alpha, w);
+    for (size_t its = 1; its < max_iter; ++its) {
+        double r_norm = 0.0;
+        SPRS_TRY(norm2_host<T>(c, n, r, &r_norm));
+        if (r_norm <= tol2) { *its_out = its; *res_out = r_norm / rhs_norm; return SPRS_OK; }
+        const T rho_old = rho;
+        SPRS_TRY(cdot(r0, r, &rho));
+        if (sabs(rho) < r0_norm_tol) {
+            SPRS_TRY(mv(x, r));
+            SPRS_TRY(axpy(sneg(sone<T>()), rhs, r));
+            SPRS_TRY(dcopy(c, r0, r, n));
+            double rn = 0.0;
+            SPRS_TRY(norm2_host<T>(c, n, r, &rn));
+            rho = sfromr<T>(rn * rn);
+            r0_norm_tol = sre(rho) * EPS * EPS;
+        }
+        const T beta = smul(sdiv(rho, rho_old), sdiv(alpha, w));
+        SPRS_TRY(launch_axpby<T>(c, n, smul(sneg(beta), w), v, beta, p));
+        SPRS_TRY(axpy(sone<T>(), r, p));
+        if (pc) SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, p, y)));
+        SPRS_TRY(mv(y, v));
+        SPRS_TRY(cdot(r0, v, &tmp));
+        if (sabs(tmp) <= 0.0) { *its_out = its; return SPRS_BREAKDOWN; }
+        alpha = sdiv(rho, tmp);
+        SPRS_TRY(axpy(sneg(alpha), v, r));
+        if (pc) SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, r, z)));
+        SPRS_TRY(mv(sz, t));
+        SPRS_TRY(cdot(t, t, &tmp));
+        if (sre(tmp) > 0.0) { T tr; SPRS_TRY(cdot(t, r, &tr)); w = sdiv(tr, tmp); }
+        else w = szero<T>();
+        SPRS_TRY(axpy(sneg(alpha), y, x));
+        SPRS_TRY(axpy(sneg(w), sz, x));
+        SPRS_TRY(axpy(sneg(w), t, r));
+        this->trace_row((double)its, r_norm, rho, alpha, w);
+    }
+    *its_out = max_iter;
+    return SPRS_INSUFFICIENT_ITER;
+}
+
+template <class T>
+static int check_diag(const sprs_diag *P, size_t n) {
+    if (!P) return SPRS_OK;
+    if (P->n != n) return SPRS_DIM_MISMATCH;
+    if (P->t_complex != (is_complex<T>::value ? 1 : 0)) return SPRS_INVALID_ARGUMENT;
+    return SPRS_OK;
+}
+
+template <class T>
+int BicgStab<T>::solve_dev(const sprs_diag *P, const T *rhs, size_t rhs_len, T *x, size_t x_len, size_t max_iter,
+                           double tol, size_t *its_out, double *res_out) {
+    size_t its_dummy; double res_dummy;
+    if (!its_out) its_out = &its_dummy;
+    if (!res_out) res_out = &res_dummy;
+    if (rhs_len != this->n) return SPRS_INCOMPATIBLE_RHS_SIZE;             // :44-48
+    if (x_len != this->n) return SPRS_INCOMPATIBLE_X_SIZE;                 // :49-53
+    SPRS_TRY(check_diag<T>(P, this->n));
+    SPRS_TRY(this->begin_solve());
+    int st;
+    const bool lit = this->mode == 1;
+    if (P && P->v_complex) {
+        if constexpr (is_complex<T>::value) {
+            const cplx *d = (const cplx *)P->dinv;
+            st = lit ? run_literal<cplx>(d, rhs, x, max_iter, tol, its_out, res_out)
+                     : run<cplx>(d, rhs, x, max_iter, tol, its_out, res_out);
+        } else {
+            return SPRS_INVALID_ARGUMENT;
+        }
+    } else {
+        const double *d = P ? (const double *)P->dinv : nullptr;
+        st = lit ? run_literal<double>(d, rhs, x, max_iter, tol, its_out, res_out)
+                 : run<double>(d, rhs, x, max_iter, tol, its_out, res_out);
+    }
+    if (st >= SPRS_ERR_HIP) return st;
+    SPRS_TRY(this->end_solve());
+    return st;
+}
+
+// ======================================================================= MINRES / CSMINRES host
+template <class T>
+int MinRes<T>::create(const sprs_csr *A, size_t size, bool saunders_) {
+    saunders = saunders_;
+    SPRS_TRY(this->init(A, size, 8));   // minres.rs:24 workspace 8n (cs_minres.rs:22 uses 7n)
+    SPRS_HIP_TRY(this->ctx, hipMalloc((void **)&d_state, sizeof(MinresDev<T>)));
+    SPRS_HIP_TRY(this->ctx, hipHostMalloc((void **)&h_state, sizeof(MinresDev<T>), hipHostMallocDefault));
+    return SPRS_OK;
+}
+template <class T>
+void MinRes<T>::destroy() {
+    if (d_state) (void)hipFree(d_state);
+    if (h_state) (void)hipHostFree(h_state);
+    d_state = h_state = nullptr;
+    KrylovBase<T>::destroy();
+}
+
+template <class T>
+template <class V>
+int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out, double *res_out) {
+    sprs_ctx *c = this->ctx;
+    const size_t n = this->n;
+    const bool pc = dinv != nullptr;
+    const bool sau = saunders && is_complex<T>::value;   // conj() is the identity on real data
+    *its_out = 0; *res_out = 0.0;
+
+    double rhs_norm = 0.0;
+    SPRS_TRY(norm2_host<T>(c, n, rhs, &rhs_norm));                          // :51
+    if (rhs_norm <= EPS) { SPRS_TRY(dzero(c, x, n)); *res_out = rhs_norm; return SPRS_OK; }   // :52-56
+    const double threshold = tol * rhs_norm;                                // :57
+
+    T *v_old = this->vec(0), *v_new = this->vec(1), *v = this->vec(2);      // :68-70
+    T *p_old = this->vec(3), *p_oold = this->vec(4), *p = this->vec(5);     // :71-73
+    T *w = this->vec(6), *w_new = this->vec(7);                             // :222-223
+
+    SPRS_TRY(dcopy(c, v_new, rhs, n));                                      // :77
+    SPRS_TRY(this->spmv(x, v_old, 0, nullptr, nullptr, nullptr, nullptr));  // :78
+    SPRS_TRY((launch_axpy<T, T>(c, n, sneg(sone<T>()), v_old, v_new)));     // :80
+    double res_norm = 0.0;
+    SPRS_TRY(norm2_host<T>(c, n, v_new, &res_norm));                        // :81
+    double beta_new;
+    if (pc) {
+        SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, v_new, w_new)));      // :233
+        T b2;
+        SPRS_TRY(dot_host<T>(c, n, v_new, w_new, true, &b2));               // :235
+        if (sre(b2) < EPS || sim(b2) > EPS * sre(b2)) {                     // :236-244
+            *its_out = 0; *res_out = sre(b2);
+            return SPRS_INVALID_PRECOND;
+        }
+        beta_new = sqrt(sre(b2));                                           // :245
+        const double ts = 1.0 / beta_new;                                   // :248
+        SPRS_TRY(launch_rscale<T>(c, n, ts, v_new));                        // :249
+        SPRS_TRY(launch_rscale<T>(c, n, ts, w_new));                        // :250
+    } else {
+        beta_new = res_norm;                                                // :82
+        SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, v_new));            // :84
+    }
+    SPRS_TRY(dzero(c, v, n)); SPRS_TRY(dzero(c, p_old, n)); SPRS_TRY(dzero(c, p, n));   // :86-88
+
+    MinresDev<T> &H = *h_state;
+    memset(&H, 0, sizeof(H));
+    MinresState<T> &S0 = H.st[0];
+    S0.c = sone<T>(); S0.c_old = sone<T>(); S0.eta = sone<T>(); S0.alpha = szero<T>();   // :60-64
+    S0.s = 0.0; S0.s_old = 0.0;
+    S0.beta = beta_new; S0.beta_one = beta_new;                             // :82-83
+    S0.res_norm = res_norm; S0.threshold = threshold;
+    H.st[1] = S0;
+    H.its = 0; H.status = ST_RUNNING;
+    SPRS_HIP_TRY(c, hipMemcpyAsync(d_state, &H, sizeof(H), hipMemcpyHostToDevice, c->stream));
+    const int *d_status = &d_state->status;
+
+    const int G = this->ew_grid();
+    const int GS = spmv_num_partials(this->A);
+    T *partAlpha = this->pslot(0), *partBeta2 = this->pslot(1);
+    double *partBeta = this->dslot(0);
+
+    auto fetch = [&]() -> int {
+        SPRS_HIP_TRY(c, hipMemcpyAsync(&H, d_state, sizeof(H), hipMemcpyDeviceToHost, c->stream));
+        SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return (int)SPRS_OK;
+    };
+    const bool tracing = this->trace != nullptr;
+    const size_t poll = tracing ? 1 : (size_t)(c->poll < 1 ? 1 : c->poll);
+    size_t since_poll = 0;
+
+    for (size_t its = 0;; ++its) {                                          // :90
+        const bool done_enqueue = its >= max_iter;
+        if (!done_enqueue) {
+            const int par = (int)(its & 1);
+            { T *tp = v_old; v_old = v; v = v_new; v_new = tp; }             // :92-96
+            if (pc) { T *tp = w; w = w_new; w_new = tp; }                    // :259,264-265
+            const T *q = pc ? w : v;                                         // operand of A and source of p
+            // M1: v_new = A q (CSMINRES: A conj(q)) ; alpha = conj(q).v_new   (:116 / :271 / cs:99-103)
+            SPRS_TRY(this->spmv(q, v_new, 1, q, partAlpha, nullptr, d_status, sau));
+            if (pc) SPRS_TRY(launch_fused<T>(c, n, G, MinresM2<T, V, true>{d_state, par, partAlpha, GS, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, T(), T(), 0.0, T()}));
+            else SPRS_TRY(launch_fused<T>(c, n, G, MinresM2<T, V, false>{d_state, par, partAlpha, GS, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, T(), T(), 0.0, T()}));
+            { T *tp = p_oold; p_oold = p_old; p_old = p; p = tp; }           // :151-154
+#define SPRS_M3(PCF, SAF)                                                                                        \
+    launch_fused<T>(c, n, G, MinresM3<T, PCF, SAF>{d_state, par, (long long)its, partBeta, partBeta2, G, v_new,  \
+                                                   w_new, q, p_old, p_oold, p, x, 0.0, 0.0, 0.0, 0.0, T(), T(),  \
+                                                   T(), T()})
+            if (pc) SPRS_TRY(SPRS_M3(true, false));
+            else if (sau) SPRS_TRY(SPRS_M3(false, true));
+            else SPRS_TRY(SPRS_M3(false, false));
+#undef SPRS_M3
+            ++since_poll;
+        }
+        if (done_enqueue || since_poll >= poll) {
+            since_poll = 0;
+            SPRS_TRY(fetch());
+            if (H.status == ST_CONVERGED) {                                 // :165-167 (0-based its)
+                *its_out = (size_t)H.its;
+                *res_out = H.st[(H.its + 1) & 1].res_norm / rhs_norm;
+                if (tracing) {
+                    const MinresState<T> &N = H.st[(H.its + 1) & 1];
+                    this->trace_row((double)H.its, N.beta, H.st[H.its & 1].alpha, N.c, sfromr<T>(N.s));
+                    if (this->trace_rows) this->trace[8 * (this->trace_rows - 1) + 7] = N.res_norm;
+                }
+                return SPRS_OK;
+            }
+            if (H.status == ST_INVALID_PC) {                                // :279-287
+                *its_out = (size_t)H.its; *res_out = H.st[H.its & 1].pc_re;
+                return SPRS_INVALID_PRECOND;
+            }
+            if (done_enqueue) break;
+            if (tracing) {
+                const MinresState<T> &N = H.st[(its + 1) & 1];
+                this->trace_row((double)its, N.beta, H.st[its & 1].alpha, N.c, sfromr<T>(N.s));
+                if (this->trace_rows) this->trace[8 * (this->trace_rows - 1) + 7] = N.res_norm;
+            }
+        }
+    }
+    *its_out = max_iter;                                                    // :171
+    return SPRS_INSUFFICIENT_ITER;
+}
+
+template <class T>
+template <class V>
+int MinRes<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out,
+                           double *res_out) {
+    sprs_ctx *c = this->ctx;
+    const size_t n = this->n;
+    const bool pc = dinv != nullptr;
+    const bool sau = saunders;
+    *its_out = 0; *res_out = 0.0;
+    double rhs_norm = 0.0;
+    SPRS_TRY(norm2_host<T>(c, n, rhs, &rhs_norm));
+    if (rhs_norm <= EPS) { SPRS_TRY(dzero(c, x, n)); *res_out = rhs_norm; return SPRS_OK; }
+    const double threshold = tol * rhs_norm;
+    T cc = sone<T>(), c_old = sone<T>(), eta = sone<T>();
+    double s = 0.0, s_old = 0.0;
+    T *v_old = this->vec(0), *v_new = this->vec(1), *v = this->vec(2);
+    T *p_old = this->vec(3), *p_oold = this->vec(4), *p = this->vec(5);
+    T *w = this->vec(6), *w_new = this->vec(7), *tvec = this->vec(6);
+    auto mv = [&](const T *in, T *out) { return this->spmv(in, out, 0, nullptr, nullptr, nullptr, nullptr); };
+    auto axpy = [&](T a, const T *xx, T *yy) { return launch_axpy<T, T>(c, n, a, xx, yy); };
+    SPRS_TRY(dcopy(c, v_new, rhs, n));
+    SPRS_TRY(mv(x, v_old));
+    SPRS_TRY(axpy(sneg(sone<T>()), v_old, v_new));
+    double res_norm = 0.0;
+    SPRS_TRY(norm2_host<T>(c, n, v_new, &res_norm));
+    double beta_new, beta_one;
+    if (pc) {
+        SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, v_new, w_new)));
+        T b2;
+        SPRS_TRY(dot_host<T>(c, n, v_new, w_new, true, &b2));
+        if (sre(b2) < EPS || sim(b2) > EPS * sre(b2)) { *res_out = sre(b2); return SPRS_INVALID_PRECOND; }
+        beta_new = sqrt(sre(b2)); beta_one = beta_new;
+        SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, v_new));
+        SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, w_new));
+    } else {
+        beta_new = res_norm; beta_one = beta_new;
+        SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, v_new));
+    }
+    SPRS_TRY(dzero(c, v, n)); SPRS_TRY(dzero(c, p_old, n)); SPRS_TRY(dzero(c, p, n));
+    for (size_t its = 0; its < max_iter; ++its) {
+        const double beta = beta_new;
+        { T *tp = v_old; v_old = v; v = v_new; v_new = tp; }
+        T alpha;
+        const T *q;
+        if (pc) {
+            { T *tp = w; w = w_new; w_new = tp; }
+            SPRS_TRY(mv(w, v_new));
+            SPRS_TRY(dot_host<T>(c, n, w, v_new, true, &alpha));
+            q = w;
+        } else if (sau) {
+            SPRS_TRY(launch_conj<T>(c, n, v, tvec));
+            SPRS_TRY(mv(tvec, v_new));
+            SPRS_TRY(dot_host<T>(c, n, v, v_new, true, &alpha));
+            q = tvec;
+        } else {
+            SPRS_TRY(mv(v, v_new));
+            SPRS_TRY(dot_host<T>(c, n, v, v_new, true, &alpha));
+            q = v;
+        }
+        SPRS_TRY(axpy(sfromr<T>(-beta), v_old, v_new));
+        SPRS_TRY(axpy(sneg(alpha), v, v_new));
+        if (pc) {
+            SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, v_new, w_new)));
+            T b2;
+            SPRS_TRY(dot_host<T>(c, n, v_new, w_new, true, &b2));
+            if (sre(b2) < EPS || sim(b2) > EPS * sre(b2)) { *its_out = its; *res_out = sre(b2); return SPRS_INVALID_PRECOND; }
+            beta_new = sqrt(sre(b2));
+            SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, v_new));
+            SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, w_new));
+        } else {
+            SPRS_TRY(norm2_host<T>(c, n, v_new, &beta_new));
+            SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, v_new));
+        }
+        const double r3 = s_old * beta;
+        const T tr = smulr(sau ? sconj(c_old) : c_old, beta);
+        const T r2 = sadd(smulr(alpha, s), smul(cc, tr));
+        const T r1_hat = ssub(smul(sau ? sconj(cc) : cc, alpha), smulr(tr, s));
+        const double r1_inv = 1.0 / sqrt(ssq(r1_hat) + beta_new * beta_new);
+        c_old = cc; s_old = s;
+        cc = smulr(sau ? sconj(r1_hat) : r1_hat, r1_inv);
+        s = beta_new * r1_inv;
+        { T *tp = p_oold; p_oold = p_old; p_old = p; p = tp; }
+        SPRS_TRY(dcopy(c, p, q, n));
+        SPRS_TRY(axpy(sneg(r2), p_old, p));
+        SPRS_TRY(axpy(sfromr<T>(-r3), p_oold, p));
+        SPRS_TRY(launch_rscale<T>(c, n, r1_inv, p));
+        SPRS_TRY(axpy(smulr(smul(cc, eta), beta_one), p, x));
+        res_norm *= fabs(s);
+        this->trace_row((double)its, beta_new, alpha, cc, sfromr<T>(s));
+        if (this->trace && this->trace_rows) this->trace[8 * (this->trace_rows - 1) + 7] = res_norm;
+        if (res_norm < threshold) { *its_out = its; *res_out = res_norm / rhs_norm; return SPRS_OK; }
+        eta = smulr(eta, -s);
+    }
+    *its_out = max_iter;
+    return SPRS_INSUFFICIENT_ITER;
+}
+
+template <class T>
+int MinRes<T>::solve_dev(const sprs_diag *P, const T *rhs, size_t rhs_len, T *x, size_t x_len, size_t max_iter,
+                         double tol, size_t *its_out, double *res_out) {
+    size_t its_dummy; double res_dummy;
+    if (!its_out) its_out = &its_dummy;
+    if (!res_out) res_out = &res_dummy;
+    if (rhs_len != this->n) return SPRS_INCOMPATIBLE_RHS_SIZE;             // minres.rs:40-44
+    if (x_len != this->n) return SPRS_INCOMPATIBLE_X_SIZE;                 // :45-49
+    if (saunders && P) return SPRS_INVALID_ARGUMENT;                       // CSMinRes has no precond_solve
+    SPRS_TRY(check_diag<T>(P, this->n));
+    SPRS_TRY(this->begin_solve());
+    int st;
+    const bool lit = this->mode == 1;
+    if (P && P->v_complex) {
+        if constexpr (is_complex<T>::value) {
+            const cplx *d = (const cplx *)P->dinv;
+            st = lit ? run_literal<cplx>(d, rhs, x, max_iter, tol, its_out, res_out)
+                     : run<cplx>(d, rhs, x, max_iter, tol, its_out, res_out);
+        } else {
+            return SPRS_INVALID_ARGUMENT;
+        }
+    } else {
+        const double *d = P ? (const double *)P->dinv : nullptr;
+        st = lit ? run_literal<double>(d, rhs, x, max_iter, tol, its_out, res_out)
+                 : run<double>(d, rhs, x, max_iter, tol, its_out, res_out);
+    }
+    if (st >= SPRS_ERR_HIP) return st;
+    SPRS_TRY(this->end_solve());
+    return st;
+}
+
+template class KrylovBase<double>;
+template class KrylovBase<cplx>;
+template class BicgStab<double>;
+template class BicgStab<cplx>;
+template class MinRes<double>;
+template class MinRes<cplx>;
+
+}  // namespace sprs

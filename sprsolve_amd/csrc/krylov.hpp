@@ -1,0 +1,136 @@
+// Solver objects behind sprs_bicgstab / sprs_minres / sprs_csminres.
+#pragma once
+#include "internal.hpp"
+
+namespace sprs {
+
+// Device-resident scalar state of a BiCGStab solve (bicg_stab.rs:84-88,127-186 locals).
+template <class T>
+struct BicgState {
+    T rho, rho_old, alpha, w, beta;
+    double r_norm, r0_norm_tol, tol2, pad0;
+    long long its;
+    int status, pad1;
+};
+
+// Device-resident scalar state of a MINRES / CSMINRES solve (minres.rs:60-64,81-83 locals).
+// Two copies, indexed by iteration parity: kernels of iteration k read st[k&1], workgroup 0 of
+// the last kernel writes st[(k+1)&1] — no workgroup ever reads a word another one is writing.
+template <class T>
+struct MinresState {
+    T c, c_old, eta, alpha;
+    double s, s_old, beta, beta_one, res_norm, threshold, pc_re, pad0;
+};
+template <class T>
+struct MinresDev {
+    MinresState<T> st[2];
+    long long its;   // 0-based iteration index of the event recorded in `status`
+    int status, pad;
+};
+
+struct SolverStats {
+    double spmv_ms = 0.0, solve_ms = 0.0;
+    int64_t spmv_launches = 0;
+};
+
+template <class T>
+class KrylovBase {
+   public:
+    sprs_ctx *ctx = nullptr;
+    const sprs_csr *A = nullptr;
+    size_t n = 0, stride = 0;
+    int nvec = 0;
+    T *work = nullptr;           // nvec * stride
+    T *rhs_buf = nullptr, *x_buf = nullptr;
+    T *part = nullptr;           // NSLOT * MAX_GRID partials of T
+    double *partD = nullptr;     // NSLOT * MAX_GRID real partials
+    int mode = 0;
+    double *trace = nullptr;
+    size_t trace_cap = 0, trace_rows = 0;
+    int profile = 0;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    SolverStats stats;
+
+    int init(const sprs_csr *A_, size_t size, int nvec_);
+    void destroy();
+    T *vec(int i) { return work + (size_t)i * stride; }
+    T *pslot(int s) { return part + (size_t)s * MAX_GRID; }
+    double *dslot(int s) { return partD + (size_t)s * MAX_GRID; }
+    int spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, const int *status, bool conj_x = false);
+    int begin_solve();
+    int end_solve();
+    void trace_row(double a0, double a1, T b, T c, T d);
+    // host-slice wrapper around a device solve
+    template <class F>
+    int solve_host(const T *rhs, size_t rhs_len, T *x, size_t x_len, F &&dev_solve);
+    int ew_grid() const;  // workgroups used by the fused element-wise kernels for this n
+};
+
+template <class T>
+class BicgStab : public KrylovBase<T> {
+   public:
+    BicgState<T> *d_state = nullptr, *h_state = nullptr;
+    int create(const sprs_csr *A, size_t size);
+    void destroy();
+    int solve_dev(const sprs_diag *P, const T *rhs, size_t rhs_len, T *x, size_t x_len, size_t max_iter, double tol,
+                  size_t *its_out, double *res_out);
+
+   private:
+    template <class V>
+    int run(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out, double *res_out);
+    template <class V>
+    int run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out, double *res_out);
+};
+
+template <class T>
+class MinRes : public KrylovBase<T> {
+   public:
+    MinresDev<T> *d_state = nullptr, *h_state = nullptr;
+    bool saunders = false;  // CSMINRES
+    int create(const sprs_csr *A, size_t size, bool saunders_);
+    void destroy();
+    int solve_dev(const sprs_diag *P, const T *rhs, size_t rhs_len, T *x, size_t x_len, size_t max_iter, double tol,
+                  size_t *its_out, double *res_out);
+
+   private:
+    template <class V>
+    int run(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out, double *res_out);
+    template <class V>
+    int run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out, double *res_out);
+};
+
+template <class T>
+template <class F>
+int KrylovBase<T>::solve_host(const T *rhs, size_t rhs_len, T *x, size_t x_len, F &&dev_solve) {
+    // size checks first (bicg_stab.rs:44-53): nothing is copied on a mismatch
+    if (rhs_len != n) return SPRS_INCOMPATIBLE_RHS_SIZE;
+    if (x_len != n) return SPRS_INCOMPATIBLE_X_SIZE;
+    SPRS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!rhs_buf) SPRS_HIP_TRY(ctx, hipMalloc((void **)&rhs_buf, sizeof(T) * stride));
+    if (!x_buf) SPRS_HIP_TRY(ctx, hipMalloc((void **)&x_buf, sizeof(T) * stride));
+    SPRS_HIP_TRY(ctx, hipMemcpyAsync(rhs_buf, rhs, sizeof(T) * n, hipMemcpyHostToDevice, ctx->stream));
+    SPRS_HIP_TRY(ctx, hipMemcpyAsync(x_buf, x, sizeof(T) * n, hipMemcpyHostToDevice, ctx->stream));
+    int st = dev_solve(rhs_buf, x_buf);
+    if (st >= SPRS_ERR_HIP) return st;
+    // x is in/out in the reference and is left modified on Err as well
+    SPRS_HIP_TRY(ctx, hipMemcpyAsync(x, x_buf, sizeof(T) * n, hipMemcpyDeviceToHost, ctx->stream));
+    SPRS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return st;
+}
+
+}  // namespace sprs
+
+// opaque C handles: type-erased over T
+struct sprs_bicgstab {
+    int is_complex;
+    void *impl;
+};
+struct sprs_minres {
+    int is_complex;
+    void *impl;
+};
+struct sprs_csminres {
+    int is_complex;
+    void *impl;
+};

@@ -1,0 +1,191 @@
+// CSR SpMV for gfx950 — the dominant kernel of the path (reference src/mat.rs:68-129).
+//
+// Design (MI355X-first, not a translation of the rayon loop):
+//  * The HBM-resident stream is (col_idx, val): 12 B/nnz for f64.  It is read with fully
+//    coalesced loads — consecutive lanes take consecutive nnz — regardless of row length.
+//  * "stream" row blocks (rows of <= LONG_ROW nnz; every BASELINE config): a workgroup takes a
+//    run of consecutive rows whose nnz fit in LDS, writes the products x[col]*val into LDS in
+//    nnz order, then one lane per row adds its row's products left to right starting from
+//    zero.  That is exactly the reference's fold (mat.rs:100-105: acc + x[col]*val, unfused),
+//    so y is BIT-IDENTICAL to the reference for these rows.
+//  * "vector" row blocks (rows longer than LONG_ROW): one wavefront per row, lanes stride the
+//    row with coalesced loads, 64-lane __shfl_down butterfly.  Sums are re-associated
+//    (documented tolerance: relative 1e-13 of sum |x*val|).
+//  * Row blocks are computed once at handle creation (the analogue of mkl_sparse_optimize,
+//    src/mkl_mat.rs:81-148).  The grid is persistent (<= ctx->grid workgroups) and, with
+//    xcd_chunk, each XCD walks its own contiguous chunk of row blocks so the x-gather of
+//    neighbouring rows hits that XCD's L2.
+//  * Optional fused epilogue: per-workgroup partials of conj(u).y, or of conj(y).y and
+//    conj(y).u, so the solvers' dot products cost no extra pass over y.
+#include "device.hpp"
+
+namespace sprs {
+
+constexpr int ROWS_CAP = BLOCK;   // rows per stream block: one lane per row in the reduce phase
+constexpr int LONG_ROW = 96;      // rows longer than this go to the wavefront-per-row path
+constexpr uint32_t VEC_FLAG = 0x80000000u;
+
+template <class T> struct nnz_cap { static constexpr int value = 2048; };       // 16 KiB LDS
+template <> struct nnz_cap<cplx> { static constexpr int value = 1280; };        // 20 KiB LDS
+
+// Host-side analysis: greedy partition of the rows into blocks (see header comment).
+int build_rowblocks(sprs_csr *A, const int32_t *rp) {
+    const int cap = A->is_complex ? nnz_cap<cplx>::value : nnz_cap<double>::value;
+    std::vector<int32_t> blk;
+    blk.reserve((size_t)(A->nrows / ROWS_CAP + 16));
+    int64_t r = 0;
+    const int64_t n = A->nrows;
+    while (r < n) {
+        int64_t len = (int64_t)rp[r + 1] - rp[r];
+        if (len > LONG_ROW) {  // vector block: up to NWAVE consecutive long rows
+            int64_t e = r + 1;
+            while (e < n && e - r < NWAVE && (int64_t)rp[e + 1] - rp[e] > LONG_ROW) ++e;
+            blk.push_back((int32_t)((uint32_t)r | VEC_FLAG));
+            r = e;
+        } else {
+            int64_t e = r + 1;
+            const int64_t base = rp[r];
+            while (e < n && e - r < ROWS_CAP) {
+                int64_t l2 = (int64_t)rp[e + 1] - rp[e];
+                if (l2 > LONG_ROW || (int64_t)rp[e + 1] - base > cap) break;
+                ++e;
+            }
+            blk.push_back((int32_t)r);
+            r = e;
+        }
+    }
+    blk.push_back((int32_t)n);
+    A->n_rowblk = (int32_t)blk.size() - 1;
+    sprs_ctx *c = A->ctx;
+    SPRS_HIP_TRY(c, hipMalloc((void **)&A->rowblk, blk.size() * sizeof(int32_t)));
+    SPRS_HIP_TRY(c, hipMemcpyAsync(A->rowblk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPRS_OK;
+}
+
+template <class T, int DOT, bool CONJX>
+__global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk, const int32_t *__restrict__ rowblk,
+                                                     const int32_t *__restrict__ row_ptr,
+                                                     const int32_t *__restrict__ col_idx, const T *__restrict__ val,
+                                                     const T *__restrict__ x, T *__restrict__ y,
+                                                     const T *__restrict__ u, T *__restrict__ part0,
+                                                     T *__restrict__ part1, const int *__restrict__ status) {
+    constexpr int CAP = nnz_cap<T>::value;
+    constexpr int ITEMS = CAP / BLOCK;
+    __shared__ T prod[CAP];
+    __shared__ T red[NWAVE];
+    if (status != nullptr && *status != ST_RUNNING) return;
+
+    const int tid = threadIdx.x;
+    T d0 = szero<T>(), d1 = szero<T>();
+
+    // persistent walk over row blocks; with xcd_chunk the 8 XCDs (workgroup id mod 8, observed
+    // round-robin placement — a locality hint only, never needed for correctness) each own a
+    // contiguous eighth of the row blocks.
+    int b, bstep, bend;
+    if (xcd_chunk) {
+        const int chunk = (n_rowblk + 7) >> 3;
+        const int xcd = blockIdx.x & 7;
+        b = xcd * chunk + (blockIdx.x >> 3);
+        bstep = gridDim.x >> 3;
+        bend = min(n_rowblk, (xcd + 1) * chunk);
+    } else {
+        b = blockIdx.x; bstep = gridDim.x; bend = n_rowblk;
+    }
+
+    for (; b < bend; b += bstep) {
+        const uint32_t rb0 = (uint32_t)rowblk[b];
+        const int ra = (int)(rb0 & ~VEC_FLAG);
+        const int rb = (int)((uint32_t)rowblk[b + 1] & ~VEC_FLAG);
+        if (!(rb0 & VEC_FLAG)) {
+            // ---------------- stream block: products to LDS, then one lane per row
+            const int pa = row_ptr[ra];
+            const int nn = row_ptr[rb] - pa;
+            int cidx[ITEMS];
+            T vv[ITEMS];
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int k = tid + i * BLOCK;
+                if (k < nn) { cidx[i] = col_idx[pa + k]; vv[i] = val[pa + k]; }
+            }
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int k = tid + i * BLOCK;
+                if (k < nn) prod[k] = smul(CONJX ? sconj(x[cidx[i]]) : x[cidx[i]], vv[i]);   // mat.rs:104  x[col] * val
+            }
+            __syncthreads();
+            const int r = ra + tid;
+            if (r < rb) {
+                const int s = row_ptr[r] - pa, e = row_ptr[r + 1] - pa;
+                T acc = szero<T>();                               // mat.rs:103  fold(T::zero(), ..)
+                for (int k = s; k < e; ++k) acc = sadd(acc, prod[k]);
+                y[r] = acc;
+                if (DOT == 1) d0 = sadd(d0, smul(sconj(u[r]), acc));
+                if (DOT == 2) { d0 = sadd(d0, smul(sconj(acc), acc)); d1 = sadd(d1, smul(sconj(acc), u[r])); }
+            }
+            __syncthreads();  // prod[] is rewritten by the next row block
+        } else {
+            // ---------------- vector block: one wavefront per (long) row
+            const int lane = tid & (WAVE - 1);
+            const int r = ra + (tid >> 6);
+            if (r < rb) {
+                const int s = row_ptr[r], e = row_ptr[r + 1];
+                T acc = szero<T>();
+                for (int k = s + lane; k < e; k += WAVE) acc = sadd(acc, smul(CONJX ? sconj(x[col_idx[k]]) : x[col_idx[k]], val[k]));
+                acc = wave_sum(acc);
+                if (lane == 0) {
+                    y[r] = acc;
+                    if (DOT == 1) d0 = sadd(d0, smul(sconj(u[r]), acc));
+                    if (DOT == 2) { d0 = sadd(d0, smul(sconj(acc), acc)); d1 = sadd(d1, smul(sconj(acc), u[r])); }
+                }
+            }
+        }
+    }
+    if (DOT >= 1) {
+        d0 = block_sum(d0, red);
+        if (tid == 0) part0[blockIdx.x] = d0;
+    }
+    if (DOT == 2) {
+        d1 = block_sum(d1, red);
+        if (tid == 0) part1[blockIdx.x] = d1;
+    }
+}
+
+// number of workgroups launch_spmv uses == number of partials it writes
+static inline int spmv_grid(const sprs_csr *A) {
+    int g = grid_for(A->ctx);
+    // at least one row block per workgroup, keep it a multiple of 8 (one slice per XCD)
+    int need = ((A->n_rowblk + 7) / 8) * 8;
+    if (need < 8) need = 8;
+    return g < need ? g : need;
+}
+
+template <class T>
+int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status,
+                bool conj_x) {
+    sprs_ctx *c = A->ctx;
+    const int g = spmv_grid(A);
+    const T *v = reinterpret_cast<const T *>(A->val);
+#define SPRS_SPMV(D, CJ)                                                                                              \
+    hipLaunchKernelGGL((spmv_kernel<T, D, CJ>), dim3(g), dim3(BLOCK), 0, c->stream, (int)A->n_rowblk, c->xcd_chunk,   \
+                       A->rowblk, A->row_ptr, A->col_idx, v, x, y, u, part0, part1, status)
+    if (conj_x && is_complex<T>::value) {  // only CSMINRES on complex data needs the conjugated gather
+        if (dot_mode == 0) SPRS_SPMV(0, true);
+        else if (dot_mode == 1) SPRS_SPMV(1, true);
+        else SPRS_SPMV(2, true);
+    } else {
+        if (dot_mode == 0) SPRS_SPMV(0, false);
+        else if (dot_mode == 1) SPRS_SPMV(1, false);
+        else SPRS_SPMV(2, false);
+    }
+#undef SPRS_SPMV
+    SPRS_HIP_TRY(c, hipGetLastError());
+    return SPRS_OK;
+}
+
+int spmv_num_partials(const sprs_csr *A) { return spmv_grid(A); }
+
+template int launch_spmv<double>(const sprs_csr *, const double *, double *, int, const double *, double *, double *, const int *, bool);
+template int launch_spmv<cplx>(const sprs_csr *, const cplx *, cplx *, int, const cplx *, cplx *, cplx *, const int *, bool);
+
+}  // namespace sprs

@@ -1,0 +1,540 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden
+fixtures.  Bit-exact wherever the arithmetic order is the reference's (element-wise BLAS-1,
+Jacobi apply, SpMV rows handled by the stream path); stated tolerances for reductions."""
+import numpy as np
+import pytest
+
+import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+RED_RTOL = 1e-13      # dot / nrm2: same terms, different summation order (relative to sum |terms|)
+TRACE_RTOL = 1e-9     # lock-step scalar trace over the first iterations (SURVEY §7 hard parts (ii))
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import sprsolve_amd
+    from sprsolve_amd import _lib
+    _lib.lib()          # fail loudly if the HIP extension is missing
+    sprsolve_amd.default_ctx(0)
+    return sprsolve_amd
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+def rand_vec(n, dtype, seed):
+    rng = np.random.default_rng(seed)
+    if np.dtype(dtype) == np.complex128:
+        return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex128)
+    return rng.uniform(-1, 1, n)
+
+
+# ------------------------------------------------------------------ SpMV
+@pytest.mark.parametrize("case", G.load("spmv_kat.json")["cases"], ids=lambda c: c["name"])
+def test_spmv_golden(sa, oracle, case):
+    indptr, indices, data, x, exp = G.spmv_case(case)
+    A = sa.HipCsr.new(case["shape"], indptr, indices, data, storage=case["storage"])
+    y = np.full(5, 7.0, dtype=data.dtype)      # must be overwritten (zero fill, mat.rs:71)
+    A.mul_vec(x, y)
+    assert np.all(np.abs(y - exp) < case["eps"] * 1.5)
+    ref = (oracle.spmv_csc(5, indptr, indices, data, x) if case["storage"] == "CSC"
+           else oracle.spmv(indptr, indices, data, x))
+    assert np.array_equal(bits(y), bits(ref)), "short rows must be bit-identical to the reference fold"
+    y2 = np.zeros_like(y)
+    d = A.mul_vec_dot(x, y2)                    # mkl_mat.rs:432-463
+    assert np.array_equal(bits(y2), bits(ref))
+    e = oracle.conj_dot(x, ref)
+    assert abs(d - e) <= 1e-14 * max(1.0, abs(e))
+
+
+def test_spmv_dimension_mismatch(sa):
+    case = G.load("spmv_kat.json")["cases"][1]
+    indptr, indices, data, x, exp = G.spmv_case(case)
+    A = sa.HipCsr.new((5, 5), indptr, indices, data)
+    with pytest.raises(sa.error.DimensionMismatch):
+        A.mul_vec(np.zeros(4), np.zeros(4))
+    with pytest.raises(sa.error.DimensionMismatch):
+        A.mul_vec(np.zeros(5), np.zeros(6))
+    with pytest.raises(ValueError):
+        sa.HipCsr.new((5, 5), indptr, np.array([1, 2, 9, 2, 3, 4, 4]), data)   # column out of range
+    with pytest.raises(ValueError):
+        sa.HipCsr.new((5, 5), np.array([0, 3, 2, 5, 6, 7]), indices, data)     # non-monotone indptr
+
+
+def random_csr(n, seed, dtype, long_rows=True):
+    """Ragged random CSR: empty rows, 1..9-nnz rows, and a few rows longer than the
+    wavefront-per-row threshold."""
+    rng = np.random.default_rng(seed)
+    cnt = rng.integers(0, 10, n)
+    cnt[rng.integers(0, n, max(1, n // 50))] = 0
+    if long_rows and n > 400:
+        for r in rng.integers(0, n, 6):
+            cnt[r] = rng.integers(97, 400)
+        cnt[n // 2] = min(n, 3000)
+        cnt[n // 2 + 1] = 130          # consecutive long rows share a vector block
+    indptr = np.zeros(n + 1, dtype=np.int64); np.cumsum(cnt, out=indptr[1:])
+    indices = np.concatenate([np.sort(rng.choice(n, c, replace=False)) for c in cnt]) if indptr[-1] else np.zeros(0, int)
+    data = rand_vec(int(indptr[-1]), dtype, seed + 1)
+    return indptr.astype(np.int32), indices.astype(np.int32), data, cnt
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128], ids=["f64", "c64"])
+@pytest.mark.parametrize("n", [1, 63, 257, 5000, 40001])
+def test_spmv_random_ragged(sa, oracle, dtype, n):
+    indptr, indices, data, cnt = random_csr(n, 100 + n, dtype)
+    x = rand_vec(n, dtype, 7)
+    A = sa.HipCsr.new((n, n), indptr, indices, data)
+    y = np.empty(n, dtype=dtype)
+    A.mul_vec(x, y)
+    ref = oracle.spmv(indptr, indices, data, x)
+    short = cnt <= 96
+    assert np.array_equal(bits(y[short]), bits(ref[short])), "stream-path rows must be bit-exact"
+    if (~short).any():
+        # wavefront-per-row path: re-associated sum, tolerance relative to sum |x*val|
+        absA = oracle.spmv(indptr, indices, np.abs(data).astype(dtype), np.abs(x).astype(dtype))
+        assert np.all(np.abs(y[~short] - ref[~short]) <= RED_RTOL * np.abs(absA[~short]))
+    # i64 / u32 index ingest (mat.rs:196-199) gives the same bits
+    for idt in (np.int64, np.uint32, np.uint64):
+        B = sa.HipCsr.new((n, n), indptr.astype(idt), indices.astype(idt), data)
+        y2 = np.empty(n, dtype=dtype); B.mul_vec(x, y2)
+        assert np.array_equal(bits(y2), bits(y))
+        B.close()
+
+
+def test_spmv_empty_matrix(sa):
+    A = sa.HipCsr.new((4, 4), np.zeros(5, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    y = np.ones(4); A.mul_vec(np.ones(4), y)
+    assert np.array_equal(y, np.zeros(4))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128], ids=["f64", "c64"])
+def test_spmv_csc_matches_reference_scatter(sa, oracle, dtype):
+    import scipy.sparse as sp
+    n = 700
+    indptr, indices, data, _ = random_csr(n, 5, dtype, long_rows=False)
+    M = sp.csr_matrix((data, indices, indptr), shape=(n, n)).tocsc()
+    x = rand_vec(n, dtype, 9)
+    A = sa.HipCsr.new((n, n), M.indptr, M.indices, M.data, storage="CSC")
+    y = np.empty(n, dtype=dtype); A.mul_vec(x, y)
+    ref = oracle.spmv_csc(n, M.indptr, M.indices, M.data, x)
+    assert np.array_equal(bits(y), bits(ref))
+
+
+def test_spmv_device_vectors_and_grid_options(sa, oracle):
+    from sprsolve_amd import gen
+    indptr, indices, data = gen.grid_laplacian_dirichlet(300, 300)
+    n = 300 * 300
+    x = rand_vec(n, np.float64, 3)
+    ref = oracle.spmv(indptr, indices, data, x)
+    A = sa.HipCsr.new((n, n), indptr, indices, data)
+    ctx = sa.default_ctx()
+    g0, c0 = ctx.get("grid"), ctx.get("xcd_chunk")
+    try:
+        for grid, chunk in ((g0, 1), (g0, 0), (8, 1), (64, 0), (4096, 1)):
+            ctx.set("grid", grid); ctx.set("xcd_chunk", chunk)
+            dx = sa.DevVec.from_numpy(x); dy = sa.DevVec(n, np.float64); dy.upload(np.full(n, np.nan))
+            A.mul_vec_unchecked(dx, dy)
+            assert np.array_equal(bits(dy.to_numpy()), bits(ref)), (grid, chunk)
+            d = A.mul_vec_dot_unchecked(dx, dy)
+            e = oracle.conj_dot(x, ref)
+            assert abs(d - e) <= RED_RTOL * np.sum(np.abs(x * ref))
+    finally:
+        ctx.set("grid", g0); ctx.set("xcd_chunk", c0)
+
+
+# ------------------------------------------------------------------ vecalg
+def _run_vecalg(va, case):
+    dt = case["dtype"]; op = case["op"]
+    x = G.vec(case["x"], dt)
+    if op == "norm2":
+        return va.norm2(x)
+    if op in ("dot", "conj_dot"):
+        return getattr(va, op)(x, G.vec(case["y"], dt))
+    if op == "scale":
+        va.scale(G.scalar(case["a"], dt), x); return x
+    if op == "rscale":
+        va.rscale(case["a"], x); return x
+    if op == "conj":
+        out = np.empty_like(x); va.conj(x, out); return out
+    if op == "axpy":
+        y = G.vec(case["y"], dt)
+        a = float(case["a_real"]) if "a_real" in case else G.scalar(case["a"], dt)
+        va.axpy(a, x, y); return y
+    if op == "axpy_repeat":
+        y = G.vec(case["y"], dt)
+        for _ in range(case["repeat"]):
+            va.axpy(G.scalar(case["a"], dt), x, y)
+        return y
+    raise KeyError(op)
+
+
+@pytest.mark.parametrize("case", G.load("vecalg_kat.json")["cases"], ids=lambda c: c["name"])
+def test_vecalg_golden(sa, case):
+    va = sa.vecalg
+    dt = case["dtype"]; eps = case.get("eps", 1e-13)
+    if case["op"] == "axpby_sequence":
+        x = G.vec(case["x"], dt); y = G.vec(case["y"], dt)
+        for st in case["steps"]:
+            for _ in range(st["repeat"]):
+                va.axpby(G.scalar(st["a"], dt), x, G.scalar(st["b"], dt), y)
+            assert np.all(np.abs(y - st["expected_fill"]) <= eps)
+        return
+    got = _run_vecalg(va, case)
+    if "expected" in case:
+        assert abs(got - G.scalar(case["expected"], dt)) <= eps
+    elif "expected_fill" in case:
+        assert np.all(np.abs(got - G.scalar(case["expected_fill"], dt)) <= eps)
+    else:
+        assert np.all(np.abs(got - G.vec({"array": case["expected_array"]}, dt)) <= eps)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128], ids=["f64", "c64"])
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1023, 100003, 1 << 20])
+def test_vecalg_random_vs_oracle(sa, oracle, dtype, n):
+    va = sa.vecalg
+    x = rand_vec(n, dtype, 11); y = rand_vec(n, dtype, 12)
+    a = rand_vec(1, dtype, 13)[0]; b = rand_vec(1, dtype, 14)[0]
+    a = complex(a) if dtype == np.complex128 else float(a)
+    b = complex(b) if dtype == np.complex128 else float(b)
+    # element-wise ops: same rounding sequence => bit-exact
+    yy = y.copy(); va.axpy(a, x, yy)
+    assert np.array_equal(bits(yy), bits(oracle.axpy(a, x, y.copy())))
+    yy = y.copy(); va.axpby(a, x, b, yy)
+    assert np.array_equal(bits(yy), bits(oracle.axpby(a, x, b, y.copy())))
+    xx = x.copy(); va.scale(a, xx)
+    assert np.array_equal(bits(xx), bits(oracle.scale(a, x.copy())))
+    xx = x.copy(); va.rscale(0.3, xx)
+    assert np.array_equal(bits(xx), bits(oracle.rscale(0.3, x.copy())))
+    out = np.empty_like(x); va.conj(x, out)
+    assert np.array_equal(bits(out), bits(oracle.conj(x)))
+    if dtype == np.complex128:
+        yy = y.copy(); va.axpy(0.7, x, yy)        # S = f64, T = Complex<f64>
+        assert np.array_equal(bits(yy), bits(oracle.axpy(0.7, x, y.copy())))
+    # reductions: tolerance relative to the sum of magnitudes
+    mag = float(np.sum(np.abs(x) * np.abs(y)))
+    assert abs(va.dot(x, y) - oracle.dot(x, y)) <= RED_RTOL * max(mag, 1e-300)
+    assert abs(va.conj_dot(x, y) - oracle.conj_dot(x, y)) <= RED_RTOL * max(mag, 1e-300)
+    assert abs(va.norm2(x) - oracle.norm2(x)) <= RED_RTOL * max(oracle.norm2(x), 1e-300)
+
+
+def test_vecalg_unaligned_device_views(sa, oracle):
+    """Vectors that start 8 bytes off a 16-byte boundary take the scalar-access kernels."""
+    import ctypes as C
+    n = 10001
+    x = rand_vec(n + 1, np.float64, 1); y = rand_vec(n + 1, np.float64, 2)
+    dx = sa.DevVec.from_numpy(x); dy = sa.DevVec.from_numpy(y)
+
+    class View:      # a device vector one element into another
+        def __init__(self, base, n):
+            self.base, self.n = base, n
+            self.is_cuda, self.dtype = True, "float64"
+        def data_ptr(self): return self.base.ptr.value + 8
+        def numel(self): return self.n
+    vx, vy = View(dx, n), View(dy, n)
+    sa.vecalg.axpy(0.5, vx, vy)
+    ref = oracle.axpy(0.5, x[1:], y[1:].copy())
+    assert np.array_equal(bits(dy.to_numpy()[1:]), bits(ref))
+    assert abs(sa.vecalg.dot(vx, vy) - oracle.dot(x[1:], ref)) <= RED_RTOL * np.sum(np.abs(x[1:] * ref))
+
+
+# ------------------------------------------------------------------ Jacobi preconditioner
+def test_diag_precond(sa, oracle):
+    n = 5003
+    d = rand_vec(n, np.float64, 1) + 2.0
+    v = rand_vec(n, np.float64, 2)
+    P = sa.DiagPrecond.new(d)
+    out = np.empty(n); P.mul_vec(v, out)
+    assert np.array_equal(bits(out), bits(oracle.diag_apply(oracle.diag_inv(d), v)))
+    vz = rand_vec(n, np.complex128, 3)
+    Pzd = sa.DiagPrecond.new(d, t_dtype=np.complex128)      # DiagPrecond<Complex64, f64>
+    outz = np.empty(n, np.complex128); Pzd.mul_vec(vz, outz)
+    assert np.array_equal(bits(outz), bits(oracle.diag_apply(oracle.diag_inv(d), vz)))
+    dz = rand_vec(n, np.complex128, 4) + 2.0
+    Pz = sa.DiagPrecond.new(dz)                              # DiagPrecond<Complex64, Complex64>
+    Pz.mul_vec(vz, outz)
+    assert np.array_equal(bits(outz), bits(oracle.diag_apply(oracle.diag_inv(dz), vz)))
+    with pytest.raises(sa.error.DimensionMismatch):
+        P.mul_vec(np.zeros(n - 1), np.zeros(n - 1))
+    with pytest.raises(NotImplementedError):
+        P.mul_vec_dot(v, out)
+
+
+# ------------------------------------------------------------------ solvers
+def _make(sa, case, p):
+    n = p["rhs"].size
+    A = sa.HipCsr.new((n, n), p["indptr"], p["indices"], p["data"])
+    cls = {"bicgstab": sa.BiCGStab, "minres": sa.MinRes, "csminres": sa.CSMinRes}[case["solver"]]
+    solver = cls.new(A, A.cols())
+    pc = None
+    if p["diag"] is not None:
+        pc = sa.DiagPrecond.new(p["diag"], t_dtype=p["data"].dtype)
+    return A, solver, pc
+
+
+@pytest.mark.parametrize("mode", ["fused", "literal"])
+@pytest.mark.parametrize("case", G.load("solver_kat.json")["cases"], ids=lambda c: c["name"])
+def test_solver_golden(sa, oracle, case, mode):
+    """The reference's integration tests (assert Ok) + the exact solutions they imply."""
+    p = G.solver_problem(case)
+    A, solver, pc = _make(sa, case, p)
+    solver.set_mode(mode)
+    x = np.zeros_like(p["rhs"])
+    # sub-epsilon tolerances make the iteration count reduction-order noise: the
+    # reference asserts only Ok; we assert Ok and the implied exact solution
+    if pc is not None:
+        iters, res = solver.precond_solve(pc, p["rhs"], x, case["max_iter"], case["tol"])
+    else:
+        iters, res = solver.solve(p["rhs"], x, case["max_iter"], case["tol"])
+    scale = max(1.0, np.max(np.abs(p["exact"])))
+    assert np.max(np.abs(x - p["exact"])) / scale < 1e-9, (iters, res)
+    true_res = np.linalg.norm(oracle.spmv(p["indptr"], p["indices"], p["data"], x) - p["rhs"]) / np.linalg.norm(p["rhs"])
+    assert true_res < 1e-10
+    assert res <= case["tol"]
+
+
+@pytest.mark.parametrize("mode", ["fused", "literal"])
+@pytest.mark.parametrize("case", G.load("solver_kat.json")["cases"], ids=lambda c: c["name"])
+def test_solver_trace_lockstep(sa, oracle, case, mode):
+    """Scalars of the recurrence agree with the oracle's in lock-step over the first iterations."""
+    p = G.solver_problem(case)
+    A, solver, pc = _make(sa, case, p)
+    solver.set_mode(mode)
+    K = 8
+    solver.set_trace(K)
+    x = np.zeros_like(p["rhs"])
+    try:
+        if pc is not None:
+            solver.precond_solve(pc, p["rhs"], x, K, 0.0)
+        else:
+            solver.solve(p["rhs"], x, K, 0.0)
+    except sa.error.InsufficientIterNum as e:
+        assert e.iters == K
+    tr = solver.trace()
+    ref = getattr(oracle, case["solver"])(p["indptr"], p["indices"], p["data"], p["rhs"], np.zeros_like(p["rhs"]),
+                                          K, 0.0, precond_diag=p["diag"], trace_cap=K)
+    assert ref.status == oracle.INSUFFICIENT_ITER
+    assert tr.shape == ref.trace.shape and tr.shape[0] == K
+    assert np.array_equal(tr[:, 0], ref.trace[:, 0])
+    # the bench-style Dirichlet problems make rho at its=1 a pure rounding residue:
+    # compare every scalar relative to the scale of its column instead of element-wise
+    scale = np.maximum(np.max(np.abs(ref.trace), axis=0), 1e-300)
+    assert np.all(np.abs(tr - ref.trace) <= 1e-6 * scale), np.abs(tr - ref.trace) / scale
+    xerr = np.max(np.abs(x - ref.x)) / max(1.0, np.max(np.abs(ref.x)))
+    assert xerr < 1e-6
+
+
+def _dense_case(c, copies=1):
+    import scipy.sparse as sp
+    M = np.array(c["A"], float)
+    A = sp.block_diag([sp.csr_matrix(M)] * copies, format="csr")
+    b = np.tile(np.array(c["b"], float), copies)
+    return A, b
+
+
+@pytest.mark.parametrize("copies", [1, 700])
+@pytest.mark.parametrize("case", G.load("branch_kat.json")["restart"], ids=lambda c: c["name"])
+def test_bicgstab_restart_branch(sa, oracle, case, copies):
+    """bicg_stab.rs:131-145: rho == 0 exactly at its=1 -> r, r0, rho are rebuilt."""
+    M, b = _dense_case(case, copies)
+    ref = oracle.bicgstab(M.indptr, M.indices, M.data, b, np.zeros_like(b), case["max_iter"], case["tol"], trace_cap=4)
+    assert ref.trace[1][2] == ref.trace[1][1] ** 2 or np.isclose(ref.trace[1][2], ref.trace[1][1] ** 2, rtol=1e-15)
+    A = sa.HipCsr.from_scipy(M)
+    for mode in ("fused", "literal"):
+        s = sa.BiCGStab.new(A, A.cols()); s.set_mode(mode); s.set_trace(4)
+        x = np.zeros_like(b)
+        try:
+            its, res = s.solve(b, x, case["max_iter"], case["tol"])
+            st = oracle.OK
+        except sa.error.InsufficientIterNum as e:
+            its, st = e.iters, oracle.INSUFFICIENT_ITER
+        assert st == ref.status and its == ref.its
+        tr = s.trace()
+        # the restart replaces rho by |A x - b|^2 at its=1 — visible in the trace
+        assert np.isclose(tr[1][2], ref.trace[1][2], rtol=1e-12)
+        if ref.status == oracle.OK:
+            assert np.allclose(x, ref.x, rtol=1e-9, atol=1e-12)
+        else:
+            assert np.array_equal(np.isnan(x), np.isnan(ref.x))
+
+
+@pytest.mark.parametrize("case", G.load("branch_kat.json")["breakdown"], ids=lambda c: c["name"])
+def test_bicgstab_breakdown_branch(sa, oracle, case):
+    """bicg_stab.rs:164-167: |r0.v| <= 0 -> Err(BreakDown(its))."""
+    M, b = _dense_case(case)
+    ref = oracle.bicgstab(M.indptr, M.indices, M.data, b, np.zeros_like(b), case["max_iter"], case["tol"])
+    assert ref.status == oracle.BREAKDOWN
+    A = sa.HipCsr.from_scipy(M)
+    for mode in ("fused", "literal"):
+        s = sa.BiCGStab.new(A, A.cols()); s.set_mode(mode)
+        x = np.zeros_like(b)
+        with pytest.raises(sa.error.BreakDown) as ei:
+            s.solve(b, x, case["max_iter"], case["tol"])
+        assert ei.value.its == ref.its
+        assert np.allclose(x, ref.x, rtol=1e-12, atol=1e-14)
+
+
+def test_solver_error_paths(sa, oracle):
+    from sprsolve_amd import gen
+    indptr, indices, data = gen.grid_laplacian_dirichlet(12, 12)
+    rhs = gen.dirichlet_rhs(12, 12)
+    n = 144
+    A = sa.HipCsr.new((n, n), indptr, indices, data)
+    for cls in (sa.BiCGStab, sa.MinRes, sa.CSMinRes):
+        s = cls.new(A, n)
+        with pytest.raises(sa.error.IncompatibleMatrixFormat, match="doesn't match the matrix size"):
+            s.solve(rhs[:-1], np.zeros(n - 1), 10, 1e-8)
+        with pytest.raises(sa.error.IncompatibleMatrixFormat, match="do not match"):
+            s.solve(rhs, np.zeros(n + 1), 10, 1e-8)
+        # rhs == 0: x := 0, Ok((0, rhs_norm))  (bicg_stab.rs:56-60 — absolute, not relative)
+        x = np.ones(n)
+        assert s.solve(np.zeros(n), x, 10, 1e-8) == (0, 0.0)
+        assert not x.any()
+    s = sa.BiCGStab.new(A, n)
+    # convergence is tested at the top of the loop: max_iter iterations without the final check
+    x = np.zeros(n)
+    with pytest.raises(sa.error.InsufficientIterNum) as ei:
+        s.solve(rhs, x, 3, 1e-30)
+    assert ei.value.iters == 3
+    ref = oracle.bicgstab(indptr, indices, data, rhs, np.zeros(n), 3, 1e-30)
+    assert np.allclose(x, ref.x, rtol=1e-10, atol=1e-12)
+    # warm start from the exact solution: Ok((0, ...)) before any iteration (bicg_stab.rs:81-83)
+    i, j = np.meshgrid(np.arange(12), np.arange(12), indexing="ij")
+    x = (i + j).ravel().astype(float)
+    its, res = s.solve(rhs, x, 10, 1e-12)
+    assert its == 0 and res <= 1e-12
+    # solver handles of the wrong size are refused instead of indexing out of bounds
+    with pytest.raises(sa.error.DimensionMismatch):
+        sa.BiCGStab.new(A, n + 1)
+
+
+def test_minres_invalid_preconditioner(sa, oracle):
+    """minres.rs:236-244: r^H M^-1 r must be positive — a negative diagonal is rejected."""
+    from sprsolve_amd import gen
+    indptr, indices, data, rhs = gen.symmetric_banded(300)
+    n = 300
+    A = sa.HipCsr.new((n, n), indptr, indices, data)
+    s = sa.MinRes.new(A, n)
+    bad = sa.DiagPrecond.new(-np.ones(n))
+    with pytest.raises(sa.error.InvalidPreconditioner):
+        s.precond_solve(bad, rhs, np.zeros(n), 50, 1e-10)
+    ref = oracle.minres(indptr, indices, data, rhs, np.zeros(n), 50, 1e-10, precond_diag=-np.ones(n))
+    assert ref.status == oracle.INVALID_PRECOND
+    # an indefinite diagonal fails later, inside the loop (minres.rs:279-287), at the same iteration
+    d = np.ones(n); d[::2] = -1.0
+    ref = oracle.minres(indptr, indices, data, rhs, np.zeros(n), 50, 1e-10, precond_diag=d)
+    P = sa.DiagPrecond.new(d)
+    x = np.zeros(n)
+    if ref.status == oracle.INVALID_PRECOND:
+        with pytest.raises(sa.error.InvalidPreconditioner):
+            s.precond_solve(P, rhs, x, 50, 1e-10)
+
+
+@pytest.mark.parametrize("mode", ["fused", "literal"])
+def test_csminres_complex_symmetric(sa, oracle, mode):
+    """CSMinRes has no test upstream: complex-symmetric grid of
+    tests/test_complex_solve2.rs with its implied exact solution, lock-step with the oracle."""
+    from sprsolve_amd import gen
+    for rows, cols in ((8, 8), (40, 60)):
+        indptr, indices, data, rhs, diag = gen.complex_symmetric_grid(rows, cols)
+        n = rows * cols
+        A = sa.HipCsr.new((n, n), indptr, indices, data)
+        s = sa.CSMinRes.new(A, n); s.set_mode(mode)
+        x = np.zeros(n, np.complex128)
+        its, res = s.solve(rhs, x, 2000, 1e-12)
+        ref = oracle.csminres(indptr, indices, data, rhs, np.zeros(n, np.complex128), 2000, 1e-12)
+        assert ref.status == oracle.OK
+        assert abs(its - ref.its) <= max(3, ref.its // 20)
+        assert np.max(np.abs(x - gen.grid_exact_solution(rows, cols))) < 1e-8
+        K = 6
+        s.set_trace(K); x[:] = 0
+        with pytest.raises(sa.error.InsufficientIterNum):
+            s.solve(rhs, x, K, 0.0)
+        reft = oracle.csminres(indptr, indices, data, rhs, np.zeros(n, np.complex128), K, 0.0, trace_cap=K)
+        tr = s.trace()
+        assert np.allclose(tr, reft.trace, rtol=TRACE_RTOL, atol=1e-12)
+        s.set_trace(0)
+
+
+def test_device_resident_solve(sa, oracle):
+    """The *_solve_dev entry points: rhs / x stay in HBM."""
+    from sprsolve_amd import gen
+    indptr, indices, data = gen.grid_laplacian_dirichlet(64, 64)
+    rhs = gen.dirichlet_rhs(64, 64)
+    n = 64 * 64
+    A = sa.HipCsr.new((n, n), indptr, indices, data)
+    P = sa.DiagPrecond.new(np.where(np.diff(indptr) == 1, 1.0, -4.0))
+    s = sa.BiCGStab.new(A, n)
+    drhs = sa.DevVec.from_numpy(rhs); dx = sa.DevVec(n, np.float64); dx.zero()
+    its, res = s.precond_solve(P, drhs, dx, 2000, 1e-10)
+    i, j = np.meshgrid(np.arange(64), np.arange(64), indexing="ij")
+    assert np.max(np.abs(dx.to_numpy() - (i + j).ravel())) < 1e-6
+    ref = oracle.bicgstab(indptr, indices, data, rhs, np.zeros(n), 2000, 1e-10,
+                          precond_diag=np.where(np.diff(indptr) == 1, 1.0, -4.0))
+    assert ref.status == oracle.OK and abs(its - ref.its) <= max(5, ref.its // 4)
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE configs)
+def test_cfg2_poisson2d_1m_properties(sa):
+    """BASELINE cfg 2 at full size (1 M rows): size-independent properties instead of the oracle."""
+    from sprsolve_amd import gen
+    R = 1000
+    indptr, indices, data = gen.grid_laplacian_dirichlet(R, R)
+    rhs = gen.dirichlet_rhs(R, R)
+    n = R * R
+    assert indptr[-1] == 4984016
+    A = sa.HipCsr.new((n, n), indptr, indices, data)
+    exact = rhs.copy()
+    i, j = np.meshgrid(np.arange(R), np.arange(R), indexing="ij")
+    exact = (i + j).ravel().astype(float)
+    # A * (i+j) == rhs exactly: a linear function is discretely harmonic, integers are exact
+    y = np.empty(n); A.mul_vec(exact, y)
+    assert np.array_equal(y, rhs)
+    # linearity with exactly representable scalars
+    u = rand_vec(n, np.float64, 1); v = rand_vec(n, np.float64, 2)
+    yu = np.empty(n); yv = np.empty(n); yuv = np.empty(n)
+    A.mul_vec(u, yu); A.mul_vec(v, yv); A.mul_vec(2.0 * u, yuv)
+    assert np.array_equal(yuv, 2.0 * yu)
+    # Jacobi-preconditioned BiCGStab reaches the known solution
+    diag = np.where(np.diff(indptr) == 1, 1.0, -4.0)
+    P = sa.DiagPrecond.new(diag)
+    s = sa.BiCGStab.new(A, n)
+    x = np.zeros(n)
+    its, res = s.precond_solve(P, rhs, x, 20000, 1e-9)
+    r = np.empty(n); A.mul_vec(x, r)
+    assert np.linalg.norm(r - rhs) / np.linalg.norm(rhs) < 1e-8
+    assert np.max(np.abs(x - exact)) < 1e-3 * np.max(exact)
+
+
+def test_cfg3_banded_minres_1m(sa):
+    from sprsolve_amd import gen
+    n = 1_000_000
+    indptr, indices, data, rhs = gen.symmetric_banded(n)
+    assert indptr[-1] == 8999980
+    A = sa.HipCsr.new((n, n), indptr, indices, data)
+    s = sa.MinRes.new(A, n)
+    x = np.zeros(n)
+    its, res = s.solve(rhs, x, 500, 1e-10)
+    r = np.empty(n); A.mul_vec(x, r)
+    assert np.linalg.norm(r - rhs) / np.linalg.norm(rhs) < 1e-9
+
+
+def test_cfg4_complex_symmetric_500k(sa):
+    from sprsolve_amd import gen
+    rows, cols = 500, 1000
+    indptr, indices, data, rhs, diag = gen.complex_symmetric_grid(rows, cols)
+    n = rows * cols
+    assert indptr[-1] == 2497000
+    A = sa.HipCsr.new((n, n), indptr, indices, data)
+    s = sa.CSMinRes.new(A, n)
+    x = np.zeros(n, np.complex128)
+    its, res = s.solve(rhs, x, 5000, 1e-10)
+    assert np.max(np.abs(x - gen.grid_exact_solution(rows, cols))) < 1e-5 * max(rows, cols)
+    # the reference's own pairing for this matrix: BiCGStab + complex Jacobi (test_complex_solve2.rs)
+    P = sa.DiagPrecond.new(diag)
+    b = sa.BiCGStab.new(A, n)
+    x[:] = 0
+    its, res = b.precond_solve(P, rhs, x, 5000, 1e-10)
+    assert np.max(np.abs(x - gen.grid_exact_solution(rows, cols))) < 1e-5 * max(rows, cols)
