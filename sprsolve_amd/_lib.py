@@ -112,6 +112,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libsprsolve_hip.so is missing at %s — run `python -c 'import __graft_entry__ as g; "
                                "g.build()'` (or make -C sprsolve_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64.so (soname libamdhip64.so.7) and its libraries ask
+        # for it by the unversioned name: if this library pulled in /opt/rocm's copy first, a later
+        # `import torch` would start a SECOND HIP runtime in the process.  Loading torch first makes
+        # both share one runtime (same soname), so torch tensors and our kernels see the same device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, args in PROTOTYPES.items():
             f = getattr(L, name)
