@@ -63,6 +63,8 @@ int sprs_ctx_create(int device, void *stream, sprs_ctx **out) {
     // number of reduction partials (== grid) stays small enough for the fused prologues
     c->grid = ((c->num_cu * 4 + 7) / 8) * 8;
     if (c->grid > MAX_GRID) c->grid = MAX_GRID;
+    c->spmv_grid = ((c->num_cu * 8 + 7) / 8) * 8;
+    if (c->spmv_grid > MAX_GRID) c->spmv_grid = MAX_GRID;
     if (hipMalloc((void **)&c->d_part, sizeof(double) * 2 * MAX_GRID) != hipSuccess) return fail(SPRS_ERR_HIP);
     if (hipMalloc((void **)&c->d_scal, 256) != hipSuccess) return fail(SPRS_ERR_HIP);
     if (hipHostMalloc((void **)&c->h_scal, 256, hipHostMallocDefault) != hipSuccess) return fail(SPRS_ERR_HIP);
@@ -95,7 +97,9 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return SPRS_INVALID_ARGUMENT;
     std::string k(key);
     if (k == "grid") { if (value < 8 || value > MAX_GRID) return SPRS_INVALID_ARGUMENT; c->grid = (int)(value & ~7); }
-    else if (k == "xcd_chunk") c->xcd_chunk = value ? 1 : 0;
+    else if (k == "spmv_grid") { if (value < 8 || value > MAX_GRID) return SPRS_INVALID_ARGUMENT; c->spmv_grid = (int)(value & ~7); }
+    else if (k == "xcd_chunk") c->xcd_chunk = value < 0 ? -1 : (value ? 1 : 0);
+    else if (k == "spmv_nt") c->spmv_nt = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "poll") { if (value < 1) return SPRS_INVALID_ARGUMENT; c->poll = (int)value; }
     else return SPRS_INVALID_ARGUMENT;
     return SPRS_OK;
@@ -105,6 +109,8 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     std::string k(key);
     if (k == "grid") return c->grid;
     if (k == "xcd_chunk") return c->xcd_chunk;
+    if (k == "spmv_grid") return c->spmv_grid;
+    if (k == "spmv_nt") return c->spmv_nt;
     if (k == "poll") return c->poll;
     if (k == "num_cu") return c->num_cu;
     if (k == "device") return c->device;

@@ -25,7 +25,13 @@ struct sprs_ctx {
     bool own_stream = false;
     int num_cu = 256;
     int grid = 1024;     // blocks launched by streaming / reduction kernels (multiple of 8)
-    int xcd_chunk = 1;   // SpMV: give each XCD a contiguous chunk of row blocks
+    int spmv_grid = 2048;  // workgroups of the persistent SpMV grid (8 per CU: full occupancy hides the gather latency)
+    // SpMV placement knobs; -1 = auto (measured on MI355X, profiles/r01_tuning.md): matrices whose stream
+    // fits the 256 MiB Infinity Cache run best with one contiguous chunk of row blocks per XCD and
+    // non-temporal (col_idx, val) loads (x stays in that XCD's L2); HBM-bound ones run best round-robin
+    // with plain loads (all XCDs sweep the same region, x re-reads are served by the Infinity Cache).
+    int xcd_chunk = -1;
+    int spmv_nt = -1;
     int poll = 16;       // iterations between host polls of the device status word
     double *d_part = nullptr;  // reduction partials for the stand-alone vecalg entry points
     double *d_scal = nullptr;  // small device result buffer

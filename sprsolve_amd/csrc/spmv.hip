@@ -63,7 +63,20 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
     return SPRS_OK;
 }
 
-template <class T, int DOT, bool CONJX>
+// streaming (read-once) loads: keep the matrix stream from evicting the gathered x lines
+template <bool NT, class U>
+__device__ __forceinline__ U ld_stream(const U *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+__device__ __forceinline__ cplx ld_stream_c(const cplx *p, bool nt) {
+    if (nt) return cplx{__builtin_nontemporal_load(&p->re), __builtin_nontemporal_load(&p->im)};
+    return *p;
+}
+template <bool NT> __device__ __forceinline__ double ld_val(const double *p) { return ld_stream<NT>(p); }
+template <bool NT> __device__ __forceinline__ cplx ld_val(const cplx *p) { return ld_stream_c(p, NT); }
+
+template <class T, int DOT, bool CONJX, bool NT>
 __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk, const int32_t *__restrict__ rowblk,
                                                      const int32_t *__restrict__ row_ptr,
                                                      const int32_t *__restrict__ col_idx, const T *__restrict__ val,
@@ -106,7 +119,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 const int k = tid + i * BLOCK;
-                if (k < nn) { cidx[i] = col_idx[pa + k]; vv[i] = val[pa + k]; }
+                if (k < nn) { cidx[i] = ld_stream<NT>(col_idx + pa + k); vv[i] = ld_val<NT>(val + pa + k); }
             }
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
             if (r < rb) {
                 const int s = row_ptr[r], e = row_ptr[r + 1];
                 T acc = szero<T>();
-                for (int k = s + lane; k < e; k += WAVE) acc = sadd(acc, smul(CONJX ? sconj(x[col_idx[k]]) : x[col_idx[k]], val[k]));
+                for (int k = s + lane; k < e; k += WAVE) { const int cj = ld_stream<NT>(col_idx + k); const T vj = ld_val<NT>(val + k); acc = sadd(acc, smul(CONJX ? sconj(x[cj]) : x[cj], vj)); }
                 acc = wave_sum(acc);
                 if (lane == 0) {
                     y[r] = acc;
@@ -153,7 +166,10 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
 
 // number of workgroups launch_spmv uses == number of partials it writes
 static inline int spmv_grid(const sprs_csr *A) {
-    int g = grid_for(A->ctx);
+    int g = A->ctx->spmv_grid;
+    if (g < 8) g = 8;
+    if (g > MAX_GRID) g = MAX_GRID;
+    g &= ~7;
     // at least one row block per workgroup, keep it a multiple of 8 (one slice per XCD)
     int need = ((A->n_rowblk + 7) / 8) * 8;
     if (need < 8) need = 8;
@@ -166,9 +182,13 @@ int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T
     sprs_ctx *c = A->ctx;
     const int g = spmv_grid(A);
     const T *v = reinterpret_cast<const T *>(A->val);
-#define SPRS_SPMV(D, CJ)                                                                                              \
-    hipLaunchKernelGGL((spmv_kernel<T, D, CJ>), dim3(g), dim3(BLOCK), 0, c->stream, (int)A->n_rowblk, c->xcd_chunk,   \
-                       A->rowblk, A->row_ptr, A->col_idx, v, x, y, u, part0, part1, status)
+    const bool cache_resident = (double)A->nnz * (sizeof(T) + 4) + 3.0 * A->nrows * sizeof(T) < 192.0 * 1024 * 1024;
+    const int xcd_chunk = c->xcd_chunk < 0 ? (cache_resident ? 1 : 0) : c->xcd_chunk;
+    const bool nt = c->spmv_nt < 0 ? cache_resident : (c->spmv_nt != 0);
+#define SPRS_SPMV2(D, CJ, NTF)                                                                                        \
+    hipLaunchKernelGGL((spmv_kernel<T, D, CJ, NTF>), dim3(g), dim3(BLOCK), 0, c->stream, (int)A->n_rowblk,            \
+                       xcd_chunk, A->rowblk, A->row_ptr, A->col_idx, v, x, y, u, part0, part1, status)
+#define SPRS_SPMV(D, CJ) do { if (nt) SPRS_SPMV2(D, CJ, true); else SPRS_SPMV2(D, CJ, false); } while (0)
     if (conj_x && is_complex<T>::value) {  // only CSMINRES on complex data needs the conjugated gather
         if (dot_mode == 0) SPRS_SPMV(0, true);
         else if (dot_mode == 1) SPRS_SPMV(1, true);
@@ -178,6 +198,7 @@ int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T
         else if (dot_mode == 1) SPRS_SPMV(1, false);
         else SPRS_SPMV(2, false);
     }
+#undef SPRS_SPMV2
 #undef SPRS_SPMV
     SPRS_HIP_TRY(c, hipGetLastError());
     return SPRS_OK;

@@ -131,10 +131,10 @@ def test_spmv_device_vectors_and_grid_options(sa, oracle):
     ref = oracle.spmv(indptr, indices, data, x)
     A = sa.HipCsr.new((n, n), indptr, indices, data)
     ctx = sa.default_ctx()
-    g0, c0 = ctx.get("grid"), ctx.get("xcd_chunk")
+    g0, c0, s0 = ctx.get("grid"), ctx.get("xcd_chunk"), ctx.get("spmv_grid")
     try:
-        for grid, chunk in ((g0, 1), (g0, 0), (8, 1), (64, 0), (4096, 1)):
-            ctx.set("grid", grid); ctx.set("xcd_chunk", chunk)
+        for grid, chunk in ((g0, 1), (g0, 0), (8, 1), (64, 0), (4096, 1), (2048, -1)):
+            ctx.set("spmv_grid", grid); ctx.set("grid", min(grid, 2048)); ctx.set("xcd_chunk", chunk); ctx.set("spmv_nt", chunk)
             dx = sa.DevVec.from_numpy(x); dy = sa.DevVec(n, np.float64); dy.upload(np.full(n, np.nan))
             A.mul_vec_unchecked(dx, dy)
             assert np.array_equal(bits(dy.to_numpy()), bits(ref)), (grid, chunk)
@@ -142,7 +142,7 @@ def test_spmv_device_vectors_and_grid_options(sa, oracle):
             e = oracle.conj_dot(x, ref)
             assert abs(d - e) <= RED_RTOL * np.sum(np.abs(x * ref))
     finally:
-        ctx.set("grid", g0); ctx.set("xcd_chunk", c0)
+        ctx.set("grid", g0); ctx.set("xcd_chunk", c0); ctx.set("spmv_grid", s0); ctx.set("spmv_nt", -1)
 
 
 # ------------------------------------------------------------------ vecalg
