@@ -215,10 +215,18 @@ def main():
             res_ = sdist.bench_poisson3d(torch, dist, ctx, rank, world, nx, ny, nz, args.steps, args.warmup, time_solve)
             dt, prof, t_spmv, bs, check, n_glob, nnz_glob = res_
         it_bytes = 2 * spmv_bytes(n_glob, nnz_glob, 8) + 26 * n_glob * 8
+        traffic, traffic_note = None, "no PMC summary found"
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if world == 1 and (nx, ny, nz) == (500, 500, 200) and os.path.exists(pmc_path):
+            # HBM-side bytes per launch from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes of this same
+            # command, gfx950 x2 FETCH correction calibrated in this kernel's access pattern) — profiles/
+            with open(pmc_path) as f:
+                pm = json.load(f)["spmv_cfg5"]
+            traffic, traffic_note = pm["traffic_bytes"], "2*FETCH_SIZE + WRITE_SIZE per launch (profiles/r01_pmc_summary.json); " + pm["note"]
         roof = dict(bound="hbm", kernel="spmv_kernel<double> (CSR SpMV, LDS stream path, fused dot epilogue)",
                     achieved=bs / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=bs / t_spmv / 1e9 / HBM_PEAK_GBS,
-                    traffic=None, algorithmic_bytes_per_launch=bs, avg_launch_us=t_spmv * 1e6,
-                    launches=prof["spmv_launches"],
+                    traffic=traffic, traffic_note=traffic_note, algorithmic_bytes_per_launch=bs,
+                    avg_launch_us=t_spmv * 1e6, launches=prof["spmv_launches"],
                     note="per rank; algorithmic bytes = nnz*12 + (n+1)*4 + 2*n*8 (SURVEY §8d), x counted once")
         out = dict(metric="BiCGStab iterations/s (f64, 50M-row 7-point 3-D Poisson) + CSR SpMV GB/s vs HBM roofline",
                    value=args.steps / dt, unit="iterations/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
