@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the distributed (RCCL) code path even with one rank — rehearsal of the N>1 leg on a 1-GPU box")
     return ap.parse_args()
 
 
@@ -154,6 +156,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif args.force_dist:
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
+                                device_id=torch.device("cuda", local_rank))
 
     import numpy as np
 
@@ -194,7 +199,7 @@ def main():
 
     if args.workload == "poisson3d":
         nx, ny, nz = (int(v) for v in args.grid.lower().split("x"))
-        if world == 1:
+        if world == 1 and not args.force_dist:
             ip, ix, dv, rhs = gen_torch.poisson3d(nx, ny, nz, device=dev)
             n = nx * ny * nz
             nnz = int(ip[-1].item())
@@ -238,7 +243,7 @@ def main():
                                bytes_per_iteration_reference_oplist=it_bytes),
                    effective_GBs_reference_oplist=it_bytes * args.steps / dt / 1e9,
                    roofline=roof, converge_check=check)
-        if world == 1 and not args.no_also:
+        if world == 1 and not args.no_also and not args.force_dist:
             r2, _, _ = bench_poisson2d(500, 50)
             also["cfg2_poisson2d_1M_bicgstab_jacobi"] = r2
         if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -293,7 +298,7 @@ def main():
         out["also"] = also
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

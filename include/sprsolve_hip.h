@@ -196,6 +196,35 @@ int sprs_csminres_solve_dev_z(sprs_csminres *S, const sprs_c64 *rhs_dev, size_t 
 int sprs_csminres_solve_dev_d(sprs_csminres *S, const double *rhs_dev, size_t rhs_len, double *x_dev, size_t x_len,
                               size_t max_iter, double tol, size_t *its_out, double *res_out);
 
+/* ---------------------------------------------------------------- multi-GPU (one process per GPU)
+ * No reference analogue: the reference is single-process (rayon).  The matrix is row-partitioned;
+ * rank r owns rows [r0, r1) and the matching slices of every vector.  A distributed operator is the
+ * local row block with column indices renumbered into the rank's EXTENDED x vector
+ * [ owned entries (n_local) | entries received from peer 0 | peer 1 | ... ]  (n_ext elements).
+ * Every solver above accepts such an operator (create it with size = n_local): SpMV is preceded by
+ * the halo exchange (RCCL send/recv with the owning peers over xGMI), every dot product / norm is
+ * followed by an RCCL all-reduce, and rhs / x are the rank's slices.  sprsolve_amd/partition.py
+ * derives the exchange plan from global column indices. */
+typedef struct sprs_comm sprs_comm;
+int sprs_comm_unique_id(void *id128_out);  /* rank 0: 128-byte RCCL id to broadcast to the other ranks */
+int sprs_comm_create(sprs_ctx *ctx, int world, int rank, const void *id128, sprs_comm **out); /* collective */
+int sprs_comm_destroy(sprs_comm *comm);
+int sprs_comm_allreduce_sum_f64(sprs_comm *comm, double *dev, size_t count); /* in place; blocking */
+/* peer_rank[n_peers]; send_off/recv_off[n_peers+1] are element offsets; send_idx_dev[send_off[n_peers]]
+ * (device, i32) lists the local entries to pack for each peer; entries from peer p land at
+ * x_ext[n_local + recv_off[p] ...].  recv_off[n_peers] == n_ext - n_local. */
+int sprs_dist_csr_create_dev_d(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz,
+                               const int32_t *dev_row_ptr, const int32_t *dev_col_idx_ext, const double *dev_val, int adopt,
+                               int n_peers, const int32_t *peer_rank, const int64_t *send_off,
+                               const int32_t *send_idx_dev, const int64_t *recv_off, sprs_csr **out);
+int sprs_dist_csr_create_dev_z(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz,
+                               const int32_t *dev_row_ptr, const int32_t *dev_col_idx_ext, const sprs_c64 *dev_val, int adopt,
+                               int n_peers, const int32_t *peer_rank, const int64_t *send_off,
+                               const int32_t *send_idx_dev, const int64_t *recv_off, sprs_csr **out);
+/* y_local = A_local * x after exchanging the halo tail of x_ext (n_ext elements, owned slice first) */
+int sprs_dist_mul_vec_dev_d(const sprs_csr *A, double *x_ext_dev, double *y_local_dev);
+int sprs_dist_mul_vec_dev_z(const sprs_csr *A, sprs_c64 *x_ext_dev, sprs_c64 *y_local_dev);
+
 /* ---------------------------------------------------------------- solver options / instrumentation
  * `solver` is any of the three solver handle types. */
 enum { SPRS_SOLVER_BICGSTAB = 1, SPRS_SOLVER_MINRES = 2, SPRS_SOLVER_CSMINRES = 3 };

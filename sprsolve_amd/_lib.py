@@ -91,6 +91,13 @@ def _protos():
     for s in ("d", "zd", "z"):
         P["sprs_diag_precond_create_" + s] = [_vp, _sz, _vp, _pp]
     P["sprs_diag_precond_destroy"] = [_vp]
+    P["sprs_comm_unique_id"] = [_vp]
+    P["sprs_comm_create"] = [_vp, _int, _int, _vp, _pp]
+    P["sprs_comm_destroy"] = [_vp]
+    P["sprs_comm_allreduce_sum_f64"] = [_vp, _vp, _sz]
+    for s in ("d", "z"):
+        P["sprs_dist_csr_create_dev_" + s] = [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _pp]
+        P["sprs_dist_mul_vec_dev_" + s] = [_vp, _vp, _vp]
     P["sprs_solver_set_mode"] = [_vp, _int, _int]
     P["sprs_solver_set_trace"] = [_vp, _int, _vp, _sz]
     P["sprs_solver_trace_rows"] = [_vp, _int, _psz]

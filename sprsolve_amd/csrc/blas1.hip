@@ -174,10 +174,11 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const T *__restrict__ p
 }
 
 template <class T>
-int reduce_partials_host(sprs_ctx *c, const T *part, int P, T *out) {
+int reduce_partials_host(sprs_ctx *c, const T *part, int P, T *out, sprs_comm *comm) {
     T *d_out = reinterpret_cast<T *>(c->d_scal);
     hipLaunchKernelGGL((finalize_kernel<T>), dim3(1), dim3(BLOCK), 0, c->stream, part, P, d_out);
     SPRS_HIP_TRY(c, hipGetLastError());
+    if (comm) SPRS_TRY(allreduce_sum(comm, reinterpret_cast<double *>(d_out), sizeof(T) / sizeof(double)));
     SPRS_HIP_TRY(c, hipMemcpyAsync(c->h_scal, d_out, sizeof(T), hipMemcpyDeviceToHost, c->stream));
     SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     memcpy(out, c->h_scal, sizeof(T));
@@ -192,7 +193,7 @@ static int red_grid(sprs_ctx *c, size_t n, int pk) {
 }
 
 template <class T>
-int dot_host(sprs_ctx *c, size_t n, const T *x, const T *y, bool conj, T *out) {
+int dot_host(sprs_ctx *c, size_t n, const T *x, const T *y, bool conj, T *out, sprs_comm *comm) {
     constexpr int PKW = pack_width<T>::value;
     const bool al = aligned16(x) && aligned16(y);
     const int pk = (al && PKW > 1) ? PKW : 1;
@@ -204,11 +205,11 @@ int dot_host(sprs_ctx *c, size_t n, const T *x, const T *y, bool conj, T *out) {
     else         { if (conj) SPRS_LAUNCH_DOT(true, PKW); else SPRS_LAUNCH_DOT(false, PKW); }
 #undef SPRS_LAUNCH_DOT
     SPRS_HIP_TRY(c, hipGetLastError());
-    return reduce_partials_host<T>(c, part, g, out);
+    return reduce_partials_host<T>(c, part, g, out, comm);
 }
 
 template <class T>
-int norm2_host(sprs_ctx *c, size_t n, const T *x, double *out) {
+int norm2_host(sprs_ctx *c, size_t n, const T *x, double *out, sprs_comm *comm) {
     constexpr int PKW = pack_width<T>::value;
     const int pk = (aligned16(x) && PKW > 1) ? PKW : 1;
     const int g = red_grid(c, n, pk);
@@ -217,7 +218,7 @@ int norm2_host(sprs_ctx *c, size_t n, const T *x, double *out) {
     else hipLaunchKernelGGL((nrm2sq_kernel<T, PKW>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, x, part);
     SPRS_HIP_TRY(c, hipGetLastError());
     double s = 0.0;
-    SPRS_TRY(reduce_partials_host<double>(c, part, g, &s));
+    SPRS_TRY(reduce_partials_host<double>(c, part, g, &s, comm));
     *out = sqrt(s);  // vecalg.rs:604
     return SPRS_OK;
 }
@@ -239,11 +240,11 @@ template int launch_diag_apply<cplx, double>(sprs_ctx *, size_t, const double *,
 template int launch_diag_apply<cplx, cplx>(sprs_ctx *, size_t, const cplx *, const cplx *, cplx *);
 template int launch_diag_inv<double>(sprs_ctx *, size_t, const double *, double *);
 template int launch_diag_inv<cplx>(sprs_ctx *, size_t, const cplx *, cplx *);
-template int dot_host<double>(sprs_ctx *, size_t, const double *, const double *, bool, double *);
-template int dot_host<cplx>(sprs_ctx *, size_t, const cplx *, const cplx *, bool, cplx *);
-template int norm2_host<double>(sprs_ctx *, size_t, const double *, double *);
-template int norm2_host<cplx>(sprs_ctx *, size_t, const cplx *, double *);
-template int reduce_partials_host<double>(sprs_ctx *, const double *, int, double *);
-template int reduce_partials_host<cplx>(sprs_ctx *, const cplx *, int, cplx *);
+template int dot_host<double>(sprs_ctx *, size_t, const double *, const double *, bool, double *, sprs_comm *);
+template int dot_host<cplx>(sprs_ctx *, size_t, const cplx *, const cplx *, bool, cplx *, sprs_comm *);
+template int norm2_host<double>(sprs_ctx *, size_t, const double *, double *, sprs_comm *);
+template int norm2_host<cplx>(sprs_ctx *, size_t, const cplx *, double *, sprs_comm *);
+template int reduce_partials_host<double>(sprs_ctx *, const double *, int, double *, sprs_comm *);
+template int reduce_partials_host<cplx>(sprs_ctx *, const cplx *, int, cplx *, sprs_comm *);
 
 }  // namespace sprs

@@ -361,6 +361,11 @@ int sprs_csr_destroy(sprs_csr *A) {
     if (A->x_tmp) (void)hipFree(A->x_tmp);
     if (A->y_tmp) (void)hipFree(A->y_tmp);
     if (A->part) (void)hipFree(A->part);
+    if (A->dist) {
+        if (A->dist->send_idx) (void)hipFree(A->dist->send_idx);
+        if (A->dist->send_buf) (void)hipFree(A->dist->send_buf);
+        delete A->dist;
+    }
     delete A;
     return SPRS_OK;
 }
@@ -502,7 +507,7 @@ int solver_create(const sprs_csr *A, size_t size, int want_complex, H **out, Mk 
     if (A->is_complex != want_complex) return SPRS_INVALID_ARGUMENT;
     // the solvers multiply size-vectors by A in place: the reference leaves a mismatch to UB
     // (mul_vec_unchecked); we refuse it here rather than index out of bounds on the GPU
-    if ((int64_t)size != A->nrows || (int64_t)size != A->ncols) return SPRS_DIM_MISMATCH;
+    if ((int64_t)size != A->nrows || (A->dist ? A->ncols < A->nrows : (int64_t)size != A->ncols)) return SPRS_DIM_MISMATCH;
     H *h = new H();
     h->is_complex = want_complex;
     int st;

@@ -55,6 +55,26 @@ struct sprs_ctx {
         if (s__ != SPRS_OK) return s__;      \
     } while (0)
 
+// RCCL communicator of one rank (dist.hip).  RCCL is resolved with dlopen at first use, so the
+// single-GPU library has no link-time dependency on it.
+struct sprs_comm {
+    sprs_ctx *ctx = nullptr;
+    void *nccl = nullptr;   // ncclComm_t
+    int world = 1, rank = 0;
+};
+
+// Row-partition metadata of a distributed CSR operator: which local x entries each peer needs
+// (packed and sent before every SpMV) and where the entries received from each peer land in
+// the halo tail [n_local, n_ext) of the extended x vector.
+struct sprs_dist_info {
+    sprs_comm *comm = nullptr;
+    int64_t n_local = 0, n_ext = 0;
+    std::vector<int> peer;
+    std::vector<int64_t> send_off, recv_off;   // n_peers + 1 each (elements)
+    int32_t *send_idx = nullptr;               // device: local indices to pack, grouped by peer
+    void *send_buf = nullptr;                  // device: packed values
+};
+
 struct sprs_csr {
     sprs_ctx *ctx = nullptr;
     int is_complex = 0;
@@ -68,6 +88,7 @@ struct sprs_csr {
     // scratch for the host-slice trait entry points (lazily allocated)
     void *x_tmp = nullptr, *y_tmp = nullptr;
     double *part = nullptr;      // partials for mul_vec_dot
+    sprs_dist_info *dist = nullptr;   // non-null: row block of a matrix partitioned over ranks
 };
 
 struct sprs_diag {
@@ -100,10 +121,16 @@ template <class T> int launch_conj(sprs_ctx *c, size_t n, const T *in, T *out);
 template <class T, class V> int launch_diag_apply(sprs_ctx *c, size_t n, const V *dinv, const T *in, T *out);
 template <class V> int launch_diag_inv(sprs_ctx *c, size_t n, const V *diag, V *dinv);
 // reductions: blocking, result returned to the host
-template <class T> int dot_host(sprs_ctx *c, size_t n, const T *x, const T *y, bool conj, T *out);
-template <class T> int norm2_host(sprs_ctx *c, size_t n, const T *x, double *out);
+// comm != null: the locally reduced value is all-reduced over the ranks before it is returned
+template <class T> int dot_host(sprs_ctx *c, size_t n, const T *x, const T *y, bool conj, T *out, sprs_comm *comm = nullptr);
+template <class T> int norm2_host(sprs_ctx *c, size_t n, const T *x, double *out, sprs_comm *comm = nullptr);
 // reduce `P` partials of T (or of double when T_is_real_partials) with the library's fixed order; blocking
-template <class T> int reduce_partials_host(sprs_ctx *c, const T *part, int P, T *out);
+template <class T> int reduce_partials_host(sprs_ctx *c, const T *part, int P, T *out, sprs_comm *comm = nullptr);
+
+// ---- dist.hip
+// exchange the halo entries of the extended vector x (local part [0,n_local) already in place)
+template <class T> int halo_exchange(const sprs_csr *A, T *x_ext);
+int allreduce_sum(sprs_comm *comm, double *dev, size_t count);   // in place, on the ctx stream
 
 inline int grid_for(const sprs_ctx *c) {
     int g = c->grid;

@@ -315,7 +315,8 @@ struct MinresM3 {
 template <class T>
 int KrylovBase<T>::init(const sprs_csr *A_, size_t size, int nvec_) {
     A = A_; ctx = A_->ctx; n = size; nvec = nvec_;
-    stride = (n + 31) & ~(size_t)31;
+    const size_t nx = A->dist ? (size_t)A->ncols : n;   // distributed: every work vector carries the halo tail
+    stride = (nx + 31) & ~(size_t)31;
     if (stride == 0) stride = 32;
     SPRS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     SPRS_HIP_TRY(ctx, hipMalloc((void **)&work, sizeof(T) * stride * (size_t)nvec));
@@ -324,6 +325,11 @@ int KrylovBase<T>::init(const sprs_csr *A_, size_t size, int nvec_) {
     SPRS_HIP_TRY(ctx, hipMalloc((void **)&partD, sizeof(double) * MAX_GRID * 4));
     SPRS_HIP_TRY(ctx, hipMemsetAsync(part, 0, sizeof(T) * MAX_GRID * 8, ctx->stream));
     SPRS_HIP_TRY(ctx, hipMemsetAsync(partD, 0, sizeof(double) * MAX_GRID * 4, ctx->stream));
+    if (A->dist) {
+        SPRS_HIP_TRY(ctx, hipMalloc((void **)&red, sizeof(double) * 32));
+        SPRS_HIP_TRY(ctx, hipMemsetAsync(red, 0, sizeof(double) * 32, ctx->stream));
+        SPRS_HIP_TRY(ctx, hipMalloc((void **)&xext, sizeof(T) * stride));
+    }
     SPRS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SPRS_OK;
 }
@@ -335,6 +341,9 @@ void KrylovBase<T>::destroy() {
     if (x_buf) (void)hipFree(x_buf);
     if (part) (void)hipFree(part);
     if (partD) (void)hipFree(partD);
+    if (red) (void)hipFree(red);
+    if (xext) (void)hipFree(xext);
+    red = nullptr; xext = nullptr;
     for (auto e : ev) (void)hipEventDestroy(e);
     ev.clear();
     work = rhs_buf = x_buf = part = nullptr; partD = nullptr;
@@ -349,8 +358,77 @@ int KrylovBase<T>::ew_grid() const {
     return g;
 }
 
+// partial hand-off kernels for the distributed case: reduce up to two partial arrays into `red`
+template <class TA, class TB>
+__global__ __launch_bounds__(BLOCK) void finalize2_kernel(const TA *__restrict__ a, const TB *__restrict__ b, int P,
+                                                          double *__restrict__ ra, double *__restrict__ rb) {
+    __shared__ TA smA[NWAVE];
+    __shared__ TB smB[NWAVE];
+    const TA va = reduce_partials(a, P, smA);
+    if (threadIdx.x == 0) *reinterpret_cast<TA *>(ra) = va;
+    if (b != nullptr) {
+        const TB vb = reduce_partials(b, P, smB);
+        if (threadIdx.x == 0) *reinterpret_cast<TB *>(rb) = vb;
+    }
+}
+
+template <class T>
+int KrylovBase<T>::red1(const T *a, int P, int slot, PartT *oa) {
+    if (!A->dist) { *oa = PartT{a, P}; return SPRS_OK; }
+    double *ra = red + 2 * slot;
+    hipLaunchKernelGGL((finalize2_kernel<T, T>), dim3(1), dim3(BLOCK), 0, ctx->stream, a, (const T *)nullptr, P, ra, ra);
+    SPRS_HIP_TRY(ctx, hipGetLastError());
+    SPRS_TRY(allreduce_sum(comm(), ra, 2));
+    *oa = PartT{reinterpret_cast<const T *>(ra), 1};
+    return SPRS_OK;
+}
+template <class T>
+int KrylovBase<T>::red2(const T *a, const T *b, int P, int slot, PartT *oa, PartT *ob) {
+    if (!A->dist) { *oa = PartT{a, P}; *ob = PartT{b, P}; return SPRS_OK; }
+    double *ra = red + 2 * slot, *rb = red + 2 * slot + 2;
+    hipLaunchKernelGGL((finalize2_kernel<T, T>), dim3(1), dim3(BLOCK), 0, ctx->stream, a, b, P, ra, rb);
+    SPRS_HIP_TRY(ctx, hipGetLastError());
+    SPRS_TRY(allreduce_sum(comm(), ra, 4));
+    *oa = PartT{reinterpret_cast<const T *>(ra), 1};
+    *ob = PartT{reinterpret_cast<const T *>(rb), 1};
+    return SPRS_OK;
+}
+template <class T>
+int KrylovBase<T>::redD1(const double *a, int P, int slot, PartD *oa) {
+    if (!A->dist) { *oa = PartD{a, P}; return SPRS_OK; }
+    double *ra = red + 2 * slot;
+    hipLaunchKernelGGL((finalize2_kernel<double, double>), dim3(1), dim3(BLOCK), 0, ctx->stream, a, (const double *)nullptr, P, ra, ra);
+    SPRS_HIP_TRY(ctx, hipGetLastError());
+    SPRS_TRY(allreduce_sum(comm(), ra, 2));
+    *oa = PartD{ra, 1};
+    return SPRS_OK;
+}
+template <class T>
+int KrylovBase<T>::redDT(const double *a, const T *b, int P, int slot, PartD *oa, PartT *ob) {
+    if (!A->dist) { *oa = PartD{a, P}; *ob = PartT{b, P}; return SPRS_OK; }
+    double *ra = red + 2 * slot, *rb = red + 2 * slot + 2;
+    hipLaunchKernelGGL((finalize2_kernel<double, T>), dim3(1), dim3(BLOCK), 0, ctx->stream, a, b, P, ra, rb);
+    SPRS_HIP_TRY(ctx, hipGetLastError());
+    SPRS_TRY(allreduce_sum(comm(), ra, 4));
+    *oa = PartD{ra, 1};
+    *ob = PartT{reinterpret_cast<const T *>(rb), 1};
+    return SPRS_OK;
+}
+
 template <class T>
 int KrylovBase<T>::spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, const int *status, bool conj_x) {
+    if (A->dist) {
+        // the SpMV input needs its halo tail filled: work vectors have room for it, a caller's
+        // vector (initial residual, restart) is staged through `xext`
+        T *xe = const_cast<T *>(x);
+        const bool is_work = x >= work && x < work + stride * (size_t)nvec;
+        if (!is_work) {
+            SPRS_HIP_TRY(ctx, hipMemcpyAsync(xext, x, sizeof(T) * n, hipMemcpyDeviceToDevice, ctx->stream));
+            xe = xext;
+        }
+        SPRS_TRY(halo_exchange<T>(A, xe));
+        x = xe;
+    }
     if (!profile) return launch_spmv<T>(A, x, y, dot, u, p0, p1, status, conj_x);
     if (ev_used + 2 > ev.size()) {
         for (int k = 0; k < 2; ++k) {
@@ -447,7 +525,7 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double 
     *its_out = 0; *res_out = 0.0;
 
     double rhs_norm = 0.0;
-    SPRS_TRY(norm2_host<T>(c, n, rhs, &rhs_norm));                  // :55
+    SPRS_TRY(this->norm2(rhs, &rhs_norm));                          // :55
     if (rhs_norm <= EPS) {                                          // :56-60
         SPRS_TRY(dzero(c, x, n));
         *its_out = 0; *res_out = rhs_norm;
@@ -467,7 +545,7 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double 
     SPRS_TRY((launch_axpy<T, T>(c, n, sneg(sone<T>()), rhs, r)));           // :75
     SPRS_TRY(dcopy(c, r0, r, n));                                           // :78
     double r0_norm = 0.0;
-    SPRS_TRY(norm2_host<T>(c, n, r0, &r0_norm));                            // :80
+    SPRS_TRY(this->norm2(r0, &r0_norm));                                    // :80
     if (r0_norm <= tol2) {                                                  // :81-83
         *its_out = 0; *res_out = r0_norm / rhs_norm;
         return SPRS_OK;
@@ -489,19 +567,28 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double 
     double *partN = this->dslot(0);
     T *partRho = this->pslot(0), *partB = this->pslot(1), *partTT = this->pslot(2), *partTR = this->pslot(3);
 
-    auto K2 = [&]() { return this->spmv(y, v, 1, r0, partB, nullptr, d_status); };          // :93/:160  v = A y ; r0.v
-    auto K3 = [&](int check) {
-        if (pc) return launch_fused<T>(c, n, G, BicgK3<T, V, true>{d_state, partB, GS, check, v, r, dinv, z, T()});
-        return launch_fused<T>(c, n, G, BicgK3<T, V, false>{d_state, partB, GS, check, v, r, dinv, z, T()});
+    typename KrylovBase<T>::PartT qB{partB, GS}, qTT{partTT, GS}, qTR{partTR, GS}, qRho{partRho, G};
+    typename KrylovBase<T>::PartD qN{partN, G};
+    auto K2 = [&]() -> int {                                                                 // :93/:160  v = A y ; r0.v
+        SPRS_TRY(this->spmv(y, v, 1, r0, partB, nullptr, d_status));
+        return this->red1(partB, GS, 0, &qB);
     };
-    auto K4 = [&]() { return this->spmv(sz, t, 2, r, partTT, partTR, d_status); };          // :104/:175 t = A s ; t.t, t.r
-    auto K5 = [&]() {
-        if (pc) return launch_fused<T>(c, n, G, BicgK5<T, true>{d_state, partTT, partTR, GS, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()});
-        return launch_fused<T>(c, n, G, BicgK5<T, false>{d_state, partTT, partTR, GS, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()});
+    auto K3 = [&](int check) -> int {
+        if (pc) return launch_fused<T>(c, n, G, BicgK3<T, V, true>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()});
+        return launch_fused<T>(c, n, G, BicgK3<T, V, false>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()});
     };
-    auto K1 = [&](int mode) {
-        if (pc) return launch_fused<T>(c, n, G, BicgK1<T, V, true>{d_state, partN, partRho, G, mode, v, r, p, dinv, y, T(), T()});
-        return launch_fused<T>(c, n, G, BicgK1<T, V, false>{d_state, partN, partRho, G, mode, v, r, p, dinv, y, T(), T()});
+    auto K4 = [&]() -> int {                                                                 // :104/:175 t = A s ; t.t, t.r
+        SPRS_TRY(this->spmv(sz, t, 2, r, partTT, partTR, d_status));
+        return this->red2(partTT, partTR, GS, 1, &qTT, &qTR);
+    };
+    auto K5 = [&]() -> int {
+        if (pc) SPRS_TRY(launch_fused<T>(c, n, G, BicgK5<T, true>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()}));
+        else SPRS_TRY(launch_fused<T>(c, n, G, BicgK5<T, false>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()}));
+        return this->redDT(partN, partRho, G, 3, &qN, &qRho);
+    };
+    auto K1 = [&](int mode) -> int {
+        if (pc) return launch_fused<T>(c, n, G, BicgK1<T, V, true>{d_state, qN.p, qRho.p, qN.P, mode, v, r, p, dinv, y, T(), T()});
+        return launch_fused<T>(c, n, G, BicgK1<T, V, false>{d_state, qN.p, qRho.p, qN.P, mode, v, r, p, dinv, y, T(), T()});
     };
     auto fetch = [&]() -> int {
         SPRS_HIP_TRY(c, hipMemcpyAsync(&H, d_state, sizeof(H), hipMemcpyDeviceToHost, c->stream));
@@ -550,7 +637,7 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double 
                 SPRS_TRY((launch_axpy<T, T>(c, n, sneg(sone<T>()), rhs, r)));       // :137
                 SPRS_TRY(dcopy(c, r0, r, n));                                       // :140
                 double rn = 0.0;
-                SPRS_TRY(norm2_host<T>(c, n, r, &rn));                              // :142
+                SPRS_TRY(this->norm2(r, &rn));                                      // :142
                 H.rho = sfromr<T>(rn * rn);                                         // :143
                 H.r0_norm_tol = sre(H.rho) * EPS * EPS;                             // :144
                 H.status = ST_RUNNING;
@@ -577,7 +664,7 @@ int BicgStab<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter,
     const bool pc = dinv != nullptr;
     *its_out = 0; *res_out = 0.0;
     double rhs_norm = 0.0;
-    SPRS_TRY(norm2_host<T>(c, n, rhs, &rhs_norm));
+    SPRS_TRY(this->norm2(rhs, &rhs_norm));
     if (rhs_norm <= EPS) { SPRS_TRY(dzero(c, x, n)); *res_out = rhs_norm; return SPRS_OK; }
     const double tol2 = tol * rhs_norm;
     T *r = this->vec(0), *r0 = this->vec(1), *y = this->vec(2);
@@ -587,14 +674,14 @@ int BicgStab<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter,
     T *z = pc ? this->vec(6) : nullptr;
     const T *sz = pc ? z : r;
     auto mv = [&](const T *in, T *out) { return this->spmv(in, out, 0, nullptr, nullptr, nullptr, nullptr); };
-    auto cdot = [&](const T *a, const T *b, T *o) { return dot_host<T>(c, n, a, b, true, o); };
+    auto cdot = [&](const T *a, const T *b, T *o) { return this->cdot(a, b, o); };
     auto axpy = [&](T a, const T *xx, T *yy) { return launch_axpy<T, T>(c, n, a, xx, yy); };
 
     SPRS_TRY(mv(x, r));
     SPRS_TRY(axpy(sneg(sone<T>()), rhs, r));
     SPRS_TRY(dcopy(c, r0, r, n));
     double r0_norm = 0.0;
-    SPRS_TRY(norm2_host<T>(c, n, r0, &r0_norm));
+    SPRS_TRY(this->norm2(r0, &r0_norm));
     if (r0_norm <= tol2) { *res_out = r0_norm / rhs_norm; return SPRS_OK; }
     double r0_norm_tol = r0_norm * EPS;
     r0_norm_tol = r0_norm_tol * r0_norm_tol;
@@ -617,7 +704,7 @@ int BicgStab<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter,
     this->trace_row(0.0, r0_norm, rho, alpha, w);
     for (size_t its = 1; its < max_iter; ++its) {
         double r_norm = 0.0;
-        SPRS_TRY(norm2_host<T>(c, n, r, &r_norm));
+        SPRS_TRY(this->norm2(r, &r_norm));
         if (r_norm <= tol2) { *its_out = its; *res_out = r_norm / rhs_norm; return SPRS_OK; }
         const T rho_old = rho;
         SPRS_TRY(cdot(r0, r, &rho));
@@ -626,7 +713,7 @@ int BicgStab<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter,
             SPRS_TRY(axpy(sneg(sone<T>()), rhs, r));
             SPRS_TRY(dcopy(c, r0, r, n));
             double rn = 0.0;
-            SPRS_TRY(norm2_host<T>(c, n, r, &rn));
+            SPRS_TRY(this->norm2(r, &rn));
             rho = sfromr<T>(rn * rn);
             r0_norm_tol = sre(rho) * EPS * EPS;
         }
@@ -718,7 +805,7 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double to
     *its_out = 0; *res_out = 0.0;
 
     double rhs_norm = 0.0;
-    SPRS_TRY(norm2_host<T>(c, n, rhs, &rhs_norm));                          // :51
+    SPRS_TRY(this->norm2(rhs, &rhs_norm));                          // :51
     if (rhs_norm <= EPS) { SPRS_TRY(dzero(c, x, n)); *res_out = rhs_norm; return SPRS_OK; }   // :52-56
     const double threshold = tol * rhs_norm;                                // :57
 
@@ -730,12 +817,12 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double to
     SPRS_TRY(this->spmv(x, v_old, 0, nullptr, nullptr, nullptr, nullptr));  // :78
     SPRS_TRY((launch_axpy<T, T>(c, n, sneg(sone<T>()), v_old, v_new)));     // :80
     double res_norm = 0.0;
-    SPRS_TRY(norm2_host<T>(c, n, v_new, &res_norm));                        // :81
+    SPRS_TRY(this->norm2(v_new, &res_norm));                        // :81
     double beta_new;
     if (pc) {
         SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, v_new, w_new)));      // :233
         T b2;
-        SPRS_TRY(dot_host<T>(c, n, v_new, w_new, true, &b2));               // :235
+        SPRS_TRY(this->cdot(v_new, w_new, &b2));               // :235
         if (sre(b2) < EPS || sim(b2) > EPS * sre(b2)) {                     // :236-244
             *its_out = 0; *res_out = sre(b2);
             return SPRS_INVALID_PRECOND;
@@ -785,11 +872,19 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double to
             const T *q = pc ? w : v;                                         // operand of A and source of p
             // M1: v_new = A q (CSMINRES: A conj(q)) ; alpha = conj(q).v_new   (:116 / :271 / cs:99-103)
             SPRS_TRY(this->spmv(q, v_new, 1, q, partAlpha, nullptr, d_status, sau));
-            if (pc) SPRS_TRY(launch_fused<T>(c, n, G, MinresM2<T, V, true>{d_state, par, partAlpha, GS, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, T(), T(), 0.0, T()}));
-            else SPRS_TRY(launch_fused<T>(c, n, G, MinresM2<T, V, false>{d_state, par, partAlpha, GS, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, T(), T(), 0.0, T()}));
+            typename KrylovBase<T>::PartT qA, qB2{partBeta2, G};
+            typename KrylovBase<T>::PartD qBt{partBeta, G};
+            SPRS_TRY(this->red1(partAlpha, GS, 0, &qA));
+            if (pc) {
+                SPRS_TRY(launch_fused<T>(c, n, G, MinresM2<T, V, true>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, T(), T(), 0.0, T()}));
+                SPRS_TRY(this->red1(partBeta2, G, 1, &qB2));
+            } else {
+                SPRS_TRY(launch_fused<T>(c, n, G, MinresM2<T, V, false>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, T(), T(), 0.0, T()}));
+                SPRS_TRY(this->redD1(partBeta, G, 1, &qBt));
+            }
             { T *tp = p_oold; p_oold = p_old; p_old = p; p = tp; }           // :151-154
 #define SPRS_M3(PCF, SAF)                                                                                        \
-    launch_fused<T>(c, n, G, MinresM3<T, PCF, SAF>{d_state, par, (long long)its, partBeta, partBeta2, G, v_new,  \
+    launch_fused<T>(c, n, G, MinresM3<T, PCF, SAF>{d_state, par, (long long)its, qBt.p, qB2.p, pc ? qB2.P : qBt.P, v_new,  \
                                                    w_new, q, p_old, p_oold, p, x, 0.0, 0.0, 0.0, 0.0, T(), T(),  \
                                                    T(), T()})
             if (pc) SPRS_TRY(SPRS_M3(true, false));
@@ -837,7 +932,7 @@ int MinRes<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, d
     const bool sau = saunders;
     *its_out = 0; *res_out = 0.0;
     double rhs_norm = 0.0;
-    SPRS_TRY(norm2_host<T>(c, n, rhs, &rhs_norm));
+    SPRS_TRY(this->norm2(rhs, &rhs_norm));
     if (rhs_norm <= EPS) { SPRS_TRY(dzero(c, x, n)); *res_out = rhs_norm; return SPRS_OK; }
     const double threshold = tol * rhs_norm;
     T cc = sone<T>(), c_old = sone<T>(), eta = sone<T>();
@@ -851,12 +946,12 @@ int MinRes<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, d
     SPRS_TRY(mv(x, v_old));
     SPRS_TRY(axpy(sneg(sone<T>()), v_old, v_new));
     double res_norm = 0.0;
-    SPRS_TRY(norm2_host<T>(c, n, v_new, &res_norm));
+    SPRS_TRY(this->norm2(v_new, &res_norm));
     double beta_new, beta_one;
     if (pc) {
         SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, v_new, w_new)));
         T b2;
-        SPRS_TRY(dot_host<T>(c, n, v_new, w_new, true, &b2));
+        SPRS_TRY(this->cdot(v_new, w_new, &b2));
         if (sre(b2) < EPS || sim(b2) > EPS * sre(b2)) { *res_out = sre(b2); return SPRS_INVALID_PRECOND; }
         beta_new = sqrt(sre(b2)); beta_one = beta_new;
         SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, v_new));
@@ -874,16 +969,16 @@ int MinRes<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, d
         if (pc) {
             { T *tp = w; w = w_new; w_new = tp; }
             SPRS_TRY(mv(w, v_new));
-            SPRS_TRY(dot_host<T>(c, n, w, v_new, true, &alpha));
+            SPRS_TRY(this->cdot(w, v_new, &alpha));
             q = w;
         } else if (sau) {
             SPRS_TRY(launch_conj<T>(c, n, v, tvec));
             SPRS_TRY(mv(tvec, v_new));
-            SPRS_TRY(dot_host<T>(c, n, v, v_new, true, &alpha));
+            SPRS_TRY(this->cdot(v, v_new, &alpha));
             q = tvec;
         } else {
             SPRS_TRY(mv(v, v_new));
-            SPRS_TRY(dot_host<T>(c, n, v, v_new, true, &alpha));
+            SPRS_TRY(this->cdot(v, v_new, &alpha));
             q = v;
         }
         SPRS_TRY(axpy(sfromr<T>(-beta), v_old, v_new));
@@ -891,13 +986,13 @@ int MinRes<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, d
         if (pc) {
             SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, v_new, w_new)));
             T b2;
-            SPRS_TRY(dot_host<T>(c, n, v_new, w_new, true, &b2));
+            SPRS_TRY(this->cdot(v_new, w_new, &b2));
             if (sre(b2) < EPS || sim(b2) > EPS * sre(b2)) { *its_out = its; *res_out = sre(b2); return SPRS_INVALID_PRECOND; }
             beta_new = sqrt(sre(b2));
             SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, v_new));
             SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, w_new));
         } else {
-            SPRS_TRY(norm2_host<T>(c, n, v_new, &beta_new));
+            SPRS_TRY(this->norm2(v_new, &beta_new));
             SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, v_new));
         }
         const double r3 = s_old * beta;

@@ -51,6 +51,9 @@ class KrylovBase {
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     SolverStats stats;
+    // distributed operator (A->dist): all-reduced scalars live in `red`, 16-byte slots
+    double *red = nullptr;       // device, 32 doubles
+    T *xext = nullptr;           // extended copy of a caller vector that has no halo tail
 
     int init(const sprs_csr *A_, size_t size, int nvec_);
     void destroy();
@@ -65,6 +68,18 @@ class KrylovBase {
     template <class F>
     int solve_host(const T *rhs, size_t rhs_len, T *x, size_t x_len, F &&dev_solve);
     int ew_grid() const;  // workgroups used by the fused element-wise kernels for this n
+    sprs_comm *comm() const { return A->dist ? A->dist->comm : nullptr; }
+    // Hand a producer's partials to its consumer kernel.  Single GPU: the consumer re-reduces the
+    // P partials itself.  Distributed: reduce locally (fixed order), all-reduce over the ranks, and
+    // the consumer reads one value.  `slot` picks a 16-byte cell of `red`.
+    struct PartT { const T *p; int P; };
+    struct PartD { const double *p; int P; };
+    int red1(const T *a, int P, int slot, PartT *oa);
+    int red2(const T *a, const T *b, int P, int slot, PartT *oa, PartT *ob);
+    int redD1(const double *a, int P, int slot, PartD *oa);
+    int redDT(const double *a, const T *b, int P, int slot, PartD *oa, PartT *ob);
+    int norm2(const T *x, double *out) { return norm2_host<T>(ctx, n, x, out, comm()); }
+    int cdot(const T *x, const T *y, T *out) { return dot_host<T>(ctx, n, x, y, true, out, comm()); }
 };
 
 template <class T>

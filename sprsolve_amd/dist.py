@@ -1,0 +1,109 @@
+"""Multi-GPU front end: one process per GPU, bootstrapped through torch.distributed, collectives
+on the data path issued by the C++ recurrence through RCCL (sprsolve_amd/csrc/dist.hip)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, partition
+from .device import dev_ptr, dev_sfx
+from .error import check
+from .mat import HipCsr
+
+
+class Comm:
+    """RCCL communicator of this rank.  The 128-byte unique id is created on rank 0 and
+    broadcast with torch.distributed (any backend)."""
+
+    def __init__(self, ctx, rank, world, tdist=None):
+        L = _lib.lib()
+        buf = (C.c_char * 128)()
+        if rank == 0:
+            check(L.sprs_comm_unique_id(buf), ctx.h)
+        if world > 1:
+            obj = [bytes(buf)] if rank == 0 else [None]
+            tdist.broadcast_object_list(obj, src=0)
+            buf = (C.c_char * 128).from_buffer_copy(obj[0])
+        h = C.c_void_p()
+        check(L.sprs_comm_create(ctx.h, int(world), int(rank), buf, C.byref(h)), ctx.h)
+        self.h, self.ctx, self.rank, self.world = h, ctx, rank, world
+
+    def allreduce_sum(self, dev, count):
+        check(_lib.lib().sprs_comm_allreduce_sum_f64(self.h, dev_ptr(dev), int(count)), self.ctx.h)
+
+    def close(self):
+        if self.h:
+            _lib.lib().sprs_comm_destroy(self.h)
+            self.h = None
+
+
+class DistCsr(HipCsr):
+    """Row block of a matrix partitioned over the ranks; `impl MatVecMul` like HipCsr, usable
+    with every solver (`BiCGStab.new(A, A.rows())`, rhs / x = this rank's slices)."""
+
+    @classmethod
+    def from_plan(cls, comm, plan, nnz, indptr_dev, data_dev, adopt=True, to_device=None):
+        """plan: partition.build_plan(...) with col_ext already a device array; to_device(np_array)
+        uploads the small index lists."""
+        s = dev_sfx(data_dev)
+        peers = np.asarray(plan["peers"], dtype=np.int32)
+        send_off = np.ascontiguousarray(plan["send_off"], dtype=np.int64)
+        recv_off = np.ascontiguousarray(plan["recv_off"], dtype=np.int64)
+        send_idx_dev = to_device(np.ascontiguousarray(plan["send_idx"], dtype=np.int32)) if plan["send_idx"].size else None
+        h = C.c_void_p()
+        st = getattr(_lib.lib(), "sprs_dist_csr_create_dev_" + s)(
+            comm.h, plan["n_local"], plan["n_ext"], int(nnz), dev_ptr(indptr_dev), dev_ptr(plan["col_ext"]),
+            dev_ptr(data_dev), 1 if adopt else 0, int(peers.size), peers.ctypes.data_as(C.c_void_p),
+            send_off.ctypes.data_as(C.c_void_p), dev_ptr(send_idx_dev) if send_idx_dev is not None else None,
+            recv_off.ctypes.data_as(C.c_void_p), C.byref(h))
+        check(st, comm.ctx.h)
+        dt = np.float64 if s == "d" else np.complex128
+        A = cls(h, comm.ctx, dt, (plan["n_local"], plan["n_ext"]), keepalive=(indptr_dev, plan["col_ext"], data_dev, send_idx_dev))
+        A.comm, A.plan = comm, plan
+        return A
+
+    def cols(self):
+        # the solvers are created with the number of OWNED entries
+        return self.shape[0]
+
+    def mul_vec_ext(self, x_ext, y_local):
+        """y_local = A_local * x after the halo exchange; x_ext has n_ext entries, owned slice first."""
+        st = getattr(_lib.lib(), "sprs_dist_mul_vec_dev_" + ("z" if self.dtype == np.complex128 else "d"))(
+            self.h, dev_ptr(x_ext), dev_ptr(y_local))
+        check(st, self.ctx.h)
+        self.ctx.sync()
+
+
+def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, time_solve):
+    """N > 1 leg of bench.py: cfg 5 row-partitioned in z-slabs, strong scaling."""
+    import sprsolve_amd as sa
+    from . import gen_torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    plane = nx * ny
+    starts = partition.slab_starts(nz, plane, world)
+    z0, z1 = int(starts[rank] // plane), int(starts[rank + 1] // plane)
+    ip, ix, dv, rhs = gen_torch.poisson3d(nx, ny, nz, z0, z1, device=dev)
+    nnz_loc = int(ip[-1].item())
+
+    def gather(obj):
+        out = [None] * world
+        tdist.all_gather_object(out, obj)
+        return out
+    plan = partition.build_plan(ix, starts, rank, gather)
+    comm = Comm(ctx, rank, world, tdist)
+    A = DistCsr.from_plan(comm, plan, nnz_loc, ip, dv, adopt=True,
+                          to_device=lambda a: torch.from_numpy(a).to(dev))
+    n_loc = plan["n_local"]
+    s = sa.BiCGStab.new(A, n_loc)
+    x = torch.zeros(n_loc, dtype=torch.float64, device=dev)
+    dt, prof = time_solve(torch, tdist, s, None, rhs, x, steps, warmup, world)
+    t_spmv = prof["spmv_ms_total"] / max(prof["spmv_launches"], 1) * 1e-3
+    bs = nnz_loc * 12 + (n_loc + 1) * 4 + 2 * n_loc * 8
+    x.zero_()
+    its, res = s.solve(rhs, x, 5000, 1e-8)
+    err = torch.tensor([float((x - 1.0).abs().max().item())], dtype=torch.float64, device=dev)
+    tdist.all_reduce(err, op=tdist.ReduceOp.MAX)
+    tot = torch.tensor([float(nnz_loc)], dtype=torch.float64, device=dev)
+    tdist.all_reduce(tot)
+    check_ = dict(tol=1e-8, iters=its, rel_res=res, max_abs_err_vs_exact=float(err.item()),
+                  halo_entries_per_rank=int(plan["n_ext"] - n_loc), peers=[int(p) for p in plan["peers"]])
+    return dt, prof, t_spmv, bs, check_, nx * ny * nz, int(tot.item())

@@ -1,0 +1,108 @@
+"""The RCCL data path on ONE GPU (the only multi-rank-capable box for N > 1 is the driver's):
+a world_size-1 communicator exercises every RCCL call the distributed solvers make — the
+unique-id bootstrap, ncclAllReduce of the dot scalars, and grouped ncclSend/ncclRecv of the halo
+(to self: a set of owned columns is declared 'remote' and travels through pack -> send -> recv
+into the halo tail).  Results must equal the plain single-GPU path bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import sprsolve_amd as sa
+    from sprsolve_amd import dist as sdist
+    ctx = sa.default_ctx(0)
+    comm = sdist.Comm(ctx, 0, 1)
+    yield dict(torch=torch, sa=sa, sdist=sdist, ctx=ctx, comm=comm, dev=torch.device("cuda", 0))
+    comm.close()
+
+
+def _self_halo_plan(torch, dev, n, indices, remote_mask_fn):
+    """Declare the owned columns selected by remote_mask_fn as 'remote, owned by rank 0 (self)'."""
+    cols = np.unique(indices[remote_mask_fn(indices)])
+    pos = np.searchsorted(cols, indices)
+    is_remote = remote_mask_fn(indices)
+    col_ext = np.where(is_remote, n + np.minimum(pos, max(cols.size - 1, 0)), indices).astype(np.int32)
+    k = cols.size
+    peers = [0] if k else []
+    off = np.array([0, k] if k else [0], dtype=np.int64)
+    return dict(col_ext=torch.from_numpy(col_ext).to(dev), n_local=n, n_ext=n + k, peers=peers,
+                send_off=off, send_idx=cols.astype(np.int32), recv_off=off)
+
+
+@pytest.mark.parametrize("with_halo", [False, True])
+def test_dist_operator_equals_plain(env, oracle, with_halo):
+    torch, sa, sdist, dev = env["torch"], env["sa"], env["sdist"], env["dev"]
+    from sprsolve_amd import gen
+    R = 96
+    indptr, indices, data = gen.grid_laplacian_dirichlet(R, R)
+    rhs = gen.dirichlet_rhs(R, R)
+    n = R * R
+    mask = (lambda c: (c % 7 == 3) | (c > n - 2 * R)) if with_halo else (lambda c: np.zeros(c.shape, bool))
+    plan = _self_halo_plan(torch, dev, n, indices, mask)
+    if with_halo:
+        assert plan["n_ext"] > n
+    ip_d = torch.from_numpy(indptr).to(dev); dv_d = torch.from_numpy(data).to(dev)
+    A = sdist.DistCsr.from_plan(env["comm"], plan, int(indptr[-1]), ip_d, dv_d, adopt=True,
+                                to_device=lambda a: torch.from_numpy(a).to(dev))
+    # SpMV through the halo exchange == reference fold, bit for bit
+    x = np.linspace(-1, 1, n) ** 3
+    x_ext = torch.zeros(plan["n_ext"], dtype=torch.float64, device=dev)
+    x_ext[:n] = torch.from_numpy(x).to(dev)
+    x_ext[n:] = float("nan")                       # the halo tail must be overwritten by the exchange
+    y = torch.empty(n, dtype=torch.float64, device=dev)
+    A.mul_vec_ext(x_ext, y)
+    ref = oracle.spmv(indptr, indices, data, x)
+    assert np.array_equal(y.cpu().numpy().view(np.uint64), ref.view(np.uint64))
+
+    # the solvers on the distributed operator follow the plain path bit for bit (world = 1:
+    # same partials, same local reduction order, all-reduce of one rank is the identity)
+    P = sa.DiagPrecond.new(np.where(np.diff(indptr) == 1, 1.0, -4.0))
+    plain = sa.HipCsr.new((n, n), indptr, indices, data)
+    K = 12
+    for cls, pc in ((sa.BiCGStab, None), (sa.BiCGStab, P), (sa.MinRes, None)):
+        outs = []
+        for op in (plain, A):
+            s = cls.new(op, n); s.set_trace(K)
+            xs = torch.zeros(n, dtype=torch.float64, device=dev)
+            b = torch.from_numpy(rhs).to(dev)
+            try:
+                if pc is not None:
+                    s.precond_solve(pc, b, xs, K, 0.0)
+                else:
+                    s.solve(b, xs, K, 0.0)
+            except sa.error.InsufficientIterNum:
+                pass
+            outs.append((s.trace(), xs.cpu().numpy()))
+        assert outs[0][0].shape[0] == K
+        assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True), cls.__name__
+        assert np.array_equal(outs[0][1].view(np.uint64), outs[1][1].view(np.uint64))
+    # and converge to the known solution through the distributed operator
+    s = sa.BiCGStab.new(A, n)
+    xs = torch.zeros(n, dtype=torch.float64, device=dev)
+    its, res = s.precond_solve(P, torch.from_numpy(rhs).to(dev), xs, 5000, 1e-10)
+    i, j = np.meshgrid(np.arange(R), np.arange(R), indexing="ij")
+    assert np.max(np.abs(xs.cpu().numpy() - (i + j).ravel())) < 1e-6
+
+
+def test_comm_allreduce_world1(env):
+    torch = env["torch"]
+    t = torch.arange(8, dtype=torch.float64, device=env["dev"])
+    env["comm"].allreduce_sum(t, 8)
+    assert t.cpu().tolist() == list(range(8))
+
+
+def test_invalid_plan_is_rejected(env):
+    torch, sa, sdist, dev = env["torch"], env["sa"], env["sdist"], env["dev"]
+    from sprsolve_amd import gen
+    indptr, indices, data = gen.grid_laplacian_dirichlet(8, 8)
+    n = 64
+    plan = dict(col_ext=torch.from_numpy(indices).to(dev), n_local=n, n_ext=n + 3, peers=[0],
+                send_off=np.array([0, 3], np.int64), send_idx=np.array([1, 2, 99], np.int32),   # 99 is out of range
+                recv_off=np.array([0, 3], np.int64))
+    with pytest.raises(ValueError):
+        sdist.DistCsr.from_plan(env["comm"], plan, int(indptr[-1]), torch.from_numpy(indptr).to(dev),
+                                torch.from_numpy(data).to(dev), to_device=lambda a: torch.from_numpy(a).to(dev))
