@@ -100,6 +100,8 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     else if (k == "spmv_grid") { if (value < 8 || value > MAX_GRID) return SPRS_INVALID_ARGUMENT; c->spmv_grid = (int)(value & ~7); }
     else if (k == "xcd_chunk") c->xcd_chunk = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_nt") c->spmv_nt = value < 0 ? -1 : (value ? 1 : 0);
+    else if (k == "spmv_strip") c->spmv_strip = (int)value;
+    else if (k == "halo_overlap") c->halo_overlap = value ? 1 : 0;
     else if (k == "poll") { if (value < 1) return SPRS_INVALID_ARGUMENT; c->poll = (int)value; }
     else return SPRS_INVALID_ARGUMENT;
     return SPRS_OK;
@@ -111,6 +113,8 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     if (k == "xcd_chunk") return c->xcd_chunk;
     if (k == "spmv_grid") return c->spmv_grid;
     if (k == "spmv_nt") return c->spmv_nt;
+    if (k == "spmv_strip") return c->spmv_strip;
+    if (k == "halo_overlap") return c->halo_overlap;
     if (k == "poll") return c->poll;
     if (k == "num_cu") return c->num_cu;
     if (k == "device") return c->device;
@@ -358,12 +362,18 @@ int sprs_csr_destroy(sprs_csr *A) {
         if (A->val) (void)hipFree(A->val);
     }
     if (A->rowblk) (void)hipFree(A->rowblk);
+    if (A->blk_order) (void)hipFree(A->blk_order);
     if (A->x_tmp) (void)hipFree(A->x_tmp);
     if (A->y_tmp) (void)hipFree(A->y_tmp);
     if (A->part) (void)hipFree(A->part);
     if (A->dist) {
         if (A->dist->send_idx) (void)hipFree(A->dist->send_idx);
         if (A->dist->send_buf) (void)hipFree(A->dist->send_buf);
+        if (A->dist->order_int) (void)hipFree(A->dist->order_int);
+        if (A->dist->order_bnd) (void)hipFree(A->dist->order_bnd);
+        if (A->dist->ev_pack) (void)hipEventDestroy(A->dist->ev_pack);
+        if (A->dist->ev_halo) (void)hipEventDestroy(A->dist->ev_halo);
+        if (A->dist->comm_stream) (void)hipStreamDestroy(A->dist->comm_stream);
         delete A->dist;
     }
     delete A;

@@ -87,30 +87,78 @@ int allreduce_sum(sprs_comm *comm, double *dev, size_t count) {
 }
 
 template <class T>
-int halo_exchange(const sprs_csr *A, T *x) {
+static int halo_issue(const sprs_csr *A, T *x, hipStream_t pack_stream, hipStream_t xfer_stream) {
     const sprs_dist_info *D = A->dist;
-    if (!D || D->peer.empty()) return SPRS_OK;
     sprs_ctx *c = A->ctx;
     const int64_t n_send = D->send_off.back();
     T *buf = reinterpret_cast<T *>(D->send_buf);
     if (n_send > 0) {
         int g = (int)std::min<int64_t>((n_send + BLOCK - 1) / BLOCK, 1024);
-        hipLaunchKernelGGL((pack_kernel<T>), dim3(g), dim3(BLOCK), 0, c->stream, n_send, D->send_idx, x, buf);
+        hipLaunchKernelGGL((pack_kernel<T>), dim3(g), dim3(BLOCK), 0, pack_stream, n_send, D->send_idx, x, buf);
         SPRS_HIP_TRY(c, hipGetLastError());
+    }
+    if (xfer_stream != pack_stream) {
+        SPRS_HIP_TRY(c, hipEventRecord(D->ev_pack, pack_stream));
+        SPRS_HIP_TRY(c, hipStreamWaitEvent(xfer_stream, D->ev_pack, 0));
     }
     constexpr size_t W = sizeof(T) / sizeof(double);   // complex travels as 2 doubles
     ncclComm_t comm = (ncclComm_t)D->comm->nccl;
     SPRS_NCCL_TRY(c, rccl().GroupStart());
     for (size_t p = 0; p < D->peer.size(); ++p) {
         const int64_t ns = D->send_off[p + 1] - D->send_off[p], nr = D->recv_off[p + 1] - D->recv_off[p];
-        if (ns > 0) SPRS_NCCL_TRY(c, rccl().Send(buf + D->send_off[p], (size_t)ns * W, ncclDouble, D->peer[p], comm, c->stream));
-        if (nr > 0) SPRS_NCCL_TRY(c, rccl().Recv(x + D->n_local + D->recv_off[p], (size_t)nr * W, ncclDouble, D->peer[p], comm, c->stream));
+        if (ns > 0) SPRS_NCCL_TRY(c, rccl().Send(buf + D->send_off[p], (size_t)ns * W, ncclDouble, D->peer[p], comm, xfer_stream));
+        if (nr > 0) SPRS_NCCL_TRY(c, rccl().Recv(x + D->n_local + D->recv_off[p], (size_t)nr * W, ncclDouble, D->peer[p], comm, xfer_stream));
     }
     SPRS_NCCL_TRY(c, rccl().GroupEnd());
+    if (xfer_stream != pack_stream) SPRS_HIP_TRY(c, hipEventRecord(D->ev_halo, xfer_stream));
     return SPRS_OK;
 }
+
+template <class T>
+int halo_exchange(const sprs_csr *A, T *x) {
+    const sprs_dist_info *D = A->dist;
+    if (!D || D->peer.empty()) return SPRS_OK;
+    return halo_issue<T>(A, x, A->ctx->stream, A->ctx->stream);
+}
+
+// overlapped form: the pack runs on the compute stream (it reads the just-produced x), the
+// transfer on the communication stream; halo_wait() makes the compute stream wait for it
+template <class T>
+int halo_begin(const sprs_csr *A, T *x) {
+    const sprs_dist_info *D = A->dist;
+    if (!D || D->peer.empty()) return SPRS_OK;
+    return halo_issue<T>(A, x, A->ctx->stream, D->comm_stream);
+}
+int halo_wait(const sprs_csr *A) {
+    const sprs_dist_info *D = A->dist;
+    if (!D || D->peer.empty()) return SPRS_OK;
+    SPRS_HIP_TRY(A->ctx, hipStreamWaitEvent(A->ctx->stream, D->ev_halo, 0));
+    return SPRS_OK;
+}
+template int halo_begin<double>(const sprs_csr *, double *);
+template int halo_begin<cplx>(const sprs_csr *, cplx *);
 template int halo_exchange<double>(const sprs_csr *, double *);
 template int halo_exchange<cplx>(const sprs_csr *, cplx *);
+
+// y = A_local x_ext with the halo exchange; overlapped with the interior rows when the operator was
+// split at creation.  Dot partials of the two launches are concatenated (spmv_num_partials()).
+template <class T>
+int dist_spmv(const sprs_csr *A, T *x_ext, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status,
+              bool conj_x) {
+    const sprs_dist_info *D = A->dist;
+    if (!D->order_int) {
+        SPRS_TRY(halo_exchange<T>(A, x_ext));
+        return launch_spmv<T>(A, x_ext, y, dot_mode, u, part0, part1, status, conj_x);
+    }
+    SPRS_TRY(halo_begin<T>(A, x_ext));
+    SPRS_TRY(launch_spmv_subset<T>(A, D->order_int, D->n_int, x_ext, y, dot_mode, u, part0, part1, status, conj_x));
+    SPRS_TRY(halo_wait(A));
+    const int off = spmv_subset_grid(A, D->n_int);
+    return launch_spmv_subset<T>(A, D->order_bnd, D->n_bnd, x_ext, y, dot_mode, u, part0 ? part0 + off : nullptr,
+                                 part1 ? part1 + off : nullptr, status, conj_x);
+}
+template int dist_spmv<double>(const sprs_csr *, double *, double *, int, const double *, double *, double *, const int *, bool);
+template int dist_spmv<cplx>(const sprs_csr *, cplx *, cplx *, int, const cplx *, cplx *, cplx *, const int *, bool);
 
 }  // namespace sprs
 
@@ -157,6 +205,26 @@ int dist_csr_create(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz
             hipMemcpy(D->send_idx, send_idx_dev, sizeof(int32_t) * (size_t)n_send, hipMemcpyDeviceToDevice) != hipSuccess) {
             sprs_csr_destroy(A);
             return SPRS_ERR_HIP;
+        }
+    }
+    // interior / boundary split of the row blocks: a block is "boundary" if any of its rows reads
+    // the halo tail (column >= n_local).  Interior blocks are multiplied while the halo travels.
+    if (n_peers > 0 && c->halo_overlap) {
+        std::vector<int32_t> lo, hi;
+        st = rowblk_spans(A, lo, hi);
+        if (st != SPRS_OK) { sprs_csr_destroy(A); return st; }
+        std::vector<int32_t> oi, ob;
+        for (int b = 0; b < A->n_rowblk; ++b) (hi[b] >= n_local ? ob : oi).push_back(b);
+        if (!oi.empty() && !ob.empty() && ob.size() * 2 <= (size_t)A->n_rowblk) {
+            bool ok = hipMalloc((void **)&D->order_int, sizeof(int32_t) * oi.size()) == hipSuccess &&
+                      hipMalloc((void **)&D->order_bnd, sizeof(int32_t) * ob.size()) == hipSuccess &&
+                      hipMemcpy(D->order_int, oi.data(), sizeof(int32_t) * oi.size(), hipMemcpyHostToDevice) == hipSuccess &&
+                      hipMemcpy(D->order_bnd, ob.data(), sizeof(int32_t) * ob.size(), hipMemcpyHostToDevice) == hipSuccess &&
+                      hipStreamCreateWithFlags(&D->comm_stream, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&D->ev_pack, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&D->ev_halo, hipEventDisableTiming) == hipSuccess;
+            if (!ok) { sprs_csr_destroy(A); return SPRS_ERR_HIP; }
+            D->n_int = (int32_t)oi.size(); D->n_bnd = (int32_t)ob.size();
         }
     }
     *out = A;
@@ -228,13 +296,11 @@ int sprs_dist_csr_create_dev_z(sprs_comm *comm, int64_t n_local, int64_t n_ext, 
 // first n_local entries are this rank's slice of x)
 int sprs_dist_mul_vec_dev_d(const sprs_csr *A, double *x_ext, double *y_local) {
     if (!A || !A->dist || A->is_complex) return SPRS_INVALID_ARGUMENT;
-    SPRS_TRY(halo_exchange<double>(A, x_ext));
-    return launch_spmv<double>(A, x_ext, y_local, 0, nullptr, nullptr, nullptr, nullptr);
+    return dist_spmv<double>(A, x_ext, y_local, 0, nullptr, nullptr, nullptr, nullptr, false);
 }
 int sprs_dist_mul_vec_dev_z(const sprs_csr *A, sprs_c64 *x_ext, sprs_c64 *y_local) {
     if (!A || !A->dist || !A->is_complex) return SPRS_INVALID_ARGUMENT;
-    SPRS_TRY(halo_exchange<cplx>(A, (cplx *)x_ext));
-    return launch_spmv<cplx>(A, (const cplx *)x_ext, (cplx *)y_local, 0, nullptr, nullptr, nullptr, nullptr);
+    return dist_spmv<cplx>(A, (cplx *)x_ext, (cplx *)y_local, 0, nullptr, nullptr, nullptr, nullptr, false);
 }
 
 }  // extern "C"

@@ -32,6 +32,11 @@ struct sprs_ctx {
     // with plain loads (all XCDs sweep the same region, x re-reads are served by the Infinity Cache).
     int xcd_chunk = -1;
     int spmv_nt = -1;
+    // SpMV row-block schedule for matrices with far bands (3-D stencils): rows per strip; 0 = natural
+    // order (default: the strip-major walk measured SLOWER on MI355X, profiles/r01_tuning.md), -1 = auto.
+    // Read at handle creation.
+    int spmv_strip = 0;
+    int halo_overlap = 1;  // distributed SpMV: run the halo-free rows while the halo travels
     int poll = 16;       // iterations between host polls of the device status word
     double *d_part = nullptr;  // reduction partials for the stand-alone vecalg entry points
     double *d_scal = nullptr;  // small device result buffer
@@ -73,6 +78,11 @@ struct sprs_dist_info {
     std::vector<int64_t> send_off, recv_off;   // n_peers + 1 each (elements)
     int32_t *send_idx = nullptr;               // device: local indices to pack, grouped by peer
     void *send_buf = nullptr;                  // device: packed values
+    // overlap of the halo exchange with the SpMV of the rows that need no halo entry
+    int32_t *order_int = nullptr, *order_bnd = nullptr;   // device: interior / boundary row blocks
+    int32_t n_int = 0, n_bnd = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
 };
 
 struct sprs_csr {
@@ -85,6 +95,8 @@ struct sprs_csr {
     bool owns_arrays = true;
     int32_t *rowblk = nullptr;   // device: n_rowblk+1 row starts, bit31 set on vector-mode blocks
     int32_t n_rowblk = 0;
+    int32_t *blk_order = nullptr;  // device: schedule of the row blocks (n_rowblk entries) or null = natural order
+    int64_t sched_period = 0;      // rows between the far bands the schedule folds over (0 = no schedule)
     // scratch for the host-slice trait entry points (lazily allocated)
     void *x_tmp = nullptr, *y_tmp = nullptr;
     double *part = nullptr;      // partials for mul_vec_dot
@@ -111,6 +123,13 @@ int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T
                 bool conj_x = false);
 int build_rowblocks(sprs_csr *A, const int32_t *host_row_ptr);
 int spmv_num_partials(const sprs_csr *A);  // workgroups launch_spmv uses == partials it writes
+// per-row-block column span (device kernel + D2H): lo/hi sized n_rowblk
+int rowblk_spans(const sprs_csr *A, std::vector<int32_t> &lo, std::vector<int32_t> &hi);
+// SpMV over a subset of the row blocks (order[0..count)); writes `subset_grid(count)` partials
+template <class T>
+int launch_spmv_subset(const sprs_csr *A, const int32_t *order, int count, const T *x, T *y, int dot_mode, const T *u,
+                       T *part0, T *part1, const int *status, bool conj_x);
+int spmv_subset_grid(const sprs_csr *A, int count);
 
 // ---- blas1.hip  (all on ctx->stream, asynchronous)
 template <class T, class S> int launch_axpy(sprs_ctx *c, size_t n, S a, const T *x, T *y);
@@ -130,6 +149,12 @@ template <class T> int reduce_partials_host(sprs_ctx *c, const T *part, int P, T
 // ---- dist.hip
 // exchange the halo entries of the extended vector x (local part [0,n_local) already in place)
 template <class T> int halo_exchange(const sprs_csr *A, T *x_ext);
+// split form used for overlap: pack + exchange on the communication stream (returns immediately),
+// then make the compute stream wait for the halo
+template <class T> int halo_begin(const sprs_csr *A, T *x_ext);
+int halo_wait(const sprs_csr *A);
+template <class T>
+int dist_spmv(const sprs_csr *A, T *x_ext, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status, bool conj_x);
 int allreduce_sum(sprs_comm *comm, double *dev, size_t count);   // in place, on the ctx stream
 
 inline int grid_for(const sprs_ctx *c) {

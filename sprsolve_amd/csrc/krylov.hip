@@ -426,10 +426,13 @@ int KrylovBase<T>::spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, con
             SPRS_HIP_TRY(ctx, hipMemcpyAsync(xext, x, sizeof(T) * n, hipMemcpyDeviceToDevice, ctx->stream));
             xe = xext;
         }
-        SPRS_TRY(halo_exchange<T>(A, xe));
         x = xe;
     }
-    if (!profile) return launch_spmv<T>(A, x, y, dot, u, p0, p1, status, conj_x);
+    auto run = [&]() -> int {
+        if (A->dist) return dist_spmv<T>(A, const_cast<T *>(x), y, dot, u, p0, p1, status, conj_x);
+        return launch_spmv<T>(A, x, y, dot, u, p0, p1, status, conj_x);
+    };
+    if (!profile) return run();
     if (ev_used + 2 > ev.size()) {
         for (int k = 0; k < 2; ++k) {
             hipEvent_t e;
@@ -438,7 +441,7 @@ int KrylovBase<T>::spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, con
         }
     }
     SPRS_HIP_TRY(ctx, hipEventRecord(ev[ev_used], ctx->stream));
-    int st = launch_spmv<T>(A, x, y, dot, u, p0, p1, status, conj_x);
+    int st = run();
     SPRS_HIP_TRY(ctx, hipEventRecord(ev[ev_used + 1], ctx->stream));
     ev_used += 2;
     return st;

@@ -17,6 +17,8 @@
 //    neighbouring rows hits that XCD's L2.
 //  * Optional fused epilogue: per-workgroup partials of conj(u).y, or of conj(y).y and
 //    conj(y).u, so the solvers' dot products cost no extra pass over y.
+#include <algorithm>
+
 #include "device.hpp"
 
 namespace sprs {
@@ -27,6 +29,8 @@ constexpr uint32_t VEC_FLAG = 0x80000000u;
 
 template <class T> struct nnz_cap { static constexpr int value = 2048; };       // 16 KiB LDS
 template <> struct nnz_cap<cplx> { static constexpr int value = 1280; };        // 20 KiB LDS
+
+int build_schedule(sprs_csr *A, const std::vector<int32_t> &blk);
 
 // Host-side analysis: greedy partition of the rows into blocks (see header comment).
 int build_rowblocks(sprs_csr *A, const int32_t *rp) {
@@ -60,7 +64,7 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
     SPRS_HIP_TRY(c, hipMalloc((void **)&A->rowblk, blk.size() * sizeof(int32_t)));
     SPRS_HIP_TRY(c, hipMemcpyAsync(A->rowblk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return SPRS_OK;
+    return build_schedule(A, blk);
 }
 
 // streaming (read-once) loads: keep the matrix stream from evicting the gathered x lines
@@ -78,6 +82,7 @@ template <bool NT> __device__ __forceinline__ cplx ld_val(const cplx *p) { retur
 
 template <class T, int DOT, bool CONJX, bool NT>
 __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk, const int32_t *__restrict__ rowblk,
+                                                     const int32_t *__restrict__ order,
                                                      const int32_t *__restrict__ row_ptr,
                                                      const int32_t *__restrict__ col_idx, const T *__restrict__ val,
                                                      const T *__restrict__ x, T *__restrict__ y,
@@ -107,9 +112,10 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
     }
 
     for (; b < bend; b += bstep) {
-        const uint32_t rb0 = (uint32_t)rowblk[b];
+        const int bb = order ? order[b] : b;          // scheduled position -> row block
+        const uint32_t rb0 = (uint32_t)rowblk[bb];
         const int ra = (int)(rb0 & ~VEC_FLAG);
-        const int rb = (int)((uint32_t)rowblk[b + 1] & ~VEC_FLAG);
+        const int rb = (int)((uint32_t)rowblk[bb + 1] & ~VEC_FLAG);
         if (!(rb0 & VEC_FLAG)) {
             // ---------------- stream block: products to LDS, then one lane per row
             const int pa = row_ptr[ra];
@@ -164,6 +170,107 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Row-block schedule for matrices with far bands.
+//
+// A 3-D stencil row i gathers x[i], x[i +- nx] and x[i +- P] (P = nx*ny rows, 2 MB of x apart for
+// cfg 5).  Swept in natural order the three x streams of one XCD are 2P rows apart, more than its
+// 4 MiB L2 holds, so every x line is fetched from the fabric several times (measured: 5.5 reads of
+// x instead of 1, profiles/r01_pmc_summary.json).  Row blocks are independent, so they may be
+// processed in any order: fold the row index at period P and walk "strip-major" — all periods of
+// one strip of S rows before the next strip.  Consecutive blocks in time then touch x cells
+// (strip, k-1), (strip, k), (strip, k+1), each S*8 bytes, which stay L2-resident until reused.
+// The result vector is unchanged (each row is still summed by one lane in nnz order).
+// The period is detected from the per-block column span; matrices without far bands keep the
+// natural order.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void rowblk_span_kernel(int n_rowblk, const int32_t *__restrict__ rowblk,
+                                                            const int32_t *__restrict__ row_ptr,
+                                                            const int32_t *__restrict__ col_idx, int32_t *__restrict__ lo,
+                                                            int32_t *__restrict__ hi) {
+    __shared__ int smin[NWAVE], smax[NWAVE];
+    for (int b = blockIdx.x; b < n_rowblk; b += gridDim.x) {
+        const int ra = (int)((uint32_t)rowblk[b] & ~VEC_FLAG), rb = (int)((uint32_t)rowblk[b + 1] & ~VEC_FLAG);
+        const int pa = row_ptr[ra], pb = row_ptr[rb];
+        int mn = INT32_MAX, mx = -1;
+        for (int k = pa + threadIdx.x; k < pb; k += BLOCK) { const int cidx = col_idx[k]; mn = min(mn, cidx); mx = max(mx, cidx); }
+        for (int off = WAVE / 2; off > 0; off >>= 1) { mn = min(mn, __shfl_down(mn, off, WAVE)); mx = max(mx, __shfl_down(mx, off, WAVE)); }
+        __syncthreads();
+        if ((threadIdx.x & (WAVE - 1)) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < NWAVE; ++w) { mn = min(mn, smin[w]); mx = max(mx, smax[w]); }
+            mn = min(mn, smin[0]); mx = max(mx, smax[0]);
+            lo[b] = mn; hi[b] = mx;
+        }
+    }
+}
+
+int rowblk_spans(const sprs_csr *A, std::vector<int32_t> &lo, std::vector<int32_t> &hi) {
+    sprs_ctx *c = A->ctx;
+    const int nb = A->n_rowblk;
+    lo.assign((size_t)nb, INT32_MAX); hi.assign((size_t)nb, -1);
+    if (nb == 0) return SPRS_OK;
+    int32_t *d_lo = nullptr, *d_hi = nullptr;
+    SPRS_HIP_TRY(c, hipMalloc((void **)&d_lo, sizeof(int32_t) * nb));
+    SPRS_HIP_TRY(c, hipMalloc((void **)&d_hi, sizeof(int32_t) * nb));
+    const int g = nb < 2048 ? nb : 2048;
+    if (A->is_complex)
+        hipLaunchKernelGGL((rowblk_span_kernel<cplx>), dim3(g), dim3(BLOCK), 0, c->stream, nb, A->rowblk, A->row_ptr, A->col_idx, d_lo, d_hi);
+    else
+        hipLaunchKernelGGL((rowblk_span_kernel<double>), dim3(g), dim3(BLOCK), 0, c->stream, nb, A->rowblk, A->row_ptr, A->col_idx, d_lo, d_hi);
+    hipError_t e1 = hipMemcpyAsync(lo.data(), d_lo, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipMemcpyAsync(hi.data(), d_hi, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e3 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_lo); (void)hipFree(d_hi);
+    SPRS_HIP_TRY(c, e1); SPRS_HIP_TRY(c, e2); SPRS_HIP_TRY(c, e3);
+    return SPRS_OK;
+}
+
+int build_schedule(sprs_csr *A, const std::vector<int32_t> &blk) {
+    sprs_ctx *c = A->ctx;
+    const int nb = A->n_rowblk;
+    int strip = c->spmv_strip;
+    if (strip == 0 || nb < 64 || A->nnz == 0) return SPRS_OK;
+    std::vector<int32_t> lo, hi;
+    SPRS_TRY(rowblk_spans(A, lo, hi));
+    // period = typical reach of the far band: median over blocks of max(row_start - lo, hi - row_end)
+    std::vector<int64_t> reach;
+    reach.reserve(nb);
+    for (int b = 0; b < nb; ++b) {
+        const int64_t ra = (int64_t)((uint32_t)blk[b] & ~VEC_FLAG), rb = (int64_t)((uint32_t)blk[b + 1] & ~VEC_FLAG);
+        if (hi[b] < 0) continue;
+        reach.push_back(std::max<int64_t>(std::max<int64_t>(ra - lo[b], (int64_t)hi[b] - (rb - 1)), 0));
+    }
+    if (reach.size() < 64) return SPRS_OK;
+    std::nth_element(reach.begin(), reach.begin() + reach.size() / 2, reach.end());
+    const int64_t P = reach[reach.size() / 2];
+    const size_t sT = A->is_complex ? 16 : 8;
+    // worth it only when the far bands are farther apart than an XCD's L2 can bridge, and the
+    // matrix has at least a few periods
+    if (strip < 0) {
+        if ((double)P * sT * 2 < 3.0 * 1024 * 1024 || P * 4 > A->nrows) return SPRS_OK;
+        strip = 8192;
+    }
+    if (P < 2 * (int64_t)strip) return SPRS_OK;
+    std::vector<std::pair<uint64_t, int32_t>> key(nb);
+    const uint64_t nper = (uint64_t)(A->nrows / P + 2);
+    for (int b = 0; b < nb; ++b) {
+        const uint64_t r = (uint64_t)((uint32_t)blk[b] & ~VEC_FLAG);
+        const uint64_t k = r / (uint64_t)P, o = r % (uint64_t)P;
+        key[b] = {((o / (uint64_t)strip) * nper + k) * (uint64_t)strip + (o % (uint64_t)strip), b};
+    }
+    std::sort(key.begin(), key.end());
+    std::vector<int32_t> order(nb);
+    for (int b = 0; b < nb; ++b) order[b] = key[b].second;
+    SPRS_HIP_TRY(c, hipMalloc((void **)&A->blk_order, sizeof(int32_t) * nb));
+    SPRS_HIP_TRY(c, hipMemcpyAsync(A->blk_order, order.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, c->stream));
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    A->sched_period = P;
+    return SPRS_OK;
+}
+
 // number of workgroups launch_spmv uses == number of partials it writes
 static inline int spmv_grid(const sprs_csr *A) {
     int g = A->ctx->spmv_grid;
@@ -176,18 +283,31 @@ static inline int spmv_grid(const sprs_csr *A) {
     return g < need ? g : need;
 }
 
+static inline int grid_for_blocks(const sprs_csr *A, int count) {
+    int g = A->ctx->spmv_grid;
+    if (g < 8) g = 8;
+    if (g > MAX_GRID / 2) g = MAX_GRID / 2;
+    g &= ~7;
+    int need = ((count + 7) / 8) * 8;
+    if (need < 8) need = 8;
+    return g < need ? g : need;
+}
+int spmv_subset_grid(const sprs_csr *A, int count) { return grid_for_blocks(A, count); }
+
 template <class T>
-int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status,
-                bool conj_x) {
+static int launch_spmv_impl(const sprs_csr *A, const int32_t *order, int count, int g, const T *x, T *y, int dot_mode,
+                            const T *u, T *part0, T *part1, const int *status, bool conj_x) {
     sprs_ctx *c = A->ctx;
-    const int g = spmv_grid(A);
     const T *v = reinterpret_cast<const T *>(A->val);
     const bool cache_resident = (double)A->nnz * (sizeof(T) + 4) + 3.0 * A->nrows * sizeof(T) < 192.0 * 1024 * 1024;
-    const int xcd_chunk = c->xcd_chunk < 0 ? (cache_resident ? 1 : 0) : c->xcd_chunk;
-    const bool nt = c->spmv_nt < 0 ? cache_resident : (c->spmv_nt != 0);
+    // a scheduled matrix wants each XCD on its own contiguous run of the schedule (that is what makes
+    // the far-band x entries hit in that XCD's L2) and the read-once stream kept out of L2
+    const bool sched = A->blk_order != nullptr;
+    const int xcd_chunk = c->xcd_chunk < 0 ? ((cache_resident || sched) ? 1 : 0) : c->xcd_chunk;
+    const bool nt = c->spmv_nt < 0 ? (cache_resident || sched) : (c->spmv_nt != 0);
 #define SPRS_SPMV2(D, CJ, NTF)                                                                                        \
-    hipLaunchKernelGGL((spmv_kernel<T, D, CJ, NTF>), dim3(g), dim3(BLOCK), 0, c->stream, (int)A->n_rowblk,            \
-                       xcd_chunk, A->rowblk, A->row_ptr, A->col_idx, v, x, y, u, part0, part1, status)
+    hipLaunchKernelGGL((spmv_kernel<T, D, CJ, NTF>), dim3(g), dim3(BLOCK), 0, c->stream, count,                       \
+                       xcd_chunk, A->rowblk, order, A->row_ptr, A->col_idx, v, x, y, u, part0, part1, status)
 #define SPRS_SPMV(D, CJ) do { if (nt) SPRS_SPMV2(D, CJ, true); else SPRS_SPMV2(D, CJ, false); } while (0)
     if (conj_x && is_complex<T>::value) {  // only CSMINRES on complex data needs the conjugated gather
         if (dot_mode == 0) SPRS_SPMV(0, true);
@@ -204,9 +324,27 @@ int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T
     return SPRS_OK;
 }
 
-int spmv_num_partials(const sprs_csr *A) { return spmv_grid(A); }
+template <class T>
+int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status,
+                bool conj_x) {
+    return launch_spmv_impl<T>(A, A->blk_order, (int)A->n_rowblk, spmv_grid(A), x, y, dot_mode, u, part0, part1, status, conj_x);
+}
+
+template <class T>
+int launch_spmv_subset(const sprs_csr *A, const int32_t *order, int count, const T *x, T *y, int dot_mode, const T *u,
+                       T *part0, T *part1, const int *status, bool conj_x) {
+    return launch_spmv_impl<T>(A, order, count, grid_for_blocks(A, count), x, y, dot_mode, u, part0, part1, status, conj_x);
+}
+
+// distributed operators with an interior/boundary split run two launches whose partials are concatenated
+int spmv_num_partials(const sprs_csr *A) {
+    if (A->dist && A->dist->order_int) return grid_for_blocks(A, A->dist->n_int) + grid_for_blocks(A, A->dist->n_bnd);
+    return spmv_grid(A);
+}
 
 template int launch_spmv<double>(const sprs_csr *, const double *, double *, int, const double *, double *, double *, const int *, bool);
 template int launch_spmv<cplx>(const sprs_csr *, const cplx *, cplx *, int, const cplx *, cplx *, cplx *, const int *, bool);
+template int launch_spmv_subset<double>(const sprs_csr *, const int32_t *, int, const double *, double *, int, const double *, double *, double *, const int *, bool);
+template int launch_spmv_subset<cplx>(const sprs_csr *, const int32_t *, int, const cplx *, cplx *, int, const cplx *, cplx *, cplx *, const int *, bool);
 
 }  // namespace sprs

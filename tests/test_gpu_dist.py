@@ -20,20 +20,24 @@ def env():
     comm.close()
 
 
-def _self_halo_plan(torch, dev, n, indices, remote_mask_fn):
+def _self_halo_plan(torch, dev, n, indices, remote_mask_fn, segments=1):
     """Declare the owned columns selected by remote_mask_fn as 'remote, owned by rank 0 (self)'."""
     cols = np.unique(indices[remote_mask_fn(indices)])
     pos = np.searchsorted(cols, indices)
     is_remote = remote_mask_fn(indices)
     col_ext = np.where(is_remote, n + np.minimum(pos, max(cols.size - 1, 0)), indices).astype(np.int32)
     k = cols.size
-    peers = [0] if k else []
-    off = np.array([0, k] if k else [0], dtype=np.int64)
+    if k and segments == 2:
+        # two exchange segments, both with rank 0 (self): exercises the per-peer offset arithmetic
+        peers, off = [0, 0], np.array([0, k // 3, k], dtype=np.int64)
+    else:
+        peers = [0] if k else []
+        off = np.array([0, k] if k else [0], dtype=np.int64)
     return dict(col_ext=torch.from_numpy(col_ext).to(dev), n_local=n, n_ext=n + k, peers=peers,
                 send_off=off, send_idx=cols.astype(np.int32), recv_off=off)
 
 
-@pytest.mark.parametrize("with_halo", [False, True])
+@pytest.mark.parametrize("with_halo", ["none", "scattered", "tail-overlapped", "tail-2-segments", "tail-no-overlap"])
 def test_dist_operator_equals_plain(env, oracle, with_halo):
     torch, sa, sdist, dev = env["torch"], env["sa"], env["sdist"], env["dev"]
     from sprsolve_amd import gen
@@ -41,9 +45,12 @@ def test_dist_operator_equals_plain(env, oracle, with_halo):
     indptr, indices, data = gen.grid_laplacian_dirichlet(R, R)
     rhs = gen.dirichlet_rhs(R, R)
     n = R * R
-    mask = (lambda c: (c % 7 == 3) | (c > n - 2 * R)) if with_halo else (lambda c: np.zeros(c.shape, bool))
-    plan = _self_halo_plan(torch, dev, n, indices, mask)
-    if with_halo:
+    mask = {"none": lambda c: np.zeros(c.shape, bool),
+            "scattered": lambda c: (c % 7 == 3) | (c > n - 2 * R),      # every row block touches the halo: no split
+            }.get(with_halo, lambda c: c > n - 3 * R)                   # only the last rows do: interior/boundary overlap
+    plan = _self_halo_plan(torch, dev, n, indices, mask, segments=2 if with_halo == "tail-2-segments" else 1)
+    env["ctx"].set("halo_overlap", 0 if with_halo == "tail-no-overlap" else 1)
+    if with_halo != "none":
         assert plan["n_ext"] > n
     ip_d = torch.from_numpy(indptr).to(dev); dv_d = torch.from_numpy(data).to(dev)
     A = sdist.DistCsr.from_plan(env["comm"], plan, int(indptr[-1]), ip_d, dv_d, adopt=True,
@@ -78,8 +85,14 @@ def test_dist_operator_equals_plain(env, oracle, with_halo):
                 pass
             outs.append((s.trace(), xs.cpu().numpy()))
         assert outs[0][0].shape[0] == K
-        assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True), cls.__name__
-        assert np.array_equal(outs[0][1].view(np.uint64), outs[1][1].view(np.uint64))
+        if with_halo in ("tail-overlapped", "tail-2-segments"):
+            # interior and boundary rows are multiplied by two launches: the dot partials are grouped
+            # differently, so scalars agree to rounding, not bit for bit (and on this Dirichlet grid the
+            # trajectories part after the unrolled iteration — see test_solver_trace_lockstep)
+            assert np.allclose(outs[0][0][0], outs[1][0][0], rtol=1e-12, atol=0), cls.__name__
+        else:
+            assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True), cls.__name__
+            assert np.array_equal(outs[0][1].view(np.uint64), outs[1][1].view(np.uint64))
     # and converge to the known solution through the distributed operator
     s = sa.BiCGStab.new(A, n)
     xs = torch.zeros(n, dtype=torch.float64, device=dev)
