@@ -102,7 +102,9 @@ int sprs_mul_vec_z(const sprs_csr *A, const sprs_c64 *x_host, size_t x_len, sprs
 int sprs_mul_vec_dot_d(const sprs_csr *A, const double *x_host, size_t x_len, double *y_host, size_t y_len, double *dot_out);
 int sprs_mul_vec_dot_z(const sprs_csr *A, const sprs_c64 *x_host, size_t x_len, sprs_c64 *y_host, size_t y_len, sprs_c64 *dot_out);
 /* MatVecMul::mul_vec_unchecked / mul_vec_dot_unchecked (mat.rs:68-152) on device vectors:
- * no dimension check, no PCIe traffic.  x_dev has ncols elements, y_dev nrows. */
+ * no dimension check, no PCIe traffic.  x_dev has ncols elements, y_dev nrows.  sprs_mul_vec_dev_* and the
+ * element-wise vecalg entry points below are ASYNCHRONOUS on the context's stream (sprs_ctx_sync to wait);
+ * entry points that return a scalar, and all solves, block. */
 int sprs_mul_vec_dev_d(const sprs_csr *A, const double *x_dev, double *y_dev);
 int sprs_mul_vec_dev_z(const sprs_csr *A, const sprs_c64 *x_dev, sprs_c64 *y_dev);
 int sprs_mul_vec_dot_dev_d(const sprs_csr *A, const double *x_dev, double *y_dev, double *dot_out);

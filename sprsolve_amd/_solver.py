@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .device import dev_len, dev_ptr, is_device_array
+from .device import dev_len, dev_ptr, is_device_array, pre_sync
 from .error import check, solve_result
 
 
@@ -63,6 +63,7 @@ class _SolverBase:
         if dev != is_device_array(x):
             raise TypeError("rhs and x must both be host arrays or both be device vectors")
         if dev:
+            pre_sync(rhs, x)
             rp, rl, xp, xl = dev_ptr(rhs), dev_len(rhs), dev_ptr(x), dev_len(x)
             if self.NAME == "csminres":
                 st = getattr(L, "sprs_csminres_solve_dev_" + self.s)(self.h, rp, rl, xp, xl, int(max_iter), float(tol),

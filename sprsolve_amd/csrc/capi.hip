@@ -63,8 +63,6 @@ int sprs_ctx_create(int device, void *stream, sprs_ctx **out) {
     // number of reduction partials (== grid) stays small enough for the fused prologues
     c->grid = ((c->num_cu * 4 + 7) / 8) * 8;
     if (c->grid > MAX_GRID) c->grid = MAX_GRID;
-    c->spmv_grid = ((c->num_cu * 8 + 7) / 8) * 8;
-    if (c->spmv_grid > MAX_GRID) c->spmv_grid = MAX_GRID;
     if (hipMalloc((void **)&c->d_part, sizeof(double) * 2 * MAX_GRID) != hipSuccess) return fail(SPRS_ERR_HIP);
     if (hipMalloc((void **)&c->d_scal, 256) != hipSuccess) return fail(SPRS_ERR_HIP);
     if (hipHostMalloc((void **)&c->h_scal, 256, hipHostMallocDefault) != hipSuccess) return fail(SPRS_ERR_HIP);
@@ -97,7 +95,7 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return SPRS_INVALID_ARGUMENT;
     std::string k(key);
     if (k == "grid") { if (value < 8 || value > MAX_GRID) return SPRS_INVALID_ARGUMENT; c->grid = (int)(value & ~7); }
-    else if (k == "spmv_grid") { if (value < 8 || value > MAX_GRID) return SPRS_INVALID_ARGUMENT; c->spmv_grid = (int)(value & ~7); }
+    else if (k == "spmv_grid") { if (value > MAX_GRID / 2 || (value >= 0 && value < 8)) return SPRS_INVALID_ARGUMENT; c->spmv_grid = value < 0 ? -1 : (int)(value & ~7); }
     else if (k == "xcd_chunk") c->xcd_chunk = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_nt") c->spmv_nt = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_strip") c->spmv_strip = (int)value;
@@ -363,6 +361,7 @@ int sprs_csr_destroy(sprs_csr *A) {
     }
     if (A->rowblk) (void)hipFree(A->rowblk);
     if (A->blk_order) (void)hipFree(A->blk_order);
+    if (A->blk_desc) (void)hipFree(A->blk_desc);
     if (A->x_tmp) (void)hipFree(A->x_tmp);
     if (A->y_tmp) (void)hipFree(A->y_tmp);
     if (A->part) (void)hipFree(A->part);

@@ -25,7 +25,7 @@ struct sprs_ctx {
     bool own_stream = false;
     int num_cu = 256;
     int grid = 1024;     // blocks launched by streaming / reduction kernels (multiple of 8)
-    int spmv_grid = 2048;  // workgroups of the persistent SpMV grid (8 per CU: full occupancy hides the gather latency)
+    int spmv_grid = -1;    // workgroups of the persistent SpMV grid; -1 = auto (4 per CU)
     // SpMV placement knobs; -1 = auto (measured on MI355X, profiles/r01_tuning.md): matrices whose stream
     // fits the 256 MiB Infinity Cache run best with one contiguous chunk of row blocks per XCD and
     // non-temporal (col_idx, val) loads (x stays in that XCD's L2); HBM-bound ones run best round-robin
@@ -95,6 +95,7 @@ struct sprs_csr {
     bool owns_arrays = true;
     int32_t *rowblk = nullptr;   // device: n_rowblk+1 row starts, bit31 set on vector-mode blocks
     int32_t n_rowblk = 0;
+    void *blk_desc = nullptr;      // device: one 16-byte {ra, rb|flag, pa, nn} descriptor per row block
     int32_t *blk_order = nullptr;  // device: schedule of the row blocks (n_rowblk entries) or null = natural order
     int64_t sched_period = 0;      // rows between the far bands the schedule folds over (0 = no schedule)
     // scratch for the host-slice trait entry points (lazily allocated)

@@ -27,6 +27,8 @@ constexpr int ROWS_CAP = BLOCK;   // rows per stream block: one lane per row in 
 constexpr int LONG_ROW = 96;      // rows longer than this go to the wavefront-per-row path
 constexpr uint32_t VEC_FLAG = 0x80000000u;
 
+struct BlkDescHost { int32_t ra, rb, pa, nn; };   // == BlkDesc (device side)
+
 template <class T> struct nnz_cap { static constexpr int value = 2048; };       // 16 KiB LDS
 template <> struct nnz_cap<cplx> { static constexpr int value = 1280; };        // 20 KiB LDS
 
@@ -61,6 +63,18 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
     blk.push_back((int32_t)n);
     A->n_rowblk = (int32_t)blk.size() - 1;
     sprs_ctx *c = A->ctx;
+    {
+        std::vector<BlkDescHost> desc((size_t)A->n_rowblk);
+        for (int b = 0; b < A->n_rowblk; ++b) {
+            const uint32_t r0 = (uint32_t)blk[b], r1 = (uint32_t)blk[b + 1];
+            const int32_t ra = (int32_t)(r0 & ~VEC_FLAG), rbv = (int32_t)(r1 & ~VEC_FLAG);
+            desc[b] = BlkDescHost{ra, (int32_t)((uint32_t)rbv | (r0 & VEC_FLAG)), rp[ra], rp[rbv] - rp[ra]};
+        }
+        SPRS_HIP_TRY(c, hipMalloc(&A->blk_desc, sizeof(BlkDescHost) * (desc.size() ? desc.size() : 1)));
+        if (!desc.empty())
+            SPRS_HIP_TRY(c, hipMemcpyAsync(A->blk_desc, desc.data(), sizeof(BlkDescHost) * desc.size(), hipMemcpyHostToDevice, c->stream));
+        SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     SPRS_HIP_TRY(c, hipMalloc((void **)&A->rowblk, blk.size() * sizeof(int32_t)));
     SPRS_HIP_TRY(c, hipMemcpyAsync(A->rowblk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -80,8 +94,17 @@ __device__ __forceinline__ cplx ld_stream_c(const cplx *p, bool nt) {
 template <bool NT> __device__ __forceinline__ double ld_val(const double *p) { return ld_stream<NT>(p); }
 template <bool NT> __device__ __forceinline__ cplx ld_val(const cplx *p) { return ld_stream_c(p, NT); }
 
+// Row-block descriptor, precomputed at handle creation so that one 16-byte load tells a workgroup
+// everything about its next block (no dependent rowblk -> row_ptr -> row_ptr chain per block).
+struct alignas(16) BlkDesc {
+    int32_t ra;      // first row
+    int32_t rb;      // one past the last row; bit 31 = vector (wavefront-per-row) block
+    int32_t pa;      // first nnz
+    int32_t nn;      // nnz in the block
+};
+
 template <class T, int DOT, bool CONJX, bool NT>
-__global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk, const int32_t *__restrict__ rowblk,
+__global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk, const BlkDesc *__restrict__ desc,
                                                      const int32_t *__restrict__ order,
                                                      const int32_t *__restrict__ row_ptr,
                                                      const int32_t *__restrict__ col_idx, const T *__restrict__ val,
@@ -111,36 +134,60 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
         b = blockIdx.x; bstep = gridDim.x; bend = n_rowblk;
     }
 
+    // Every stream load is unconditional on a clamped (always valid) address so the compiler issues
+    // them back to back — 2*ITEMS stream loads, then ITEMS gathers, all in flight together (per-element
+    // `if (k < nn)` branches made it serialise every gather behind an s_waitcnt vmcnt(0)); clamped
+    // duplicates hit the same cache line.  (Requesting block i+1's stream before block i's barriers was
+    // measured too: no gain — the kernel is HBM-bound — at +30 VGPRs, so it is not done.)
     for (; b < bend; b += bstep) {
-        const int bb = order ? order[b] : b;          // scheduled position -> row block
-        const uint32_t rb0 = (uint32_t)rowblk[bb];
-        const int ra = (int)(rb0 & ~VEC_FLAG);
-        const int rb = (int)((uint32_t)rowblk[bb + 1] & ~VEC_FLAG);
-        if (!(rb0 & VEC_FLAG)) {
+        const BlkDesc d = desc[order ? order[b] : b];
+        const int ra = d.ra, rb = d.rb & 0x7fffffff;
+        if (d.rb >= 0) {
             // ---------------- stream block: products to LDS, then one lane per row
-            const int pa = row_ptr[ra];
-            const int nn = row_ptr[rb] - pa;
-            int cidx[ITEMS];
-            T vv[ITEMS];
+            const int pa = d.pa, nn = d.nn;
+            // row extents and the dot operand for the reduce phase: requested now, used after the barrier
+            const int r = ra + tid;
+            const bool has_row = r < rb;
+            const int rcl = has_row ? r : rb - 1;
+            const int s = row_ptr[rcl] - pa, e = row_ptr[rcl + 1] - pa;
+            [[maybe_unused]] T uu;
+            if (DOT != 0) uu = u[rcl];
+            if (nn > 0) {
+                const int last = nn - 1;
+                int cidx[ITEMS];
+                T vv[ITEMS], xg[ITEMS];
 #pragma unroll
-            for (int i = 0; i < ITEMS; ++i) {
-                const int k = tid + i * BLOCK;
-                if (k < nn) { cidx[i] = ld_stream<NT>(col_idx + pa + k); vv[i] = ld_val<NT>(val + pa + k); }
-            }
+                for (int i = 0; i < ITEMS; ++i) {
+                    const int k = min(tid + i * BLOCK, last);
+                    cidx[i] = ld_stream<NT>(col_idx + pa + k);
+                    vv[i] = ld_val<NT>(val + pa + k);
+                }
 #pragma unroll
-            for (int i = 0; i < ITEMS; ++i) {
-                const int k = tid + i * BLOCK;
-                if (k < nn) prod[k] = smul(CONJX ? sconj(x[cidx[i]]) : x[cidx[i]], vv[i]);   // mat.rs:104  x[col] * val
+                for (int i = 0; i < ITEMS; ++i) xg[i] = x[cidx[i]];
+#pragma unroll
+                for (int i = 0; i < ITEMS; ++i) {
+                    const int k = tid + i * BLOCK;
+                    if (k < nn) prod[k] = smul(CONJX ? sconj(xg[i]) : xg[i], vv[i]);   // mat.rs:104  x[col] * val
+                }
             }
             __syncthreads();
-            const int r = ra + tid;
-            if (r < rb) {
-                const int s = row_ptr[r] - pa, e = row_ptr[r + 1] - pa;
+            if (has_row) {
                 T acc = szero<T>();                               // mat.rs:103  fold(T::zero(), ..)
-                for (int k = s; k < e; ++k) acc = sadd(acc, prod[k]);
+                const int len = e - s;
+                if (len <= 8) {
+                    // short rows (every stencil): fetch up to 8 products at once, add the valid ones in order
+                    T pv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pv[j] = prod[min(s + j, CAP - 1)];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j < len) acc = sadd(acc, pv[j]);
+                } else {
+                    for (int k = s; k < e; ++k) acc = sadd(acc, prod[k]);
+                }
                 y[r] = acc;
-                if (DOT == 1) d0 = sadd(d0, smul(sconj(u[r]), acc));
-                if (DOT == 2) { d0 = sadd(d0, smul(sconj(acc), acc)); d1 = sadd(d1, smul(sconj(acc), u[r])); }
+                if (DOT == 1) d0 = sadd(d0, smul(sconj(uu), acc));
+                if (DOT == 2) { d0 = sadd(d0, smul(sconj(acc), acc)); d1 = sadd(d1, smul(sconj(acc), uu)); }
             }
             __syncthreads();  // prod[] is rewritten by the next row block
         } else {
@@ -169,7 +216,6 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
         if (tid == 0) part1[blockIdx.x] = d1;
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Row-block schedule for matrices with far bands.
@@ -272,26 +318,28 @@ int build_schedule(sprs_csr *A, const std::vector<int32_t> &blk) {
 }
 
 // number of workgroups launch_spmv uses == number of partials it writes
-static inline int spmv_grid(const sprs_csr *A) {
-    int g = A->ctx->spmv_grid;
-    if (g < 8) g = 8;
-    if (g > MAX_GRID) g = MAX_GRID;
-    g &= ~7;
-    // at least one row block per workgroup, keep it a multiple of 8 (one slice per XCD)
-    int need = ((A->n_rowblk + 7) / 8) * 8;
-    if (need < 8) need = 8;
-    return g < need ? g : need;
+// Matrices whose whole stream fits the 256 MiB Infinity Cache behave differently from HBM-bound ones
+// (profiles/r01_tuning.md): they want one contiguous chunk of row blocks per XCD (x stays in that XCD's
+// L2); HBM-bound ones want the row blocks dealt round-robin over the XCDs.
+static inline bool is_cache_resident(const sprs_csr *A) {
+    const double s = A->is_complex ? 16.0 : 8.0;
+    return (double)A->nnz * (s + 4) + 3.0 * A->nrows * s < 192.0 * 1024 * 1024;
 }
-
-static inline int grid_for_blocks(const sprs_csr *A, int count) {
+static inline int base_grid(const sprs_csr *A) {
     int g = A->ctx->spmv_grid;
+    if (g <= 0) g = A->ctx->num_cu * 4;   // measured best for HBM-bound and cache-resident matrices alike (A/B on the full solve)
     if (g < 8) g = 8;
     if (g > MAX_GRID / 2) g = MAX_GRID / 2;
-    g &= ~7;
+    return g & ~7;
+}
+static inline int grid_for_blocks(const sprs_csr *A, int count) {
+    const int g = base_grid(A);
+    // at least one row block per workgroup, keep it a multiple of 8 (one slice per XCD)
     int need = ((count + 7) / 8) * 8;
     if (need < 8) need = 8;
     return g < need ? g : need;
 }
+static inline int spmv_grid(const sprs_csr *A) { return grid_for_blocks(A, A->n_rowblk); }
 int spmv_subset_grid(const sprs_csr *A, int count) { return grid_for_blocks(A, count); }
 
 template <class T>
@@ -299,15 +347,15 @@ static int launch_spmv_impl(const sprs_csr *A, const int32_t *order, int count, 
                             const T *u, T *part0, T *part1, const int *status, bool conj_x) {
     sprs_ctx *c = A->ctx;
     const T *v = reinterpret_cast<const T *>(A->val);
-    const bool cache_resident = (double)A->nnz * (sizeof(T) + 4) + 3.0 * A->nrows * sizeof(T) < 192.0 * 1024 * 1024;
+    const bool cache_resident = is_cache_resident(A);
     // a scheduled matrix wants each XCD on its own contiguous run of the schedule (that is what makes
     // the far-band x entries hit in that XCD's L2) and the read-once stream kept out of L2
     const bool sched = A->blk_order != nullptr;
     const int xcd_chunk = c->xcd_chunk < 0 ? ((cache_resident || sched) ? 1 : 0) : c->xcd_chunk;
-    const bool nt = c->spmv_nt < 0 ? (cache_resident || sched) : (c->spmv_nt != 0);
+    const bool nt = c->spmv_nt > 0;   // measured: non-temporal stream loads never pay once the loads are batched
 #define SPRS_SPMV2(D, CJ, NTF)                                                                                        \
     hipLaunchKernelGGL((spmv_kernel<T, D, CJ, NTF>), dim3(g), dim3(BLOCK), 0, c->stream, count,                       \
-                       xcd_chunk, A->rowblk, order, A->row_ptr, A->col_idx, v, x, y, u, part0, part1, status)
+                       xcd_chunk, reinterpret_cast<const BlkDesc *>(A->blk_desc), order, A->row_ptr, A->col_idx, v, x, y, u, part0, part1, status)
 #define SPRS_SPMV(D, CJ) do { if (nt) SPRS_SPMV2(D, CJ, true); else SPRS_SPMV2(D, CJ, false); } while (0)
     if (conj_x && is_complex<T>::value) {  // only CSMINRES on complex data needs the conjugated gather
         if (dot_mode == 0) SPRS_SPMV(0, true);

@@ -105,6 +105,16 @@ def is_device_array(a):
     return hasattr(a, "data_ptr") and getattr(a, "is_cuda", False)
 
 
+def pre_sync(*arrays):
+    """torch tensors are produced on torch's stream while the library runs on its own: make sure
+    pending torch work on them has finished before the library touches them."""
+    for a in arrays:
+        if a is not None and type(a).__module__.split(".")[0] == "torch":
+            import torch
+            torch.cuda.current_stream(a.device).synchronize()
+            return
+
+
 def dev_ptr(a):
     if isinstance(a, DevVec):
         return a.ptr

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib, partition
-from .device import dev_ptr, dev_sfx
+from .device import dev_ptr, dev_sfx, pre_sync
 from .error import check
 from .mat import HipCsr
 
@@ -28,6 +28,7 @@ class Comm:
         self.h, self.ctx, self.rank, self.world = h, ctx, rank, world
 
     def allreduce_sum(self, dev, count):
+        pre_sync(dev)
         check(_lib.lib().sprs_comm_allreduce_sum_f64(self.h, dev_ptr(dev), int(count)), self.ctx.h)
 
     def close(self):
@@ -67,6 +68,7 @@ class DistCsr(HipCsr):
 
     def mul_vec_ext(self, x_ext, y_local):
         """y_local = A_local * x after the halo exchange; x_ext has n_ext entries, owned slice first."""
+        pre_sync(x_ext, y_local)
         st = getattr(_lib.lib(), "sprs_dist_mul_vec_dev_" + ("z" if self.dtype == np.complex128 else "d"))(
             self.h, dev_ptr(x_ext), dev_ptr(y_local))
         check(st, self.ctx.h)

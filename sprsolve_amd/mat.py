@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .device import DevVec, default_ctx, dev_len, dev_ptr, dev_sfx, is_device_array, sfx
+from .device import DevVec, default_ctx, dev_len, dev_ptr, dev_sfx, is_device_array, pre_sync, sfx
 from .error import check
 
 
@@ -126,13 +126,16 @@ class HipCsr(MatVecMul):
         return out.value if s == "d" else out.py()
 
     def mul_vec_unchecked(self, v_in, v_out):
-        """mat.rs:68-143 on device vectors (no dimension check, nothing crosses PCIe)."""
+        """mat.rs:68-143 on device vectors (no dimension check, nothing crosses PCIe).  Blocking."""
+        pre_sync(v_in, v_out)
         st = getattr(_lib.lib(), "sprs_mul_vec_dev_" + self._s())(self.h, dev_ptr(v_in), dev_ptr(v_out))
         check(st, self.ctx.h)
+        self.ctx.sync()
 
     def mul_vec_dot_unchecked(self, v_in, v_out):
         """mat.rs:145-152 on device vectors."""
         s = self._s()
+        pre_sync(v_in, v_out)
         out = C.c_double() if s == "d" else _lib.c64()
         st = getattr(_lib.lib(), "sprs_mul_vec_dot_dev_" + s)(self.h, dev_ptr(v_in), dev_ptr(v_out), C.byref(out))
         check(st, self.ctx.h)
@@ -140,6 +143,7 @@ class HipCsr(MatVecMul):
 
     def time_mul_vec(self, v_in, v_out, reps=20):
         """Mean device milliseconds of one SpMV launch (HIP events on the library's stream)."""
+        pre_sync(v_in, v_out)
         ms = C.c_double()
         st = getattr(_lib.lib(), "sprs_mul_vec_dev_timed_" + self._s())(self.h, dev_ptr(v_in), dev_ptr(v_out), int(reps),
                                                                        C.byref(ms))

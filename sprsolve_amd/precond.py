@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .device import default_ctx, dev_len, dev_ptr, is_device_array
+from .device import default_ctx, dev_len, dev_ptr, is_device_array, pre_sync
 from .error import check
 from .mat import MatVecMul
 
@@ -49,6 +49,7 @@ class DiagPrecond(MatVecMul):
 
     def mul_vec_unchecked(self, v_in, v_out):
         """precond.rs:48-52 on device vectors."""
+        pre_sync(v_in, v_out)
         check(getattr(_lib.lib(), "sprs_diag_mul_vec_dev_" + self._s())(self.h, dev_ptr(v_in), dev_ptr(v_out)), self.ctx.h)
         self.ctx.sync()
 

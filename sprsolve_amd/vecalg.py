@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .device import DevVec, default_ctx, dev_len, dev_ptr, dev_sfx, is_device_array
+from .device import DevVec, default_ctx, dev_len, dev_ptr, dev_sfx, is_device_array, pre_sync
 from .error import check
 
 
@@ -22,6 +22,7 @@ class _Staged:
 
     def __enter__(self):
         if is_device_array(self.a):
+            pre_sync(self.a)
             return self.a
         if not isinstance(self.a, np.ndarray):
             self.a = np.asarray(self.a)
