@@ -23,7 +23,7 @@ y = torch.empty_like(x)
 yref = None
 B = nnz * 12 + (n + 1) * 4 + 2 * n * 8
 mats = {}
-for strip in (0,):
+for strip in (0, 1):
     ctx.set("spmv_strip", strip)
     mats[strip] = sa.HipCsr.from_device((n, n), nnz, ip, ix, dv, adopt=True, ctx=ctx)
     mats[strip].mul_vec_unchecked(x, y)
@@ -32,9 +32,9 @@ for strip in (0,):
     assert torch.equal(y, yref), "schedule changed the result"
 for rnd in range(2):
     for strip, A in mats.items():
-        for grid in (768, 1024, 1280, 2048):
-            for chunk in (0, 1):
-                for nt in (0,):
+        for grid in (1024,):
+            for chunk in (-1,):
+                for nt in (0, 1):
                     ctx.set("spmv_grid", grid); ctx.set("xcd_chunk", chunk); ctx.set("spmv_nt", nt)
                     A.time_mul_vec(x, y, reps=3)
                     ms = A.time_mul_vec(x, y, reps=20)

@@ -216,6 +216,9 @@ int dist_csr_create(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz
         std::vector<int32_t> oi, ob;
         for (int b = 0; b < A->n_rowblk; ++b) (hi[b] >= n_local ? ob : oi).push_back(b);
         if (!oi.empty() && !ob.empty() && ob.size() * 2 <= (size_t)A->n_rowblk) {
+            // keep the XCD-period placement of the local operator for the (large) interior launch
+            if (A->blk_order && !A->sched_strip_major && A->sched_period > 0 && !A->blk_row_start.empty())
+                oi = place_on_xcds(oi, A->blk_row_start, A->sched_period);
             bool ok = hipMalloc((void **)&D->order_int, sizeof(int32_t) * oi.size()) == hipSuccess &&
                       hipMalloc((void **)&D->order_bnd, sizeof(int32_t) * ob.size()) == hipSuccess &&
                       hipMemcpy(D->order_int, oi.data(), sizeof(int32_t) * oi.size(), hipMemcpyHostToDevice) == hipSuccess &&

@@ -32,9 +32,11 @@ struct sprs_ctx {
     // with plain loads (all XCDs sweep the same region, x re-reads are served by the Infinity Cache).
     int xcd_chunk = -1;
     int spmv_nt = -1;
-    // SpMV row-block schedule for matrices with far bands (3-D stencils): rows per strip; 0 = natural
-    // order (default: the strip-major walk measured SLOWER on MI355X, profiles/r01_tuning.md), -1 = auto.
-    // Read at handle creation.
+    // SpMV row-block schedule for matrices with far bands (3-D stencils), read at handle creation:
+    // 0 = natural order, round-robin over the XCDs (default: fastest in every measurement on MI355X);
+    // 1 = XCD-period placement (rows r and r +- P on the same XCD; cuts the L2->fabric x traffic from
+    // ~5.5 reads to ~1 but was 2 % SLOWER), >= 2 = strip-major walk with that many rows per strip
+    // (5-10 % slower).  Both kept as experiments — see profiles/r01_tuning.md.
     int spmv_strip = 0;
     int halo_overlap = 1;  // distributed SpMV: run the halo-free rows while the halo travels
     int poll = 16;       // iterations between host polls of the device status word
@@ -98,6 +100,8 @@ struct sprs_csr {
     void *blk_desc = nullptr;      // device: one 16-byte {ra, rb|flag, pa, nn} descriptor per row block
     int32_t *blk_order = nullptr;  // device: schedule of the row blocks (n_rowblk entries) or null = natural order
     int64_t sched_period = 0;      // rows between the far bands the schedule folds over (0 = no schedule)
+    bool sched_strip_major = false;
+    std::vector<int64_t> blk_row_start;   // host copy of the row-block starts (kept when a schedule exists)
     // scratch for the host-slice trait entry points (lazily allocated)
     void *x_tmp = nullptr, *y_tmp = nullptr;
     double *part = nullptr;      // partials for mul_vec_dot
@@ -126,6 +130,7 @@ int build_rowblocks(sprs_csr *A, const int32_t *host_row_ptr);
 int spmv_num_partials(const sprs_csr *A);  // workgroups launch_spmv uses == partials it writes
 // per-row-block column span (device kernel + D2H): lo/hi sized n_rowblk
 int rowblk_spans(const sprs_csr *A, std::vector<int32_t> &lo, std::vector<int32_t> &hi);
+std::vector<int32_t> place_on_xcds(const std::vector<int32_t> &blocks, const std::vector<int64_t> &row_start, int64_t P);
 // SpMV over a subset of the row blocks (order[0..count)); writes `subset_grid(count)` partials
 template <class T>
 int launch_spmv_subset(const sprs_csr *A, const int32_t *order, int count, const T *x, T *y, int dot_mode, const T *u,

@@ -81,6 +81,15 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
     return build_schedule(A, blk);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
+// global load and store (s_waitcnt vmcnt(0)), which would serialise the HBM stream behind each barrier;
+// here only this wave's LDS operations are waited for, global memory operations stay in flight.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // streaming (read-once) loads: keep the matrix stream from evicting the gathered x lines
 template <bool NT, class U>
 __device__ __forceinline__ U ld_stream(const U *p) {
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
                     if (k < nn) prod[k] = smul(CONJX ? sconj(xg[i]) : xg[i], vv[i]);   // mat.rs:104  x[col] * val
                 }
             }
-            __syncthreads();
+            lds_barrier();
             if (has_row) {
                 T acc = szero<T>();                               // mat.rs:103  fold(T::zero(), ..)
                 const int len = e - s;
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
                 if (DOT == 1) d0 = sadd(d0, smul(sconj(uu), acc));
                 if (DOT == 2) { d0 = sadd(d0, smul(sconj(acc), acc)); d1 = sadd(d1, smul(sconj(acc), uu)); }
             }
-            __syncthreads();  // prod[] is rewritten by the next row block
+            lds_barrier();  // prod[] is rewritten by the next row block
         } else {
             // ---------------- vector block: one wavefront per (long) row
             const int lane = tid & (WAVE - 1);
@@ -274,6 +283,28 @@ int rowblk_spans(const sprs_csr *A, std::vector<int32_t> &lo, std::vector<int32_
     return SPRS_OK;
 }
 
+// Interleave `blocks` (row-block ids, ascending) so that schedule position j — which the persistent walk
+// gives to a workgroup on XCD j mod 8 — holds a block of row group (row_start / (P/8)) mod 8 == j mod 8.
+std::vector<int32_t> place_on_xcds(const std::vector<int32_t> &blocks, const std::vector<int64_t> &row_start, int64_t P) {
+    const int64_t G = std::max<int64_t>(P / 8, 1);
+    std::vector<std::vector<int32_t>> q(8);
+    for (int32_t b : blocks) q[(size_t)((row_start[(size_t)b] / G) % 8)].push_back(b);
+    std::vector<int32_t> order(blocks.size());
+    size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0}, filled = 0;
+    while (filled < blocks.size()) {
+        for (int x = 0; x < 8 && filled < blocks.size(); ++x) {
+            int src = x;
+            if (pos[src] >= q[src].size()) {          // this XCD's queue ran dry: take from the longest one
+                size_t best = 0;
+                for (int y = 0; y < 8; ++y)
+                    if (q[y].size() - pos[y] > best) { best = q[y].size() - pos[y]; src = y; }
+            }
+            order[filled++] = q[src][pos[src]++];
+        }
+    }
+    return order;
+}
+
 int build_schedule(sprs_csr *A, const std::vector<int32_t> &blk) {
     sprs_ctx *c = A->ctx;
     const int nb = A->n_rowblk;
@@ -293,27 +324,41 @@ int build_schedule(sprs_csr *A, const std::vector<int32_t> &blk) {
     std::nth_element(reach.begin(), reach.begin() + reach.size() / 2, reach.end());
     const int64_t P = reach[reach.size() / 2];
     const size_t sT = A->is_complex ? 16 : 8;
-    // worth it only when the far bands are farther apart than an XCD's L2 can bridge, and the
-    // matrix has at least a few periods
-    if (strip < 0) {
-        if ((double)P * sT * 2 < 3.0 * 1024 * 1024 || P * 4 > A->nrows) return SPRS_OK;
-        strip = 8192;
-    }
-    if (P < 2 * (int64_t)strip) return SPRS_OK;
-    std::vector<std::pair<uint64_t, int32_t>> key(nb);
-    const uint64_t nper = (uint64_t)(A->nrows / P + 2);
-    for (int b = 0; b < nb; ++b) {
-        const uint64_t r = (uint64_t)((uint32_t)blk[b] & ~VEC_FLAG);
-        const uint64_t k = r / (uint64_t)P, o = r % (uint64_t)P;
-        key[b] = {((o / (uint64_t)strip) * nper + k) * (uint64_t)strip + (o % (uint64_t)strip), b};
-    }
-    std::sort(key.begin(), key.end());
     std::vector<int32_t> order(nb);
-    for (int b = 0; b < nb; ++b) order[b] = key[b].second;
+    if (strip == -1 || strip == 1) {
+        // ---- XCD-period placement (experimental).
+        // Workgroup w runs on XCD w mod 8 (observed round-robin dispatch; a locality hint only) and, in the
+        // persistent walk, processes schedule positions w, w + grid, ...; so position j belongs to XCD j mod 8.
+        // Rows are cut into groups of P/8 rows and group g is given to XCD g mod 8: rows r and r +- P then
+        // live on the SAME XCD, one group apart in that XCD's own sequence, so the far-band x entries a group
+        // gathers are exactly the lines its XCD fetched for the previous group / will reuse for the next one.
+        // x then crosses the fabric about once instead of ~5.5 times, while all XCDs still sweep the matrix
+        // front to back together (the (col_idx, val) stream stays 8 contiguous runs).
+        if ((double)P * sT < 256.0 * 1024 || P * 3 > A->nrows) return SPRS_OK;   // no far band worth placing
+        std::vector<int32_t> all(nb);
+        for (int b = 0; b < nb; ++b) all[b] = b;
+        std::vector<int64_t> rs(nb);
+        for (int b = 0; b < nb; ++b) rs[b] = (int64_t)((uint32_t)blk[b] & ~VEC_FLAG);
+        A->blk_row_start = rs;
+        order = place_on_xcds(all, rs, P);
+    } else {
+        // ---- strip-major walk (experimental, measured slower: profiles/r01_tuning.md)
+        if (P < 2 * (int64_t)strip) return SPRS_OK;
+        std::vector<std::pair<uint64_t, int32_t>> key(nb);
+        const uint64_t nper = (uint64_t)(A->nrows / P + 2);
+        for (int b = 0; b < nb; ++b) {
+            const uint64_t r = (uint64_t)((uint32_t)blk[b] & ~VEC_FLAG);
+            const uint64_t k = r / (uint64_t)P, o = r % (uint64_t)P;
+            key[b] = {((o / (uint64_t)strip) * nper + k) * (uint64_t)strip + (o % (uint64_t)strip), b};
+        }
+        std::sort(key.begin(), key.end());
+        for (int b = 0; b < nb; ++b) order[b] = key[b].second;
+    }
     SPRS_HIP_TRY(c, hipMalloc((void **)&A->blk_order, sizeof(int32_t) * nb));
     SPRS_HIP_TRY(c, hipMemcpyAsync(A->blk_order, order.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, c->stream));
     SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     A->sched_period = P;
+    A->sched_strip_major = !(strip == -1 || strip == 1);
     return SPRS_OK;
 }
 
@@ -350,8 +395,9 @@ static int launch_spmv_impl(const sprs_csr *A, const int32_t *order, int count, 
     const bool cache_resident = is_cache_resident(A);
     // a scheduled matrix wants each XCD on its own contiguous run of the schedule (that is what makes
     // the far-band x entries hit in that XCD's L2) and the read-once stream kept out of L2
+    // (the XCD-period schedule encodes its placement in the order array and needs the round-robin walk)
     const bool sched = A->blk_order != nullptr;
-    const int xcd_chunk = c->xcd_chunk < 0 ? ((cache_resident || sched) ? 1 : 0) : c->xcd_chunk;
+    const int xcd_chunk = sched ? (A->sched_strip_major ? 1 : 0) : (c->xcd_chunk < 0 ? (cache_resident ? 1 : 0) : c->xcd_chunk);
     const bool nt = c->spmv_nt > 0;   // measured: non-temporal stream loads never pay once the loads are batched
 #define SPRS_SPMV2(D, CJ, NTF)                                                                                        \
     hipLaunchKernelGGL((spmv_kernel<T, D, CJ, NTF>), dim3(g), dim3(BLOCK), 0, c->stream, count,                       \
