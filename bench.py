@@ -186,6 +186,14 @@ def main():
         its, res = s.precond_solve(P, rhs, x, 20000, 1e-8)
         g = torch.arange(n, device=dev)
         err = float((x - (g // R + g % R).to(torch.float64)).abs().max().item())
+        # PCIe-inclusive rate of the literal reference signature (host slices in, host slice out): never `value`
+        rhs_h = rhs.cpu().numpy(); x_h = np.zeros(n)
+        t0 = time.perf_counter()
+        try:
+            s.precond_solve(P, rhs_h, x_h, steps, 0.0)
+        except sa.error.InsufficientIterNum:
+            pass
+        pcie_dt = time.perf_counter() - t0
         bs = spmv_bytes(n, nnz, 8)
         # stand-alone SpMV timing (back-to-back launches, HIP events on the library's stream)
         y = torch.empty_like(x)
@@ -193,6 +201,7 @@ def main():
         t_spmv = prof["spmv_ms_total"] / max(prof["spmv_launches"], 1) * 1e-3
         return dict(workload="cfg2: 1000x1000 2-D 5-point Poisson (Dirichlet rows), n=1e6, nnz=4984016, BiCGStab + Jacobi",
                     value=steps / dt, ms_per_step=dt / steps * 1e3, n=n, nnz=nnz,
+                    pcie_inclusive_it_s=steps / pcie_dt,
                     spmv_us_in_solve=t_spmv * 1e6, spmv_us_back_to_back=ms_alone * 1e3,
                     spmv_GBs_in_solve=bs / t_spmv / 1e9, spmv_GBs_back_to_back=bs / (ms_alone * 1e-3) / 1e9,
                     spmv_bytes=bs, iter_bytes_reference_oplist=2 * bs + 26 * n * 8 + 2 * n * 24,
