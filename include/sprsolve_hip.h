@@ -10,7 +10,8 @@
  * across this boundary.  The reference-side binding is shown in INTEGRATION.md.
  *
  * Suffix convention:  _d = f64,  _z = Complex<f64> (layout {re, im} = num_complex::Complex<f64>
- * repr(C) = double2),  _zd = complex vector with a real scalar/diagonal.
+ * repr(C) = double2),  _zd = complex vector with a real scalar/diagonal;  _s / _c / _cs are the same
+ * for f32 / Complex<f32> (declared in one block further down).
  * "host" pointers are ordinary CPU memory; "dev" pointers are HIP device memory on the
  * context's GPU.  All calls are blocking from the caller's view unless stated otherwise.
  */
@@ -24,7 +25,8 @@
 extern "C" {
 #endif
 
-typedef struct { double re, im; } sprs_c64;
+typedef struct { double re, im; } sprs_c64;   /* Complex<f64> */
+typedef struct { float re, im; } sprs_c32;    /* Complex<f32> */
 
 /* Status codes. 1..5 map 1:1 onto reference src/error.rs:7-22 `SolverError`; 6 is the
  * `panic!("Dimension mismatch")` of src/mat.rs:50-52,58-60 and src/precond.rs:39-41. */
@@ -48,6 +50,7 @@ typedef struct sprs_diag sprs_diag;         /* DiagPrecond<T,V>              (pr
 typedef struct sprs_bicgstab sprs_bicgstab; /* BiCGStab<T,M>                 (bicg_stab.rs:17-31) */
 typedef struct sprs_minres sprs_minres;     /* MinRes<T,M>                   (minres.rs:13-27)    */
 typedef struct sprs_csminres sprs_csminres; /* CSMinRes<T,M>                 (cs_minres.rs:11-25) */
+typedef struct sprs_comm sprs_comm;         /* RCCL communicator of this rank (multi-GPU section)  */
 
 /* ---------------------------------------------------------------- context */
 /* device: HIP device ordinal.  stream: an existing hipStream_t to run on (e.g. the caller's
@@ -198,6 +201,78 @@ int sprs_csminres_solve_dev_z(sprs_csminres *S, const sprs_c64 *rhs_dev, size_t 
 int sprs_csminres_solve_dev_d(sprs_csminres *S, const double *rhs_dev, size_t rhs_len, double *x_dev, size_t x_len,
                               size_t max_iter, double tol, size_t *its_out, double *res_out);
 
+/* ---------------------------------------------------------------- f32 / Complex<f32>
+ * The reference is generic over cauchy::Scalar = {f32, f64, c32, c64} and its unit tests exercise f32 / c32
+ * BLAS-1 (src/vecalg.rs:647-658,669-677,771-798,816-830).  Every typed entry point above exists again with
+ * suffix _s (f32), _c (Complex<f32> = sprs_c32) and _cs (complex vector, real scalar/diagonal); T::Real
+ * quantities (tol, residual, norm2, rscale factor) are float. */
+int sprs_csr_create_s(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *row_ptr, const int32_t *col_idx, const float *val, int storage_csc, sprs_csr **out);
+int sprs_csr_create_c(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *row_ptr, const int32_t *col_idx, const sprs_c32 *val, int storage_csc, sprs_csr **out);
+int sprs_csr_create_i64_s(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t *row_ptr, const int64_t *col_idx, const float *val, int storage_csc, sprs_csr **out);
+int sprs_csr_create_i64_c(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t *row_ptr, const int64_t *col_idx, const sprs_c32 *val, int storage_csc, sprs_csr **out);
+int sprs_csr_create_dev_s(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *dev_row_ptr, const int32_t *dev_col_idx, const float *dev_val, int adopt, sprs_csr **out);
+int sprs_csr_create_dev_c(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *dev_row_ptr, const int32_t *dev_col_idx, const sprs_c32 *dev_val, int adopt, sprs_csr **out);
+int sprs_mul_vec_s(const sprs_csr *A, const float *x_host, size_t x_len, float *y_host, size_t y_len);
+int sprs_mul_vec_c(const sprs_csr *A, const sprs_c32 *x_host, size_t x_len, sprs_c32 *y_host, size_t y_len);
+int sprs_mul_vec_dot_s(const sprs_csr *A, const float *x_host, size_t x_len, float *y_host, size_t y_len, float *dot_out);
+int sprs_mul_vec_dot_c(const sprs_csr *A, const sprs_c32 *x_host, size_t x_len, sprs_c32 *y_host, size_t y_len, sprs_c32 *dot_out);
+int sprs_mul_vec_dev_s(const sprs_csr *A, const float *x_dev, float *y_dev);
+int sprs_mul_vec_dev_c(const sprs_csr *A, const sprs_c32 *x_dev, sprs_c32 *y_dev);
+int sprs_mul_vec_dot_dev_s(const sprs_csr *A, const float *x_dev, float *y_dev, float *dot_out);
+int sprs_mul_vec_dot_dev_c(const sprs_csr *A, const sprs_c32 *x_dev, sprs_c32 *y_dev, sprs_c32 *dot_out);
+int sprs_mul_vec_dev_timed_s(const sprs_csr *A, const float *x_dev, float *y_dev, int reps, double *ms_per_launch);
+int sprs_mul_vec_dev_timed_c(const sprs_csr *A, const sprs_c32 *x_dev, sprs_c32 *y_dev, int reps, double *ms_per_launch);
+int sprs_dot_s(sprs_ctx *ctx, size_t n, const float *x, const float *y, float *out);
+int sprs_dot_c(sprs_ctx *ctx, size_t n, const sprs_c32 *x, const sprs_c32 *y, sprs_c32 *out);
+int sprs_conj_dot_s(sprs_ctx *ctx, size_t n, const float *x, const float *y, float *out);
+int sprs_conj_dot_c(sprs_ctx *ctx, size_t n, const sprs_c32 *x, const sprs_c32 *y, sprs_c32 *out);
+int sprs_norm2_s(sprs_ctx *ctx, size_t n, const float *x, float *out);
+int sprs_norm2_c(sprs_ctx *ctx, size_t n, const sprs_c32 *x, float *out);
+int sprs_scale_s(sprs_ctx *ctx, size_t n, float a, float *x);
+int sprs_scale_c(sprs_ctx *ctx, size_t n, sprs_c32 a, sprs_c32 *x);
+int sprs_rscale_s(sprs_ctx *ctx, size_t n, float a, float *x);
+int sprs_rscale_c(sprs_ctx *ctx, size_t n, float a, sprs_c32 *x);
+int sprs_conj_s(sprs_ctx *ctx, size_t n, const float *in, float *out);
+int sprs_conj_c(sprs_ctx *ctx, size_t n, const sprs_c32 *in, sprs_c32 *out);
+int sprs_axpy_s(sprs_ctx *ctx, size_t n, float a, const float *x, float *y);
+int sprs_axpy_c(sprs_ctx *ctx, size_t n, sprs_c32 a, const sprs_c32 *x, sprs_c32 *y);
+int sprs_axpy_cs(sprs_ctx *ctx, size_t n, float a, const sprs_c32 *x, sprs_c32 *y);
+int sprs_axpby_s(sprs_ctx *ctx, size_t n, float a, const float *x, float b, float *y);
+int sprs_axpby_c(sprs_ctx *ctx, size_t n, sprs_c32 a, const sprs_c32 *x, sprs_c32 b, sprs_c32 *y);
+int sprs_diag_precond_create_s(sprs_ctx *ctx, size_t n, const float *diag_host, sprs_diag **out);
+int sprs_diag_precond_create_cs(sprs_ctx *ctx, size_t n, const float *diag_host, sprs_diag **out);
+int sprs_diag_precond_create_c(sprs_ctx *ctx, size_t n, const sprs_c32 *diag_host, sprs_diag **out);
+int sprs_diag_mul_vec_s(const sprs_diag *P, const float *in_host, size_t in_len, float *out_host, size_t out_len);
+int sprs_diag_mul_vec_c(const sprs_diag *P, const sprs_c32 *in_host, size_t in_len, sprs_c32 *out_host, size_t out_len);
+int sprs_diag_mul_vec_dev_s(const sprs_diag *P, const float *in_dev, float *out_dev);
+int sprs_diag_mul_vec_dev_c(const sprs_diag *P, const sprs_c32 *in_dev, sprs_c32 *out_dev);
+int sprs_bicgstab_create_s(const sprs_csr *A, size_t size, sprs_bicgstab **out);
+int sprs_bicgstab_create_c(const sprs_csr *A, size_t size, sprs_bicgstab **out);
+int sprs_bicgstab_solve_s(sprs_bicgstab *S, const float *rhs, size_t rhs_len, float *x, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_bicgstab_solve_c(sprs_bicgstab *S, const sprs_c32 *rhs, size_t rhs_len, sprs_c32 *x, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_bicgstab_precond_solve_s(sprs_bicgstab *S, const sprs_diag *P, const float *rhs, size_t rhs_len, float *x, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_bicgstab_precond_solve_c(sprs_bicgstab *S, const sprs_diag *P, const sprs_c32 *rhs, size_t rhs_len, sprs_c32 *x, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_bicgstab_solve_dev_s(sprs_bicgstab *S, const sprs_diag *P_or_null, const float *rhs_dev, size_t rhs_len, float *x_dev, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_bicgstab_solve_dev_c(sprs_bicgstab *S, const sprs_diag *P_or_null, const sprs_c32 *rhs_dev, size_t rhs_len, sprs_c32 *x_dev, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_minres_create_s(const sprs_csr *A, size_t size, sprs_minres **out);
+int sprs_minres_create_c(const sprs_csr *A, size_t size, sprs_minres **out);
+int sprs_minres_solve_s(sprs_minres *S, const float *rhs, size_t rhs_len, float *x, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_minres_solve_c(sprs_minres *S, const sprs_c32 *rhs, size_t rhs_len, sprs_c32 *x, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_minres_precond_solve_s(sprs_minres *S, const sprs_diag *P, const float *rhs, size_t rhs_len, float *x, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_minres_precond_solve_c(sprs_minres *S, const sprs_diag *P, const sprs_c32 *rhs, size_t rhs_len, sprs_c32 *x, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_minres_solve_dev_s(sprs_minres *S, const sprs_diag *P_or_null, const float *rhs_dev, size_t rhs_len, float *x_dev, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_minres_solve_dev_c(sprs_minres *S, const sprs_diag *P_or_null, const sprs_c32 *rhs_dev, size_t rhs_len, sprs_c32 *x_dev, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_csminres_create_c(const sprs_csr *A, size_t size, sprs_csminres **out);
+int sprs_csminres_create_s(const sprs_csr *A, size_t size, sprs_csminres **out);
+int sprs_csminres_solve_c(sprs_csminres *S, const sprs_c32 *rhs, size_t rhs_len, sprs_c32 *x, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_csminres_solve_s(sprs_csminres *S, const float *rhs, size_t rhs_len, float *x, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_csminres_solve_dev_c(sprs_csminres *S, const sprs_c32 *rhs_dev, size_t rhs_len, sprs_c32 *x_dev, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_csminres_solve_dev_s(sprs_csminres *S, const float *rhs_dev, size_t rhs_len, float *x_dev, size_t x_len, size_t max_iter, float tol, size_t *its_out, float *res_out);
+int sprs_dist_csr_create_dev_s(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz, const int32_t *dev_row_ptr, const int32_t *dev_col_idx_ext, const float *dev_val, int adopt, int n_peers, const int32_t *peer_rank, const int64_t *send_off, const int32_t *send_idx_dev, const int64_t *recv_off, sprs_csr **out);
+int sprs_dist_csr_create_dev_c(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz, const int32_t *dev_row_ptr, const int32_t *dev_col_idx_ext, const sprs_c32 *dev_val, int adopt, int n_peers, const int32_t *peer_rank, const int64_t *send_off, const int32_t *send_idx_dev, const int64_t *recv_off, sprs_csr **out);
+int sprs_dist_mul_vec_dev_s(const sprs_csr *A, float *x_ext_dev, float *y_local_dev);
+int sprs_dist_mul_vec_dev_c(const sprs_csr *A, sprs_c32 *x_ext_dev, sprs_c32 *y_local_dev);
+
 /* ---------------------------------------------------------------- multi-GPU (one process per GPU)
  * No reference analogue: the reference is single-process (rayon).  The matrix is row-partitioned;
  * rank r owns rows [r0, r1) and the matching slices of every vector.  A distributed operator is the
@@ -207,7 +282,6 @@ int sprs_csminres_solve_dev_d(sprs_csminres *S, const double *rhs_dev, size_t rh
  * the halo exchange (RCCL send/recv with the owning peers over xGMI), every dot product / norm is
  * followed by an RCCL all-reduce, and rhs / x are the rank's slices.  sprsolve_amd/partition.py
  * derives the exchange plan from global column indices. */
-typedef struct sprs_comm sprs_comm;
 int sprs_comm_unique_id(void *id128_out);  /* rank 0: 128-byte RCCL id to broadcast to the other ranks */
 int sprs_comm_create(sprs_ctx *ctx, int world, int rank, const void *id128, sprs_comm **out); /* collective */
 int sprs_comm_destroy(sprs_comm *comm);

@@ -1,11 +1,11 @@
 /* TEST INFRASTRUCTURE ONLY — CPU oracle, template body.
  *
- * Included twice by sprs_oracle.c:  SFX=d (T=double)  and  SFX=z (T=orc_c64).
+ * Included twice by sprs_oracle.c:  SFX=d (T=R)  and  SFX=z (T=orc_c64).
  * A statement-for-statement restatement of the reference's hot path; every function cites
  * the reference file:line it follows (paths relative to the reference root).  Sums are
  * strict left folds, no fma (compile with -ffp-contract=off).
  *
- * Index type is int64 (the reference's sprs::CsMat<T> uses usize, mat.rs:199).
+ * R = T::Real (double or float).  Index type is int64 (the reference's sprs::CsMat<T> uses usize, mat.rs:199).
  */
 
 #define FN(name) ORC_CAT3(orc_, name, SFX_US)
@@ -48,15 +48,15 @@ void FN(scale)(int64_t n, T a, T *v) {
 }
 
 /* vecalg.rs:596-599  rscale_fallback: v = v.mul_real(a) */
-void FN(rscale)(int64_t n, double a, T *v) {
+void FN(rscale)(int64_t n, R a, T *v) {
     for (int64_t i = 0; i < n; ++i) v[i] = S(mulr)(v[i], a);
 }
 
-/* vecalg.rs:601-605  norm2_fallback: sqrt(fold(0, acc + x.square())), unscaled */
-double FN(norm2)(int64_t n, const T *v) {
-    double acc = 0.0;
+/* vecalg.rs:601-605  norm2_fallback: R_SQRT(fold(0, acc + x.square())), unscaled */
+R FN(norm2)(int64_t n, const T *v) {
+    R acc = 0.0;
     for (int64_t i = 0; i < n; ++i) acc = acc + S(sq)(v[i]);
-    return sqrt(acc);
+    return R_SQRT(acc);
 }
 
 /* ------------------------------------------------------------------ mat.rs:68-152 */
@@ -120,21 +120,21 @@ T FN(spmv_csr_dot)(int64_t nrows, const int64_t *indptr, const int64_t *indices,
 /* ------------------------------------------------------------------ precond.rs:20-52 */
 
 /* precond.rs:20-29 DiagPrecond::new: diag_inv = V::one() / v  (V real) */
-void FN(diag_inv_real)(int64_t n, const double *diag, double *dinv) {
-    for (int64_t i = 0; i < n; ++i) dinv[i] = 1.0 / diag[i];
+void FN(diag_inv_real)(int64_t n, const R *diag, R *dinv) {
+    for (int64_t i = 0; i < n; ++i) dinv[i] = (R)1 / diag[i];
 }
 /* precond.rs:48-52 apply: out = in * diag_inv   (T: Mul<V>; V real => mul_real) */
 static void FN(pc_apply)(int64_t n, const void *dinv, int dinv_complex, const T *in, T *out) {
 #if SFX_IS_COMPLEX
     if (dinv_complex) {
-        const orc_c64 *d = (const orc_c64 *)dinv;
-        for (int64_t i = 0; i < n; ++i) out[i] = z_mul(in[i], d[i]);
+        const CT *d = (const CT *)dinv;
+        for (int64_t i = 0; i < n; ++i) out[i] = ORC_CAT2(CSP, mul)(in[i], d[i]);
         return;
     }
 #else
     (void)dinv_complex;
 #endif
-    const double *d = (const double *)dinv;
+    const R *d = (const R *)dinv;
     for (int64_t i = 0; i < n; ++i) out[i] = S(mulr)(in[i], d[i]);
 }
 void FN(diag_apply)(int64_t n, const void *dinv, int dinv_complex, const T *in, T *out) {
@@ -157,8 +157,8 @@ static void FN(trace8)(double *trace, int64_t cap, int64_t *cnt, double a0, doub
  * work: 7*n scalars (bicg_stab.rs:28).  trace rows: [its, r_norm, rho, alpha, w]. */
 int FN(bicgstab)(int64_t size, const int64_t *indptr, const int64_t *indices, const T *data,
                  int parallel, const void *pc, int pc_complex, const T *rhs, int64_t rhs_len, T *x,
-                 int64_t x_len, int64_t max_iter, double tol, T *work, int64_t *its_out,
-                 double *res_out, double *trace, int64_t trace_cap, int64_t *trace_rows) {
+                 int64_t x_len, int64_t max_iter, R tol, T *work, int64_t *its_out,
+                 R *res_out, double *trace, int64_t trace_cap, int64_t *trace_rows) {
     FN(csr) A = {size, indptr, indices, data, parallel};
     int64_t n = rhs_len, tr = 0;
     *its_out = 0; *res_out = 0.0;
@@ -166,13 +166,13 @@ int FN(bicgstab)(int64_t size, const int64_t *indptr, const int64_t *indices, co
     if (n != size) return ORC_INCOMPATIBLE_RHS;          /* :44-48 */
     if (n != x_len) return ORC_INCOMPATIBLE_X;           /* :49-53 */
 
-    double rhs_norm = FN(norm2)(n, rhs);                 /* :55 */
-    if (rhs_norm <= DBL_EPSILON) {                       /* :56-60 */
+    R rhs_norm = FN(norm2)(n, rhs);                 /* :55 */
+    if (rhs_norm <= R_EPS) {                       /* :56-60 */
         for (int64_t i = 0; i < n; ++i) x[i] = S(zero)();
         *its_out = 0; *res_out = rhs_norm;
         return ORC_OK;
     }
-    double tol2 = tol * rhs_norm;                        /* :61 */
+    R tol2 = tol * rhs_norm;                        /* :61 */
 
     /* :64-69 / :234-241 workspace layout */
     T *r = work, *r0 = work + n, *y = work + 2 * n, *p = NULL, *v, *t, *z = NULL;
@@ -182,12 +182,12 @@ int FN(bicgstab)(int64_t size, const int64_t *indptr, const int64_t *indices, co
     FN(mv)(&A, x, r);                                    /* :73 */
     FN(axpy)(n, S(neg)(S(one)()), rhs, r);               /* :75  r = A x - rhs */
     memcpy(r0, r, (size_t)n * sizeof(T));                /* :78 */
-    double r0_norm = FN(norm2)(n, r0);                   /* :80 */
+    R r0_norm = FN(norm2)(n, r0);                   /* :80 */
     if (r0_norm <= tol2) {                               /* :81-83 */
         *its_out = 0; *res_out = r0_norm / rhs_norm;
         return ORC_OK;
     }
-    double r0_norm_tol = r0_norm * DBL_EPSILON;          /* :84 */
+    R r0_norm_tol = r0_norm * R_EPS;          /* :84 */
     r0_norm_tol = r0_norm_tol * r0_norm_tol;             /* :85 */
 
     T rho = S(fromr)(r0_norm * r0_norm);                 /* :88 */
@@ -213,7 +213,7 @@ int FN(bicgstab)(int64_t size, const int64_t *indptr, const int64_t *indices, co
     FN(trace8)(trace, trace_cap, &tr, 0.0, r0_norm, rho, alpha, w);
 
     for (int64_t its = 1; its < max_iter; ++its) {       /* :122 */
-        double r_norm = FN(norm2)(n, r);                 /* :123 */
+        R r_norm = FN(norm2)(n, r);                 /* :123 */
         if (r_norm <= tol2) {                            /* :124-126 */
             *its_out = its; *res_out = r_norm / rhs_norm;
             if (trace_rows) *trace_rows = tr;
@@ -225,9 +225,9 @@ int FN(bicgstab)(int64_t size, const int64_t *indptr, const int64_t *indices, co
             FN(mv)(&A, x, r);                            /* :134 */
             FN(axpy)(n, S(neg)(S(one)()), rhs, r);       /* :137 */
             memcpy(r0, r, (size_t)n * sizeof(T));        /* :140 */
-            double rn = FN(norm2)(n, r);                 /* :142 */
+            R rn = FN(norm2)(n, r);                 /* :142 */
             rho = S(fromr)(rn * rn);                     /* :143 */
-            r0_norm_tol = S(re)(rho) * DBL_EPSILON * DBL_EPSILON;   /* :144 */
+            r0_norm_tol = S(re)(rho) * R_EPS * R_EPS;   /* :144 */
         }
         T beta = S(mul)(S(div)(rho, rho_old), S(div)(alpha, w));    /* :146 */
         T *yp = pc ? p : y;
@@ -265,8 +265,8 @@ int FN(bicgstab)(int64_t size, const int64_t *indptr, const int64_t *indices, co
  * trace rows: [its, beta_new, alpha, c, (s, res_norm)]. */
 int FN(minres)(int saunders, int64_t size, const int64_t *indptr, const int64_t *indices,
                const T *data, int parallel, const void *pc, int pc_complex, const T *rhs,
-               int64_t rhs_len, T *x, int64_t x_len, int64_t max_iter, double tol, T *work,
-               int64_t *its_out, double *res_out, double *trace, int64_t trace_cap,
+               int64_t rhs_len, T *x, int64_t x_len, int64_t max_iter, R tol, T *work,
+               int64_t *its_out, R *res_out, double *trace, int64_t trace_cap,
                int64_t *trace_rows) {
     FN(csr) A = {size, indptr, indices, data, parallel};
     int64_t n = rhs_len, trn = 0;
@@ -275,16 +275,16 @@ int FN(minres)(int saunders, int64_t size, const int64_t *indptr, const int64_t 
     if (n != size) return ORC_INCOMPATIBLE_RHS;          /* minres.rs:40-44 */
     if (n != x_len) return ORC_INCOMPATIBLE_X;           /* :45-49 */
 
-    double rhs_norm = FN(norm2)(n, rhs);                 /* :51 */
-    if (rhs_norm <= DBL_EPSILON) {                       /* :52-56 */
+    R rhs_norm = FN(norm2)(n, rhs);                 /* :51 */
+    if (rhs_norm <= R_EPS) {                       /* :52-56 */
         for (int64_t i = 0; i < n; ++i) x[i] = S(zero)();
         *its_out = 0; *res_out = rhs_norm;
         return ORC_OK;
     }
-    double threshold = tol * rhs_norm;                   /* :57 */
+    R threshold = tol * rhs_norm;                   /* :57 */
 
     T c = S(one)(), c_old = S(one)();                    /* :60-61 */
-    double s = 0.0, s_old = 0.0;                         /* :62-63 */
+    R s = 0.0, s_old = 0.0;                         /* :62-63 */
     T eta = S(one)();                                    /* :64 */
 
     T *v_old = work, *v_new = work + n, *v = work + 2 * n;          /* :68-70 */
@@ -295,31 +295,31 @@ int FN(minres)(int saunders, int64_t size, const int64_t *indptr, const int64_t 
     memcpy(v_new, rhs, (size_t)n * sizeof(T));           /* :77 */
     FN(mv)(&A, x, v_old);                                /* :78 */
     FN(axpy)(n, S(neg)(S(one)()), v_old, v_new);         /* :80  v_new = rhs - A x */
-    double res_norm = FN(norm2)(n, v_new);               /* :81 */
-    double beta_new, beta_one;
+    R res_norm = FN(norm2)(n, v_new);               /* :81 */
+    R beta_new, beta_one;
     if (pc) {
         FN(pc_apply)(n, pc, pc_complex, v_new, w_new);   /* :233 */
         T b2 = FN(conj_dot)(n, v_new, w_new);            /* :235 */
-        if (S(re)(b2) < DBL_EPSILON || S(im)(b2) > DBL_EPSILON * S(re)(b2)) {   /* :236-244 */
+        if (S(re)(b2) < R_EPS || S(im)(b2) > R_EPS * S(re)(b2)) {   /* :236-244 */
             *its_out = 0; *res_out = S(re)(b2);
             return ORC_INVALID_PRECOND;
         }
-        beta_new = sqrt(S(re)(b2));                      /* :245 */
+        beta_new = R_SQRT(S(re)(b2));                      /* :245 */
         beta_one = beta_new;                             /* :246 */
-        double ts = 1.0 / beta_new;                      /* :248 */
+        R ts = (R)1 / beta_new;                      /* :248 */
         FN(rscale)(n, ts, v_new);                        /* :249 */
         FN(rscale)(n, ts, w_new);                        /* :250 */
     } else {
         beta_new = res_norm;                             /* :82 */
         beta_one = beta_new;                             /* :83 */
-        FN(rscale)(n, 1.0 / beta_new, v_new);            /* :84 */
+        FN(rscale)(n, (R)1 / beta_new, v_new);            /* :84 */
     }
     for (int64_t i = 0; i < n; ++i) v[i] = S(zero)();     /* :86 */
     for (int64_t i = 0; i < n; ++i) p_old[i] = S(zero)(); /* :87 */
     for (int64_t i = 0; i < n; ++i) p[i] = S(zero)();     /* :88 */
 
     for (int64_t its = 0; its < max_iter; ++its) {       /* :90 */
-        double beta = beta_new;                          /* :91 */
+        R beta = beta_new;                          /* :91 */
         T *vt = v_old; v_old = v; v = v_new; v_new = vt; /* :92-96 pointer rotation */
         T alpha;
         const T *q;                                      /* the vector copied into p */
@@ -343,27 +343,27 @@ int FN(minres)(int saunders, int64_t size, const int64_t *indptr, const int64_t 
         if (pc) {
             FN(pc_apply)(n, pc, pc_complex, v_new, w_new);   /* :276 */
             T b2 = FN(conj_dot)(n, v_new, w_new);            /* :278 */
-            if (S(re)(b2) < DBL_EPSILON || S(im)(b2) > DBL_EPSILON * S(re)(b2)) {   /* :279-287 */
+            if (S(re)(b2) < R_EPS || S(im)(b2) > R_EPS * S(re)(b2)) {   /* :279-287 */
                 *its_out = its; *res_out = S(re)(b2);
                 if (trace_rows) *trace_rows = trn;
                 return ORC_INVALID_PRECOND;
             }
-            beta_new = sqrt(S(re)(b2));                  /* :288 */
-            double ts = 1.0 / beta_new;                  /* :289 */
+            beta_new = R_SQRT(S(re)(b2));                  /* :288 */
+            R ts = (R)1 / beta_new;                  /* :289 */
             FN(rscale)(n, ts, v_new);                    /* :290 */
             FN(rscale)(n, ts, w_new);                    /* :291 */
         } else {
             beta_new = FN(norm2)(n, v_new);              /* :120 */
-            FN(rscale)(n, 1.0 / beta_new, v_new);        /* :121 */
+            FN(rscale)(n, (R)1 / beta_new, v_new);        /* :121 */
         }
 
         /* Givens: minres.rs:132-148 ; cs_minres.rs:119-134 adds the conj() calls */
-        double r3 = s_old * beta;                        /* :132 */
+        R r3 = s_old * beta;                        /* :132 */
         T trv = saunders ? S(mulr)(S(conj)(c_old), beta) : S(mulr)(c_old, beta);   /* :133 / cs:120 */
         T r2 = S(add)(S(mulr)(alpha, s), S(mul)(c, trv));                          /* :134 */
         T r1_hat = saunders ? S(sub)(S(mul)(S(conj)(c), alpha), S(mulr)(trv, s))   /* cs:122 */
                             : S(sub)(S(mul)(c, alpha), S(mulr)(trv, s));           /* :136 */
-        double r1_inv = 1.0 / sqrt(S(sq)(r1_hat) + beta_new * beta_new);           /* :139-140 */
+        R r1_inv = (R)1 / R_SQRT(S(sq)(r1_hat) + beta_new * beta_new);           /* :139-140 */
         c_old = c;                                       /* :142 */
         s_old = s;                                       /* :143 */
         c = saunders ? S(mulr)(S(conj)(r1_hat), r1_inv) : S(mulr)(r1_hat, r1_inv); /* :147 / cs:133 */
@@ -376,7 +376,7 @@ int FN(minres)(int saunders, int64_t size, const int64_t *indptr, const int64_t 
         FN(rscale)(n, r1_inv, p);                        /* :160 */
         FN(axpy)(n, S(mulr)(S(mul)(c, eta), beta_one), p, x);   /* :162 */
 
-        res_norm *= fabs(s);                             /* :164 */
+        res_norm *= R_ABS(s);                             /* :164 */
         FN(trace8)(trace, trace_cap, &trn, (double)its, beta_new, alpha, c, S(fromr)(s));
         if (trace && trn <= trace_cap && trn > 0) trace[8 * (trn - 1) + 7] = res_norm;
         if (res_norm < threshold) {                      /* :165-167 */

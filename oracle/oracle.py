@@ -47,11 +47,23 @@ def lib():
         _lib.orc_conj_dot_z.restype = _C64
         _lib.orc_spmv_csr_dot_z.restype = _C64
         _lib.orc_max_threads.restype = C.c_int
+        _lib.orc_norm2_s.restype = C.c_float
+        _lib.orc_norm2_c.restype = C.c_float
+        _lib.orc_dot_s.restype = C.c_float
+        _lib.orc_conj_dot_s.restype = C.c_float
+        _lib.orc_spmv_csr_dot_s.restype = C.c_float
+        _lib.orc_dot_c.restype = _C32
+        _lib.orc_conj_dot_c.restype = _C32
+        _lib.orc_spmv_csr_dot_c.restype = _C32
     return _lib
 
 
 class _C64(C.Structure):
     _fields_ = [("re", C.c_double), ("im", C.c_double)]
+
+
+class _C32(C.Structure):
+    _fields_ = [("re", C.c_float), ("im", C.c_float)]
 
 
 def set_threads(n):
@@ -68,7 +80,11 @@ def _sfx(dtype):
         return "d"
     if dtype == np.complex128:
         return "z"
-    raise TypeError("oracle supports float64 / complex128 only, got %s" % dtype)
+    if dtype == np.float32:
+        return "s"
+    if dtype == np.complex64:
+        return "c"
+    raise TypeError("oracle supports float32/64 and complex64/128, got %s" % dtype)
 
 
 def _arr(a, dtype):
@@ -82,12 +98,18 @@ def _p(a):
 def _scalar(v, sfx):
     if sfx == "d":
         return C.c_double(float(v))
+    if sfx == "s":
+        return C.c_float(float(v))
     v = complex(v)
-    return _C64(v.real, v.imag)
+    return _C64(v.real, v.imag) if sfx == "z" else _C32(v.real, v.imag)
+
+
+def _real(v, sfx):
+    return C.c_double(float(v)) if sfx in "dz" else C.c_float(float(v))
 
 
 def _ret(v, sfx):
-    return float(v) if sfx == "d" else complex(v.re, v.im)
+    return float(v) if sfx in "ds" else complex(v.re, v.im)
 
 
 def _i64(a):
@@ -116,8 +138,11 @@ def axpy(a, x, y):
     """y += x * a  (in place on y; y must be a contiguous ndarray)."""
     s = _sfx(y.dtype); x = _arr(x, y.dtype)
     assert y.flags.c_contiguous and x.shape == y.shape
-    if s == "z" and isinstance(a, (float, int, np.floating)) :
-        lib().orc_axpy_zd(C.c_int64(y.size), C.c_double(float(a)), _p(x), _p(y))
+    if s in "zc" and isinstance(a, (float, int, np.floating)):
+        if s == "z":
+            lib().orc_axpy_zd(C.c_int64(y.size), C.c_double(float(a)), _p(x), _p(y))
+        else:
+            lib().orc_axpy_cs(C.c_int64(y.size), C.c_float(float(a)), _p(x), _p(y))
     else:
         getattr(lib(), "orc_axpy_" + s)(C.c_int64(y.size), _scalar(a, s), _p(x), _p(y))
     return y
@@ -139,7 +164,7 @@ def scale(a, v):
 
 def rscale(a, v):
     s = _sfx(v.dtype); assert v.flags.c_contiguous
-    getattr(lib(), "orc_rscale_" + s)(C.c_int64(v.size), C.c_double(float(a)), _p(v))
+    getattr(lib(), "orc_rscale_" + s)(C.c_int64(v.size), _real(a, s), _p(v))
     return v
 
 
@@ -185,8 +210,12 @@ def diag_inv(diag):
     out = np.empty_like(diag)
     if diag.dtype == np.float64:
         lib().orc_diag_inv_real_d(C.c_int64(diag.size), _p(diag), _p(out))
+    elif diag.dtype == np.float32:
+        lib().orc_diag_inv_real_s(C.c_int64(diag.size), _p(diag), _p(out))
     elif diag.dtype == np.complex128:
         lib().orc_diag_inv_complex(C.c_int64(diag.size), _p(diag), _p(out))
+    elif diag.dtype == np.complex64:
+        lib().orc_diag_inv_complex_f(C.c_int64(diag.size), _p(diag), _p(out))
     else:
         raise TypeError(diag.dtype)
     return out
@@ -195,7 +224,7 @@ def diag_inv(diag):
 def diag_apply(dinv, v):
     s = _sfx(v.dtype); v = _arr(v, v.dtype); dinv = np.ascontiguousarray(dinv)
     out = np.empty_like(v)
-    getattr(lib(), "orc_diag_apply_" + s)(C.c_int64(v.size), _p(dinv), C.c_int(int(dinv.dtype == np.complex128)),
+    getattr(lib(), "orc_diag_apply_" + s)(C.c_int64(v.size), _p(dinv), C.c_int(int(dinv.dtype.kind == 'c')),
                                           _p(v), _p(out))
     return out
 
@@ -217,14 +246,14 @@ def _solve(kind, indptr, indices, data, rhs, x0, max_iter, tol, precond_diag=Non
     indptr = _i64(indptr); indices = _i64(indices)
     n = indptr.size - 1 if size is None else size
     work = np.zeros(8 * max(n, rhs.size), dtype=data.dtype)
-    its = C.c_int64(0); res = C.c_double(0.0); rows = C.c_int64(0)
+    its = C.c_int64(0); res = (C.c_double if s in "dz" else C.c_float)(0.0); rows = C.c_int64(0)
     trace = np.zeros((max(trace_cap, 1), 8))
     pc = None; pc_c = 0
     if precond_diag is not None:
-        pc = diag_inv(np.ascontiguousarray(precond_diag)); pc_c = int(pc.dtype == np.complex128)
+        pc = diag_inv(np.ascontiguousarray(precond_diag)); pc_c = int(pc.dtype.kind == 'c')
     pc_p = _p(pc) if pc is not None else C.c_void_p(0)
     common = [C.c_int64(n), _p(indptr), _p(indices), _p(data), C.c_int(1 if parallel else 0), pc_p, C.c_int(pc_c),
-              _p(rhs), C.c_int64(rhs.size), _p(x), C.c_int64(x.size), C.c_int64(max_iter), C.c_double(tol),
+              _p(rhs), C.c_int64(rhs.size), _p(x), C.c_int64(x.size), C.c_int64(max_iter), _real(tol, s),
               _p(work), C.byref(its), C.byref(res), _p(trace), C.c_int64(trace_cap), C.byref(rows)]
     if kind == "bicgstab":
         st = getattr(lib(), "orc_bicgstab_" + s)(*common)

@@ -20,6 +20,7 @@
 #include <float.h>
 
 typedef struct { double re, im; } orc_c64;
+typedef struct { float re, im; } orc_c32;
 
 /* ---- f64 ---- */
 static inline double d_zero(void) { return 0.0; }
@@ -60,5 +61,46 @@ static inline double z_re(orc_c64 a) { return a.re; }
 static inline double z_im(orc_c64 a) { return a.im; }
 static inline double z_sq(orc_c64 a) { return a.re * a.re + a.im * a.im; }
 static inline double z_abs(orc_c64 a) { return hypot(a.re, a.im); }
+
+/* ---- f32 ---- */
+static inline float f_zero(void) { return 0.0f; }
+static inline float f_one(void) { return 1.0f; }
+static inline float f_add(float a, float b) { return a + b; }
+static inline float f_sub(float a, float b) { return a - b; }
+static inline float f_mul(float a, float b) { return a * b; }
+static inline float f_div(float a, float b) { return a / b; }
+static inline float f_neg(float a) { return -a; }
+static inline float f_conj(float a) { return a; }
+static inline float f_mulr(float a, float r) { return a * r; }
+static inline float f_fromr(float r) { return r; }
+static inline float f_re(float a) { return a; }
+static inline float f_im(float a) { (void)a; return 0.0f; }
+static inline float f_sq(float a) { return a * a; }
+static inline float f_abs(float a) { return fabsf(a); }
+
+/* ---- Complex<f32> ---- */
+static inline orc_c32 c_make(float re, float im) { orc_c32 r; r.re = re; r.im = im; return r; }
+static inline orc_c32 c_zero(void) { return c_make(0.0f, 0.0f); }
+static inline orc_c32 c_one(void) { return c_make(1.0f, 0.0f); }
+static inline orc_c32 c_add(orc_c32 a, orc_c32 b) { return c_make(a.re + b.re, a.im + b.im); }
+static inline orc_c32 c_sub(orc_c32 a, orc_c32 b) { return c_make(a.re - b.re, a.im - b.im); }
+static inline orc_c32 c_mul(orc_c32 a, orc_c32 b) {
+    return c_make(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+}
+static inline orc_c32 c_div(orc_c32 a, orc_c32 b) {
+    float n = b.re * b.re + b.im * b.im;
+    float re = a.re * b.re + a.im * b.im;
+    float im = a.im * b.re - a.re * b.im;
+    return c_make(re / n, im / n);
+}
+static inline orc_c32 c_neg(orc_c32 a) { return c_make(-a.re, -a.im); }
+static inline orc_c32 c_conj(orc_c32 a) { return c_make(a.re, -a.im); }
+static inline orc_c32 c_mulr(orc_c32 a, float r) { return c_make(a.re * r, a.im * r); }
+static inline orc_c32 c_fromr(float r) { return c_make(r, 0.0f); }
+static inline float c_re(orc_c32 a) { return a.re; }
+static inline float c_im(orc_c32 a) { return a.im; }
+static inline float c_sq(orc_c32 a) { return a.re * a.re + a.im * a.im; }
+static inline float c_abs(orc_c32 a) { return hypotf(a.re, a.im); }
+
 
 #endif

@@ -56,9 +56,16 @@ int orc_max_threads(void) {
 #endif
 }
 
-/* f64 instantiation */
+#define ORC_UNDEF_ALL
+/* f64 */
 #define T double
+#define R double
+#define CT orc_c64
+#define R_EPS DBL_EPSILON
+#define R_SQRT sqrt
+#define R_ABS fabs
 #define SP d_
+#define CSP z_
 #define SFX_US _d
 #define SFX_IS_COMPLEX 0
 #include "krylov_tmpl.h"
@@ -66,15 +73,52 @@ int orc_max_threads(void) {
 #undef SP
 #undef SFX_US
 #undef SFX_IS_COMPLEX
-
-/* Complex<f64> instantiation */
+/* Complex<f64> */
 #define T orc_c64
 #define SP z_
 #define SFX_US _z
 #define SFX_IS_COMPLEX 1
 #include "krylov_tmpl.h"
 #undef T
+#undef R
+#undef CT
+#undef R_EPS
+#undef R_SQRT
+#undef R_ABS
 #undef SP
+#undef CSP
+#undef SFX_US
+#undef SFX_IS_COMPLEX
+/* f32 (the reference is generic over cauchy::Scalar; its tests use f32/c32 at vecalg.rs:647-658,669-677,771-830) */
+#define T float
+#define R float
+#define CT orc_c32
+#define R_EPS FLT_EPSILON
+#define R_SQRT sqrtf
+#define R_ABS fabsf
+#define SP f_
+#define CSP c_
+#define SFX_US _s
+#define SFX_IS_COMPLEX 0
+#include "krylov_tmpl.h"
+#undef T
+#undef SP
+#undef SFX_US
+#undef SFX_IS_COMPLEX
+/* Complex<f32> */
+#define T orc_c32
+#define SP c_
+#define SFX_US _c
+#define SFX_IS_COMPLEX 1
+#include "krylov_tmpl.h"
+#undef T
+#undef R
+#undef CT
+#undef R_EPS
+#undef R_SQRT
+#undef R_ABS
+#undef SP
+#undef CSP
 #undef SFX_US
 #undef SFX_IS_COMPLEX
 
@@ -87,4 +131,10 @@ void orc_diag_inv_complex(int64_t n, const orc_c64 *diag, orc_c64 *dinv) {
  * vecalg.rs:746-757): y += x * a with a real */
 void orc_axpy_zd(int64_t n, double a, const orc_c64 *x, orc_c64 *y) {
     for (int64_t i = 0; i < n; ++i) y[i] = z_add(y[i], z_mulr(x[i], a));
+}
+void orc_diag_inv_complex_f(int64_t n, const orc_c32 *diag, orc_c32 *dinv) {
+    for (int64_t i = 0; i < n; ++i) dinv[i] = c_div(c_one(), diag[i]);
+}
+void orc_axpy_cs(int64_t n, float a, const orc_c32 *x, orc_c32 *y) {
+    for (int64_t i = 0; i < n; ++i) y[i] = c_add(y[i], c_mulr(x[i], a));
 }

@@ -29,6 +29,23 @@ class c64(C.Structure):
         return complex(self.re, self.im)
 
 
+class c32(C.Structure):
+    _fields_ = [("re", C.c_float), ("im", C.c_float)]
+
+    @classmethod
+    def of(cls, v):
+        v = complex(v)
+        return cls(v.real, v.imag)
+
+    def py(self):
+        return complex(self.re, self.im)
+
+
+# per-suffix C types: scalar passed by value, T::Real, pointer to T::Real
+SCALAR = {"d": C.c_double, "z": c64, "s": C.c_float, "c": c32}
+REAL = {"d": C.c_double, "z": C.c_double, "s": C.c_float, "c": C.c_float}
+
+
 def build(force=False, jobs=4):
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     args = ["make", "-C", CSRC, "-s", "-j%d" % jobs]
@@ -57,7 +74,8 @@ def _protos():
     for n in ("h2d", "d2h", "d2d"):
         P["sprs_memcpy_" + n] = [_vp, _vp, _vp, _sz]
     P["sprs_memset_zero"] = [_vp, _vp, _sz]
-    for s in ("d", "z"):
+    for s in ("d", "z", "s", "c"):
+        sc, re_, pre = SCALAR[s], REAL[s], C.POINTER(REAL[s])
         P["sprs_csr_create_" + s] = [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _pp]
         P["sprs_csr_create_i64_" + s] = [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _pp]
         P["sprs_csr_create_dev_" + s] = [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _pp]
@@ -66,12 +84,11 @@ def _protos():
         P["sprs_mul_vec_dev_" + s] = [_vp, _vp, _vp]
         P["sprs_mul_vec_dot_dev_" + s] = [_vp, _vp, _vp, _vp]
         P["sprs_mul_vec_dev_timed_" + s] = [_vp, _vp, _vp, _int, _pd]
-        sc = _dbl if s == "d" else c64
         P["sprs_dot_" + s] = [_vp, _sz, _vp, _vp, _vp]
         P["sprs_conj_dot_" + s] = [_vp, _sz, _vp, _vp, _vp]
-        P["sprs_norm2_" + s] = [_vp, _sz, _vp, _pd]
+        P["sprs_norm2_" + s] = [_vp, _sz, _vp, pre]
         P["sprs_scale_" + s] = [_vp, _sz, sc, _vp]
-        P["sprs_rscale_" + s] = [_vp, _sz, _dbl, _vp]
+        P["sprs_rscale_" + s] = [_vp, _sz, re_, _vp]
         P["sprs_conj_" + s] = [_vp, _sz, _vp, _vp]
         P["sprs_axpy_" + s] = [_vp, _sz, sc, _vp, _vp]
         P["sprs_axpby_" + s] = [_vp, _sz, sc, _vp, sc, _vp]
@@ -79,23 +96,24 @@ def _protos():
         P["sprs_diag_mul_vec_dev_" + s] = [_vp, _vp, _vp]
         for k in ("bicgstab", "minres", "csminres"):
             P["sprs_%s_create_%s" % (k, s)] = [_vp, _sz, _pp]
-            P["sprs_%s_solve_%s" % (k, s)] = [_vp, _vp, _sz, _vp, _sz, _sz, _dbl, _psz, _pd]
+            P["sprs_%s_solve_%s" % (k, s)] = [_vp, _vp, _sz, _vp, _sz, _sz, re_, _psz, pre]
         for k in ("bicgstab", "minres"):
-            P["sprs_%s_precond_solve_%s" % (k, s)] = [_vp, _vp, _vp, _sz, _vp, _sz, _sz, _dbl, _psz, _pd]
-            P["sprs_%s_solve_dev_%s" % (k, s)] = [_vp, _vp, _vp, _sz, _vp, _sz, _sz, _dbl, _psz, _pd]
-        P["sprs_csminres_solve_dev_" + s] = [_vp, _vp, _sz, _vp, _sz, _sz, _dbl, _psz, _pd]
+            P["sprs_%s_precond_solve_%s" % (k, s)] = [_vp, _vp, _vp, _sz, _vp, _sz, _sz, re_, _psz, pre]
+            P["sprs_%s_solve_dev_%s" % (k, s)] = [_vp, _vp, _vp, _sz, _vp, _sz, _sz, re_, _psz, pre]
+        P["sprs_csminres_solve_dev_" + s] = [_vp, _vp, _sz, _vp, _sz, _sz, re_, _psz, pre]
     P["sprs_axpy_zd"] = [_vp, _sz, _dbl, _vp, _vp]
+    P["sprs_axpy_cs"] = [_vp, _sz, C.c_float, _vp, _vp]
     P["sprs_csr_destroy"] = [_vp]
     for k in ("bicgstab", "minres", "csminres"):
         P["sprs_%s_destroy" % k] = [_vp]
-    for s in ("d", "zd", "z"):
+    for s in ("d", "zd", "z", "s", "cs", "c"):
         P["sprs_diag_precond_create_" + s] = [_vp, _sz, _vp, _pp]
     P["sprs_diag_precond_destroy"] = [_vp]
     P["sprs_comm_unique_id"] = [_vp]
     P["sprs_comm_create"] = [_vp, _int, _int, _vp, _pp]
     P["sprs_comm_destroy"] = [_vp]
     P["sprs_comm_allreduce_sum_f64"] = [_vp, _vp, _sz]
-    for s in ("d", "z"):
+    for s in ("d", "z", "s", "c"):
         P["sprs_dist_csr_create_dev_" + s] = [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _pp]
         P["sprs_dist_mul_vec_dev_" + s] = [_vp, _vp, _vp]
     P["sprs_solver_set_mode"] = [_vp, _int, _int]

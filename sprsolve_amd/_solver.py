@@ -16,7 +16,8 @@ class _SolverBase:
         self.A = A                      # borrowed, like `A: &'data M` (bicg_stab.rs:18)
         self.size = int(size)
         self.dtype = A.dtype
-        self.s = "z" if self.dtype == np.complex128 else "d"
+        from .device import sfx
+        self.s = sfx(self.dtype)
         h = C.c_void_p()
         st = getattr(_lib.lib(), "sprs_%s_create_%s" % (self.NAME, self.s))(A.h, self.size, C.byref(h))
         check(st, A.ctx.h)
@@ -58,7 +59,7 @@ class _SolverBase:
     # ---- the call itself
     def _solve(self, precond, rhs, x, max_iter, tol, want_precond):
         L = _lib.lib()
-        its = C.c_size_t(0); res = C.c_double(0.0)
+        its = C.c_size_t(0); res = _lib.REAL[self.s](0.0)
         dev = is_device_array(rhs)
         if dev != is_device_array(x):
             raise TypeError("rhs and x must both be host arrays or both be device vectors")

@@ -39,7 +39,7 @@ struct ScaleF {  // vecalg.rs:592-595  v *= a
 };
 template <class T>
 struct RscaleF {  // vecalg.rs:596-599  v = v.mul_real(a)
-    double a; T *x;
+    Real<T> a; T *x;
     template <int PK> __device__ __forceinline__ void run(int64_t i) const {
         auto xv = ldp<T, PK>(x, i);
 #pragma unroll
@@ -114,7 +114,7 @@ int launch_scale(sprs_ctx *c, size_t n, T a, T *x) {
     return launch_ew<T>(c, n, aligned16(x), ScaleF<T>{a, x});
 }
 template <class T>
-int launch_rscale(sprs_ctx *c, size_t n, double a, T *x) {
+int launch_rscale(sprs_ctx *c, size_t n, Real<T> a, T *x) {
     return launch_ew<T>(c, n, aligned16(x), RscaleF<T>{a, x});
 }
 template <class T>
@@ -150,9 +150,9 @@ __global__ __launch_bounds__(BLOCK) void dot_kernel(int64_t n, const T *__restri
 }
 
 template <class T, int PK>
-__global__ __launch_bounds__(BLOCK) void nrm2sq_kernel(int64_t n, const T *__restrict__ x, double *__restrict__ part) {
-    __shared__ double smem[NWAVE];
-    double acc = 0.0;
+__global__ __launch_bounds__(BLOCK) void nrm2sq_kernel(int64_t n, const T *__restrict__ x, Real<T> *__restrict__ part) {
+    __shared__ Real<T> smem[NWAVE];
+    Real<T> acc = 0;
     SPRS_FOREACH_PACK(n, PK, i) {
         auto xv = ldp<T, PK>(x, i);
 #pragma unroll
@@ -178,7 +178,7 @@ int reduce_partials_host(sprs_ctx *c, const T *part, int P, T *out, sprs_comm *c
     T *d_out = reinterpret_cast<T *>(c->d_scal);
     hipLaunchKernelGGL((finalize_kernel<T>), dim3(1), dim3(BLOCK), 0, c->stream, part, P, d_out);
     SPRS_HIP_TRY(c, hipGetLastError());
-    if (comm) SPRS_TRY(allreduce_sum(comm, reinterpret_cast<double *>(d_out), sizeof(T) / sizeof(double)));
+    if (comm) SPRS_TRY(allreduce_sum(comm, d_out, sizeof(T) / sizeof(Real<T>), sizeof(Real<T>) == 4));
     SPRS_HIP_TRY(c, hipMemcpyAsync(c->h_scal, d_out, sizeof(T), hipMemcpyDeviceToHost, c->stream));
     SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     memcpy(out, c->h_scal, sizeof(T));
@@ -209,42 +209,39 @@ int dot_host(sprs_ctx *c, size_t n, const T *x, const T *y, bool conj, T *out, s
 }
 
 template <class T>
-int norm2_host(sprs_ctx *c, size_t n, const T *x, double *out, sprs_comm *comm) {
+int norm2_host(sprs_ctx *c, size_t n, const T *x, Real<T> *out, sprs_comm *comm) {
     constexpr int PKW = pack_width<T>::value;
     const int pk = (aligned16(x) && PKW > 1) ? PKW : 1;
     const int g = red_grid(c, n, pk);
-    double *part = c->d_part;
+    Real<T> *part = reinterpret_cast<Real<T> *>(c->d_part);
     if (pk == 1) hipLaunchKernelGGL((nrm2sq_kernel<T, 1>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, x, part);
     else hipLaunchKernelGGL((nrm2sq_kernel<T, PKW>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, x, part);
     SPRS_HIP_TRY(c, hipGetLastError());
-    double s = 0.0;
-    SPRS_TRY(reduce_partials_host<double>(c, part, g, &s, comm));
-    *out = sqrt(s);  // vecalg.rs:604
+    Real<T> s = 0;
+    SPRS_TRY(reduce_partials_host<Real<T>>(c, part, g, &s, comm));
+    *out = ssqrt(s);  // vecalg.rs:604
     return SPRS_OK;
 }
 
 // ------------------------------------------------------------------ explicit instantiations
-template int launch_axpy<double, double>(sprs_ctx *, size_t, double, const double *, double *);
-template int launch_axpy<cplx, cplx>(sprs_ctx *, size_t, cplx, const cplx *, cplx *);
-template int launch_axpy<cplx, double>(sprs_ctx *, size_t, double, const cplx *, cplx *);
-template int launch_axpby<double>(sprs_ctx *, size_t, double, const double *, double, double *);
-template int launch_axpby<cplx>(sprs_ctx *, size_t, cplx, const cplx *, cplx, cplx *);
-template int launch_scale<double>(sprs_ctx *, size_t, double, double *);
-template int launch_scale<cplx>(sprs_ctx *, size_t, cplx, cplx *);
-template int launch_rscale<double>(sprs_ctx *, size_t, double, double *);
-template int launch_rscale<cplx>(sprs_ctx *, size_t, double, cplx *);
-template int launch_conj<double>(sprs_ctx *, size_t, const double *, double *);
-template int launch_conj<cplx>(sprs_ctx *, size_t, const cplx *, cplx *);
-template int launch_diag_apply<double, double>(sprs_ctx *, size_t, const double *, const double *, double *);
-template int launch_diag_apply<cplx, double>(sprs_ctx *, size_t, const double *, const cplx *, cplx *);
-template int launch_diag_apply<cplx, cplx>(sprs_ctx *, size_t, const cplx *, const cplx *, cplx *);
-template int launch_diag_inv<double>(sprs_ctx *, size_t, const double *, double *);
-template int launch_diag_inv<cplx>(sprs_ctx *, size_t, const cplx *, cplx *);
-template int dot_host<double>(sprs_ctx *, size_t, const double *, const double *, bool, double *, sprs_comm *);
-template int dot_host<cplx>(sprs_ctx *, size_t, const cplx *, const cplx *, bool, cplx *, sprs_comm *);
-template int norm2_host<double>(sprs_ctx *, size_t, const double *, double *, sprs_comm *);
-template int norm2_host<cplx>(sprs_ctx *, size_t, const cplx *, double *, sprs_comm *);
-template int reduce_partials_host<double>(sprs_ctx *, const double *, int, double *, sprs_comm *);
-template int reduce_partials_host<cplx>(sprs_ctx *, const cplx *, int, cplx *, sprs_comm *);
+#define SPRS_INST_REAL(T)                                                                    \
+    template int launch_axpy<T, T>(sprs_ctx *, size_t, T, const T *, T *);                   \
+    template int launch_axpby<T>(sprs_ctx *, size_t, T, const T *, T, T *);                  \
+    template int launch_scale<T>(sprs_ctx *, size_t, T, T *);                                \
+    template int launch_rscale<T>(sprs_ctx *, size_t, Real<T>, T *);                         \
+    template int launch_conj<T>(sprs_ctx *, size_t, const T *, T *);                         \
+    template int launch_diag_apply<T, Real<T>>(sprs_ctx *, size_t, const Real<T> *, const T *, T *); \
+    template int launch_diag_inv<T>(sprs_ctx *, size_t, const T *, T *);                     \
+    template int dot_host<T>(sprs_ctx *, size_t, const T *, const T *, bool, T *, sprs_comm *); \
+    template int norm2_host<T>(sprs_ctx *, size_t, const T *, Real<T> *, sprs_comm *);       \
+    template int reduce_partials_host<T>(sprs_ctx *, const T *, int, T *, sprs_comm *);
+#define SPRS_INST_CPLX(T)                                                                    \
+    SPRS_INST_REAL(T)                                                                        \
+    template int launch_axpy<T, Real<T>>(sprs_ctx *, size_t, Real<T>, const T *, T *);       \
+    template int launch_diag_apply<T, T>(sprs_ctx *, size_t, const T *, const T *, T *);
+SPRS_INST_REAL(double)
+SPRS_INST_REAL(float)
+SPRS_INST_CPLX(cplx)
+SPRS_INST_CPLX(cplxf)
 
 }  // namespace sprs

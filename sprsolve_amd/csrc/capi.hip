@@ -8,6 +8,7 @@
 using namespace sprs;
 
 static_assert(sizeof(sprs_c64) == sizeof(cplx), "Complex<f64> layout");
+static_assert(sizeof(sprs_c32) == sizeof(cplxf), "Complex<f32> layout");
 
 #define SPRS_GUARD_BEGIN try {
 #define SPRS_GUARD_END                         \
@@ -205,7 +206,7 @@ int csr_create_host(sprs_ctx *c, int64_t nrows, int64_t ncols, int64_t nnz, cons
         vsrc = vv.data();
     }
     sprs_csr *A = new sprs_csr();
-    A->ctx = c; A->is_complex = is_complex<T>::value ? 1 : 0;
+    A->ctx = c; A->dtype = dtype_of<T>::value;
     A->nrows = nrows; A->ncols = ncols; A->nnz = nnz; A->owns_arrays = true;
     auto fail = [&](int st) { sprs_csr_destroy(A); return st; };
     if (hipSetDevice(c->device) != hipSuccess) return fail(SPRS_ERR_HIP);
@@ -239,7 +240,7 @@ int csr_create_dev(sprs_ctx *c, int64_t nrows, int64_t ncols, int64_t nnz, const
     for (int64_t i = 0; i < nrows; ++i)
         if (rp[i + 1] < rp[i]) return SPRS_INVALID_ARGUMENT;
     sprs_csr *A = new sprs_csr();
-    A->ctx = c; A->is_complex = is_complex<T>::value ? 1 : 0;
+    A->ctx = c; A->dtype = dtype_of<T>::value;
     A->nrows = nrows; A->ncols = ncols; A->nnz = nnz;
     auto fail = [&](int st) { sprs_csr_destroy(A); return st; };
     if (adopt) {
@@ -279,7 +280,7 @@ int ensure_tmp(const sprs_csr *Ac) {
 template <class T>
 int mul_vec_host(const sprs_csr *A, const T *x, size_t x_len, T *y, size_t y_len, T *dot_out) {
     if (!A || !x || !y) return SPRS_INVALID_ARGUMENT;
-    if (A->is_complex != (is_complex<T>::value ? 1 : 0)) return SPRS_INVALID_ARGUMENT;
+    if (A->dtype != dtype_of<T>::value) return SPRS_INVALID_ARGUMENT;
     if ((size_t)A->ncols != x_len || x_len != y_len) return SPRS_DIM_MISMATCH;   // mat.rs:50-52
     sprs_ctx *c = A->ctx;
     SPRS_HIP_TRY(c, hipSetDevice(c->device));
@@ -298,7 +299,7 @@ int mul_vec_host(const sprs_csr *A, const T *x, size_t x_len, T *y, size_t y_len
 template <class T>
 int mul_vec_dev(const sprs_csr *A, const T *dx, T *dy, T *dot_out) {
     if (!A || !dx || !dy) return SPRS_INVALID_ARGUMENT;
-    if (A->is_complex != (is_complex<T>::value ? 1 : 0)) return SPRS_INVALID_ARGUMENT;
+    if (A->dtype != dtype_of<T>::value) return SPRS_INVALID_ARGUMENT;
     sprs_ctx *c = A->ctx;
     SPRS_HIP_TRY(c, hipSetDevice(c->device));
     if (!dot_out) return launch_spmv<T>(A, dx, dy, 0, nullptr, nullptr, nullptr, nullptr);
@@ -311,7 +312,7 @@ int mul_vec_dev(const sprs_csr *A, const T *dx, T *dy, T *dot_out) {
 template <class T>
 int mul_vec_timed(const sprs_csr *A, const T *dx, T *dy, int reps, double *ms) {
     if (!A || !dx || !dy || !ms || reps < 1) return SPRS_INVALID_ARGUMENT;
-    if (A->is_complex != (is_complex<T>::value ? 1 : 0)) return SPRS_INVALID_ARGUMENT;
+    if (A->dtype != dtype_of<T>::value) return SPRS_INVALID_ARGUMENT;
     sprs_ctx *c = A->ctx;
     SPRS_HIP_TRY(c, hipSetDevice(c->device));
     hipEvent_t e0, e1;
@@ -330,26 +331,157 @@ int mul_vec_timed(const sprs_csr *A, const T *dx, T *dy, int reps, double *ms) {
 
 }  // namespace
 
-extern "C" {
+// ------------------------------------------------------------------------------ Jacobi preconditioner
+namespace {
+template <class V>
+int diag_create(sprs_ctx *c, size_t n, const V *diag_host, int t_dtype, sprs_diag **out) {
+    if (!c || !out || (!diag_host && n)) return SPRS_INVALID_ARGUMENT;
+    *out = nullptr;
+    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    sprs_diag *P = new sprs_diag();
+    P->ctx = c; P->n = n; P->t_dtype = t_dtype; P->v_complex = is_complex<V>::value ? 1 : 0;
+    auto fail = [&](int st) { sprs_diag_precond_destroy(P); return st; };
+    V *tmp = nullptr;
+    const size_t np = ((n + 31) & ~(size_t)31) + 32;
+    if (hipMalloc(&P->dinv, sizeof(V) * np) != hipSuccess) return fail(SPRS_ERR_HIP);
+    if (hipMalloc((void **)&tmp, sizeof(V) * np) != hipSuccess) return fail(SPRS_ERR_HIP);
+    int st = SPRS_OK;
+    if (hipMemcpyAsync(tmp, diag_host, sizeof(V) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) st = SPRS_ERR_HIP;
+    if (st == SPRS_OK) st = launch_diag_inv<V>(c, n, tmp, (V *)P->dinv);   // precond.rs:22-24
+    if (st == SPRS_OK && hipStreamSynchronize(c->stream) != hipSuccess) st = SPRS_ERR_HIP;
+    (void)hipFree(tmp);
+    if (st != SPRS_OK) return fail(st);
+    *out = P;
+    return SPRS_OK;
+}
 
-int sprs_csr_create_d(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int32_t *rp, const int32_t *ci, const double *v, int csc, sprs_csr **out) {
-    SPRS_GUARD_BEGIN return csr_create_host<double, int32_t>(c, nr, nc, nnz, rp, ci, v, csc, out); SPRS_GUARD_END
+template <class T>
+int diag_apply_dev(const sprs_diag *P, const T *in, T *out) {
+    if (!P || !in || !out) return SPRS_INVALID_ARGUMENT;
+    if (P->t_dtype != dtype_of<T>::value) return SPRS_INVALID_ARGUMENT;
+    if (P->v_complex) {
+        if constexpr (is_complex<T>::value) return launch_diag_apply<T, T>(P->ctx, P->n, (const T *)P->dinv, in, out);
+        else return SPRS_INVALID_ARGUMENT;
+    }
+    return launch_diag_apply<T, Real<T>>(P->ctx, P->n, (const Real<T> *)P->dinv, in, out);
 }
-int sprs_csr_create_z(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int32_t *rp, const int32_t *ci, const sprs_c64 *v, int csc, sprs_csr **out) {
-    SPRS_GUARD_BEGIN return csr_create_host<cplx, int32_t>(c, nr, nc, nnz, rp, ci, (const cplx *)v, csc, out); SPRS_GUARD_END
+
+template <class T>
+int diag_apply_host(const sprs_diag *Pc, const T *in, size_t in_len, T *out, size_t out_len) {
+    if (!Pc || !in || !out) return SPRS_INVALID_ARGUMENT;
+    if (Pc->n != in_len || Pc->n != out_len) return SPRS_DIM_MISMATCH;     // precond.rs:39-41
+    sprs_diag *P = const_cast<sprs_diag *>(Pc);
+    sprs_ctx *c = P->ctx;
+    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    if (!P->in_tmp) SPRS_HIP_TRY(c, hipMalloc(&P->in_tmp, sizeof(T) * (P->n + 2)));
+    if (!P->out_tmp) SPRS_HIP_TRY(c, hipMalloc(&P->out_tmp, sizeof(T) * (P->n + 2)));
+    SPRS_HIP_TRY(c, hipMemcpyAsync(P->in_tmp, in, sizeof(T) * in_len, hipMemcpyHostToDevice, c->stream));
+    SPRS_TRY(diag_apply_dev<T>(P, (const T *)P->in_tmp, (T *)P->out_tmp));
+    SPRS_HIP_TRY(c, hipMemcpyAsync(out, P->out_tmp, sizeof(T) * out_len, hipMemcpyDeviceToHost, c->stream));
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPRS_OK;
 }
-int sprs_csr_create_i64_d(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int64_t *rp, const int64_t *ci, const double *v, int csc, sprs_csr **out) {
-    SPRS_GUARD_BEGIN return csr_create_host<double, int64_t>(c, nr, nc, nnz, rp, ci, v, csc, out); SPRS_GUARD_END
+
+// ------------------------------------------------------------------------------ solver handles
+// one opaque handle layout for the three solver kinds: { dtype, impl }
+template <template <class> class S, class F>
+int with_solver(int dtype, void *impl, F &&f) {
+    switch (dtype) {
+        case DT_D: return f((S<double> *)impl);
+        case DT_Z: return f((S<cplx> *)impl);
+        case DT_S: return f((S<float> *)impl);
+        case DT_C: return f((S<cplxf> *)impl);
+    }
+    return SPRS_INVALID_ARGUMENT;
 }
-int sprs_csr_create_i64_z(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int64_t *rp, const int64_t *ci, const sprs_c64 *v, int csc, sprs_csr **out) {
-    SPRS_GUARD_BEGIN return csr_create_host<cplx, int64_t>(c, nr, nc, nnz, rp, ci, (const cplx *)v, csc, out); SPRS_GUARD_END
+
+template <class T, class H, template <class> class S, class Mk>
+int solver_create(const sprs_csr *A, size_t size, H **out, Mk mk) {
+    if (!A || !out) return SPRS_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (A->dtype != dtype_of<T>::value) return SPRS_INVALID_ARGUMENT;
+    // the solvers multiply size-vectors by A in place: the reference leaves a mismatch to UB
+    // (mul_vec_unchecked); we refuse it here rather than index out of bounds on the GPU
+    if ((int64_t)size != A->nrows || (A->dist ? A->ncols < A->nrows : (int64_t)size != A->ncols)) return SPRS_DIM_MISMATCH;
+    H *h = new H();
+    h->dtype = dtype_of<T>::value;
+    auto *s = new S<T>();
+    h->impl = s;
+    int st = mk(s);
+    if (st != SPRS_OK) { s->destroy(); delete s; delete h; return st; }
+    *out = h;
+    return SPRS_OK;
 }
-int sprs_csr_create_dev_d(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int32_t *rp, const int32_t *ci, const double *v, int adopt, sprs_csr **out) {
-    SPRS_GUARD_BEGIN return csr_create_dev<double>(c, nr, nc, nnz, rp, ci, v, adopt, out); SPRS_GUARD_END
+
+template <class H, template <class> class S>
+int solver_destroy(H *h) {
+    if (!h) return SPRS_OK;
+    with_solver<S>(h->dtype, h->impl, [](auto *s) { (void)hipStreamSynchronize(s->ctx->stream); s->destroy(); delete s; return (int)SPRS_OK; });
+    delete h;
+    return SPRS_OK;
 }
-int sprs_csr_create_dev_z(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int32_t *rp, const int32_t *ci, const sprs_c64 *v, int adopt, sprs_csr **out) {
-    SPRS_GUARD_BEGIN return csr_create_dev<cplx>(c, nr, nc, nnz, rp, ci, (const cplx *)v, adopt, out); SPRS_GUARD_END
+
+// host-slice solve: copy rhs/x in, run the device solve, copy x back
+template <class T, class SolverT>
+int solve_host(SolverT *s, const sprs_diag *P, const T *rhs, size_t rl, T *x, size_t xl, size_t max_iter, Real<T> tol,
+               size_t *its, Real<T> *res) {
+    if (!s || !rhs || !x) return SPRS_INVALID_ARGUMENT;
+    return s->solve_host(rhs, rl, x, xl, [&](T *drhs, T *dx) {
+        return s->solve_dev(P, drhs, rl, dx, xl, max_iter, tol, its, res);
+    });
 }
+
+// device-vector solve; stage through aligned buffers when the caller's vectors are not 16-byte aligned
+template <class T, class SolverT>
+int solve_dev(SolverT *s, const sprs_diag *P, const T *rhs, size_t rl, T *x, size_t xl, size_t max_iter, Real<T> tol,
+              size_t *its, Real<T> *res) {
+    if (!s || !rhs || !x) return SPRS_INVALID_ARGUMENT;
+    if (rl != s->n) return SPRS_INCOMPATIBLE_RHS_SIZE;
+    if (xl != s->n) return SPRS_INCOMPATIBLE_X_SIZE;
+    sprs_ctx *c = s->ctx;
+    const bool al = ((reinterpret_cast<uintptr_t>(rhs) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+    if (al) return s->solve_dev(P, rhs, rl, x, xl, max_iter, tol, its, res);
+    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    if (!s->rhs_buf) SPRS_HIP_TRY(c, hipMalloc((void **)&s->rhs_buf, sizeof(T) * s->stride));
+    if (!s->x_buf) SPRS_HIP_TRY(c, hipMalloc((void **)&s->x_buf, sizeof(T) * s->stride));
+    SPRS_HIP_TRY(c, hipMemcpyAsync(s->rhs_buf, rhs, sizeof(T) * rl, hipMemcpyDeviceToDevice, c->stream));
+    SPRS_HIP_TRY(c, hipMemcpyAsync(s->x_buf, x, sizeof(T) * xl, hipMemcpyDeviceToDevice, c->stream));
+    int st = s->solve_dev(P, s->rhs_buf, rl, s->x_buf, xl, max_iter, tol, its, res);
+    if (st >= SPRS_ERR_HIP) return st;
+    SPRS_HIP_TRY(c, hipMemcpyAsync(x, s->x_buf, sizeof(T) * xl, hipMemcpyDeviceToDevice, c->stream));
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return st;
+}
+
+template <class T, class H> BicgStab<T> *bi(H *h) { return (h && h->dtype == dtype_of<T>::value) ? (BicgStab<T> *)h->impl : nullptr; }
+template <class T, class H> MinRes<T> *mr(H *h) { return (h && h->dtype == dtype_of<T>::value) ? (MinRes<T> *)h->impl : nullptr; }
+
+}  // namespace
+
+struct sprs_bicgstab; struct sprs_minres; struct sprs_csminres;
+static int base_of(void *solver, int kind, int *dtype, void **impl) {
+    if (!solver) return SPRS_INVALID_ARGUMENT;
+    if (kind == SPRS_SOLVER_BICGSTAB) { auto *h = (sprs_bicgstab *)solver; *dtype = h->dtype; *impl = h->impl; }
+    else if (kind == SPRS_SOLVER_MINRES) { auto *h = (sprs_minres *)solver; *dtype = h->dtype; *impl = h->impl; }
+    else if (kind == SPRS_SOLVER_CSMINRES) { auto *h = (sprs_csminres *)solver; *dtype = h->dtype; *impl = h->impl; }
+    else return SPRS_INVALID_ARGUMENT;
+    return SPRS_OK;
+}
+// every solver impl derives from KrylovBase<T>
+template <class F>
+static int with_base(void *solver, int kind, F &&f) {
+    int dt; void *impl;
+    SPRS_TRY(base_of(solver, kind, &dt, &impl));
+    if (kind == SPRS_SOLVER_BICGSTAB)
+        return with_solver<BicgStab>(dt, impl, [&](auto *s) { return f(s); });
+    return with_solver<MinRes>(dt, impl, [&](auto *s) { return f(s); });
+}
+
+
+#define SPRS_CHK(c) do { if (!(c)) return SPRS_INVALID_ARGUMENT; } while (0)
+#define SPRS_G(...) try { __VA_ARGS__ } catch (...) { return SPRS_ERR_HIP; }
+
+extern "C" {
 
 int sprs_csr_destroy(sprs_csr *A) {
     if (!A) return SPRS_OK;
@@ -382,114 +514,6 @@ int64_t sprs_csr_rows(const sprs_csr *A) { return A ? A->nrows : -1; }
 int64_t sprs_csr_cols(const sprs_csr *A) { return A ? A->ncols : -1; }
 int64_t sprs_csr_nnz(const sprs_csr *A) { return A ? A->nnz : -1; }
 
-int sprs_mul_vec_d(const sprs_csr *A, const double *x, size_t xl, double *y, size_t yl) {
-    SPRS_GUARD_BEGIN return mul_vec_host<double>(A, x, xl, y, yl, nullptr); SPRS_GUARD_END
-}
-int sprs_mul_vec_z(const sprs_csr *A, const sprs_c64 *x, size_t xl, sprs_c64 *y, size_t yl) {
-    SPRS_GUARD_BEGIN return mul_vec_host<cplx>(A, (const cplx *)x, xl, (cplx *)y, yl, nullptr); SPRS_GUARD_END
-}
-int sprs_mul_vec_dot_d(const sprs_csr *A, const double *x, size_t xl, double *y, size_t yl, double *d) {
-    SPRS_GUARD_BEGIN if (!d) return SPRS_INVALID_ARGUMENT; return mul_vec_host<double>(A, x, xl, y, yl, d); SPRS_GUARD_END
-}
-int sprs_mul_vec_dot_z(const sprs_csr *A, const sprs_c64 *x, size_t xl, sprs_c64 *y, size_t yl, sprs_c64 *d) {
-    SPRS_GUARD_BEGIN if (!d) return SPRS_INVALID_ARGUMENT; return mul_vec_host<cplx>(A, (const cplx *)x, xl, (cplx *)y, yl, (cplx *)d); SPRS_GUARD_END
-}
-int sprs_mul_vec_dev_d(const sprs_csr *A, const double *x, double *y) { return mul_vec_dev<double>(A, x, y, nullptr); }
-int sprs_mul_vec_dev_z(const sprs_csr *A, const sprs_c64 *x, sprs_c64 *y) { return mul_vec_dev<cplx>(A, (const cplx *)x, (cplx *)y, nullptr); }
-int sprs_mul_vec_dot_dev_d(const sprs_csr *A, const double *x, double *y, double *d) {
-    if (!d) return SPRS_INVALID_ARGUMENT;
-    return mul_vec_dev<double>(A, x, y, d);
-}
-int sprs_mul_vec_dot_dev_z(const sprs_csr *A, const sprs_c64 *x, sprs_c64 *y, sprs_c64 *d) {
-    if (!d) return SPRS_INVALID_ARGUMENT;
-    return mul_vec_dev<cplx>(A, (const cplx *)x, (cplx *)y, (cplx *)d);
-}
-int sprs_mul_vec_dev_timed_d(const sprs_csr *A, const double *x, double *y, int reps, double *ms) { return mul_vec_timed<double>(A, x, y, reps, ms); }
-int sprs_mul_vec_dev_timed_z(const sprs_csr *A, const sprs_c64 *x, sprs_c64 *y, int reps, double *ms) {
-    return mul_vec_timed<cplx>(A, (const cplx *)x, (cplx *)y, reps, ms);
-}
-
-// ------------------------------------------------------------------------------ vecalg
-#define SPRS_CHK(c) do { if (!(c)) return SPRS_INVALID_ARGUMENT; } while (0)
-static inline cplx cz(sprs_c64 a) { return cplx{a.re, a.im}; }
-
-int sprs_dot_d(sprs_ctx *c, size_t n, const double *x, const double *y, double *o) { SPRS_CHK(c && o); return dot_host<double>(c, n, x, y, false, o); }
-int sprs_dot_z(sprs_ctx *c, size_t n, const sprs_c64 *x, const sprs_c64 *y, sprs_c64 *o) { SPRS_CHK(c && o); return dot_host<cplx>(c, n, (const cplx *)x, (const cplx *)y, false, (cplx *)o); }
-int sprs_conj_dot_d(sprs_ctx *c, size_t n, const double *x, const double *y, double *o) { SPRS_CHK(c && o); return dot_host<double>(c, n, x, y, true, o); }
-int sprs_conj_dot_z(sprs_ctx *c, size_t n, const sprs_c64 *x, const sprs_c64 *y, sprs_c64 *o) { SPRS_CHK(c && o); return dot_host<cplx>(c, n, (const cplx *)x, (const cplx *)y, true, (cplx *)o); }
-int sprs_norm2_d(sprs_ctx *c, size_t n, const double *x, double *o) { SPRS_CHK(c && o); return norm2_host<double>(c, n, x, o); }
-int sprs_norm2_z(sprs_ctx *c, size_t n, const sprs_c64 *x, double *o) { SPRS_CHK(c && o); return norm2_host<cplx>(c, n, (const cplx *)x, o); }
-int sprs_scale_d(sprs_ctx *c, size_t n, double a, double *x) { SPRS_CHK(c); return launch_scale<double>(c, n, a, x); }
-int sprs_scale_z(sprs_ctx *c, size_t n, sprs_c64 a, sprs_c64 *x) { SPRS_CHK(c); return launch_scale<cplx>(c, n, cz(a), (cplx *)x); }
-int sprs_rscale_d(sprs_ctx *c, size_t n, double a, double *x) { SPRS_CHK(c); return launch_rscale<double>(c, n, a, x); }
-int sprs_rscale_z(sprs_ctx *c, size_t n, double a, sprs_c64 *x) { SPRS_CHK(c); return launch_rscale<cplx>(c, n, a, (cplx *)x); }
-int sprs_conj_d(sprs_ctx *c, size_t n, const double *in, double *out) { SPRS_CHK(c); return launch_conj<double>(c, n, in, out); }
-int sprs_conj_z(sprs_ctx *c, size_t n, const sprs_c64 *in, sprs_c64 *out) { SPRS_CHK(c); return launch_conj<cplx>(c, n, (const cplx *)in, (cplx *)out); }
-int sprs_axpy_d(sprs_ctx *c, size_t n, double a, const double *x, double *y) { SPRS_CHK(c); return launch_axpy<double, double>(c, n, a, x, y); }
-int sprs_axpy_z(sprs_ctx *c, size_t n, sprs_c64 a, const sprs_c64 *x, sprs_c64 *y) { SPRS_CHK(c); return launch_axpy<cplx, cplx>(c, n, cz(a), (const cplx *)x, (cplx *)y); }
-int sprs_axpy_zd(sprs_ctx *c, size_t n, double a, const sprs_c64 *x, sprs_c64 *y) { SPRS_CHK(c); return launch_axpy<cplx, double>(c, n, a, (const cplx *)x, (cplx *)y); }
-int sprs_axpby_d(sprs_ctx *c, size_t n, double a, const double *x, double b, double *y) { SPRS_CHK(c); return launch_axpby<double>(c, n, a, x, b, y); }
-int sprs_axpby_z(sprs_ctx *c, size_t n, sprs_c64 a, const sprs_c64 *x, sprs_c64 b, sprs_c64 *y) { SPRS_CHK(c); return launch_axpby<cplx>(c, n, cz(a), (const cplx *)x, cz(b), (cplx *)y); }
-
-}  // extern "C"
-
-// ------------------------------------------------------------------------------ Jacobi preconditioner
-namespace {
-template <class V>
-int diag_create(sprs_ctx *c, size_t n, const V *diag_host, int t_complex, sprs_diag **out) {
-    if (!c || !out || (!diag_host && n)) return SPRS_INVALID_ARGUMENT;
-    *out = nullptr;
-    SPRS_HIP_TRY(c, hipSetDevice(c->device));
-    sprs_diag *P = new sprs_diag();
-    P->ctx = c; P->n = n; P->t_complex = t_complex; P->v_complex = is_complex<V>::value ? 1 : 0;
-    auto fail = [&](int st) { sprs_diag_precond_destroy(P); return st; };
-    V *tmp = nullptr;
-    const size_t np = ((n + 31) & ~(size_t)31) + 32;
-    if (hipMalloc(&P->dinv, sizeof(V) * np) != hipSuccess) return fail(SPRS_ERR_HIP);
-    if (hipMalloc((void **)&tmp, sizeof(V) * np) != hipSuccess) return fail(SPRS_ERR_HIP);
-    int st = SPRS_OK;
-    if (hipMemcpyAsync(tmp, diag_host, sizeof(V) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) st = SPRS_ERR_HIP;
-    if (st == SPRS_OK) st = launch_diag_inv<V>(c, n, tmp, (V *)P->dinv);   // precond.rs:22-24
-    if (st == SPRS_OK && hipStreamSynchronize(c->stream) != hipSuccess) st = SPRS_ERR_HIP;
-    (void)hipFree(tmp);
-    if (st != SPRS_OK) return fail(st);
-    *out = P;
-    return SPRS_OK;
-}
-
-template <class T>
-int diag_apply_dev(const sprs_diag *P, const T *in, T *out) {
-    if (!P || !in || !out) return SPRS_INVALID_ARGUMENT;
-    if (P->t_complex != (is_complex<T>::value ? 1 : 0)) return SPRS_INVALID_ARGUMENT;
-    if (P->v_complex) {
-        if constexpr (is_complex<T>::value) return launch_diag_apply<cplx, cplx>(P->ctx, P->n, (const cplx *)P->dinv, in, out);
-        else return SPRS_INVALID_ARGUMENT;
-    }
-    return launch_diag_apply<T, double>(P->ctx, P->n, (const double *)P->dinv, in, out);
-}
-
-template <class T>
-int diag_apply_host(const sprs_diag *Pc, const T *in, size_t in_len, T *out, size_t out_len) {
-    if (!Pc || !in || !out) return SPRS_INVALID_ARGUMENT;
-    if (Pc->n != in_len || Pc->n != out_len) return SPRS_DIM_MISMATCH;     // precond.rs:39-41
-    sprs_diag *P = const_cast<sprs_diag *>(Pc);
-    sprs_ctx *c = P->ctx;
-    SPRS_HIP_TRY(c, hipSetDevice(c->device));
-    if (!P->in_tmp) SPRS_HIP_TRY(c, hipMalloc(&P->in_tmp, sizeof(T) * (P->n + 2)));
-    if (!P->out_tmp) SPRS_HIP_TRY(c, hipMalloc(&P->out_tmp, sizeof(T) * (P->n + 2)));
-    SPRS_HIP_TRY(c, hipMemcpyAsync(P->in_tmp, in, sizeof(T) * in_len, hipMemcpyHostToDevice, c->stream));
-    SPRS_TRY(diag_apply_dev<T>(P, (const T *)P->in_tmp, (T *)P->out_tmp));
-    SPRS_HIP_TRY(c, hipMemcpyAsync(out, P->out_tmp, sizeof(T) * out_len, hipMemcpyDeviceToHost, c->stream));
-    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return SPRS_OK;
-}
-}  // namespace
-
-extern "C" {
-
-int sprs_diag_precond_create_d(sprs_ctx *c, size_t n, const double *d, sprs_diag **out) { SPRS_GUARD_BEGIN return diag_create<double>(c, n, d, 0, out); SPRS_GUARD_END }
-int sprs_diag_precond_create_zd(sprs_ctx *c, size_t n, const double *d, sprs_diag **out) { SPRS_GUARD_BEGIN return diag_create<double>(c, n, d, 1, out); SPRS_GUARD_END }
-int sprs_diag_precond_create_z(sprs_ctx *c, size_t n, const sprs_c64 *d, sprs_diag **out) { SPRS_GUARD_BEGIN return diag_create<cplx>(c, n, (const cplx *)d, 1, out); SPRS_GUARD_END }
 int sprs_diag_precond_destroy(sprs_diag *P) {
     if (!P) return SPRS_OK;
     if (P->ctx) { (void)hipSetDevice(P->ctx->device); (void)hipStreamSynchronize(P->ctx->stream); }
@@ -499,192 +523,127 @@ int sprs_diag_precond_destroy(sprs_diag *P) {
     delete P;
     return SPRS_OK;
 }
-int sprs_diag_mul_vec_d(const sprs_diag *P, const double *in, size_t il, double *out, size_t ol) { SPRS_GUARD_BEGIN return diag_apply_host<double>(P, in, il, out, ol); SPRS_GUARD_END }
-int sprs_diag_mul_vec_z(const sprs_diag *P, const sprs_c64 *in, size_t il, sprs_c64 *out, size_t ol) { SPRS_GUARD_BEGIN return diag_apply_host<cplx>(P, (const cplx *)in, il, (cplx *)out, ol); SPRS_GUARD_END }
-int sprs_diag_mul_vec_dev_d(const sprs_diag *P, const double *in, double *out) { return diag_apply_dev<double>(P, in, out); }
-int sprs_diag_mul_vec_dev_z(const sprs_diag *P, const sprs_c64 *in, sprs_c64 *out) { return diag_apply_dev<cplx>(P, (const cplx *)in, (cplx *)out); }
-
-}  // extern "C"
-
-// ------------------------------------------------------------------------------ solvers
-namespace {
-
-template <class H, template <class> class S, class Mk>
-int solver_create(const sprs_csr *A, size_t size, int want_complex, H **out, Mk mk) {
-    if (!A || !out) return SPRS_INVALID_ARGUMENT;
-    *out = nullptr;
-    if (A->is_complex != want_complex) return SPRS_INVALID_ARGUMENT;
-    // the solvers multiply size-vectors by A in place: the reference leaves a mismatch to UB
-    // (mul_vec_unchecked); we refuse it here rather than index out of bounds on the GPU
-    if ((int64_t)size != A->nrows || (A->dist ? A->ncols < A->nrows : (int64_t)size != A->ncols)) return SPRS_DIM_MISMATCH;
-    H *h = new H();
-    h->is_complex = want_complex;
-    int st;
-    if (want_complex) { auto *s = new S<cplx>(); h->impl = s; st = mk(s); }
-    else { auto *s = new S<double>(); h->impl = s; st = mk(s); }
-    if (st != SPRS_OK) {
-        if (want_complex) { auto *s = (S<cplx> *)h->impl; s->destroy(); delete s; }
-        else { auto *s = (S<double> *)h->impl; s->destroy(); delete s; }
-        delete h;
-        return st;
-    }
-    *out = h;
-    return SPRS_OK;
-}
-
-template <class H, template <class> class S>
-int solver_destroy(H *h) {
-    if (!h) return SPRS_OK;
-    if (h->is_complex) { auto *s = (S<cplx> *)h->impl; (void)hipStreamSynchronize(s->ctx->stream); s->destroy(); delete s; }
-    else { auto *s = (S<double> *)h->impl; (void)hipStreamSynchronize(s->ctx->stream); s->destroy(); delete s; }
-    delete h;
-    return SPRS_OK;
-}
-
-// host-slice solve: copy rhs/x in, run the device solve, copy x back
-template <class T, class SolverT>
-int solve_host(SolverT *s, const sprs_diag *P, const T *rhs, size_t rl, T *x, size_t xl, size_t max_iter, double tol,
-               size_t *its, double *res) {
-    if (!s || !rhs || !x) return SPRS_INVALID_ARGUMENT;
-    return s->solve_host(rhs, rl, x, xl, [&](T *drhs, T *dx) {
-        return s->solve_dev(P, drhs, rl, dx, xl, max_iter, tol, its, res);
-    });
-}
-
-// device-vector solve; stage through aligned buffers when the caller's vectors are not 16-byte aligned
-template <class T, class SolverT>
-int solve_dev(SolverT *s, const sprs_diag *P, const T *rhs, size_t rl, T *x, size_t xl, size_t max_iter, double tol,
-              size_t *its, double *res) {
-    if (!s || !rhs || !x) return SPRS_INVALID_ARGUMENT;
-    if (rl != s->n) return SPRS_INCOMPATIBLE_RHS_SIZE;
-    if (xl != s->n) return SPRS_INCOMPATIBLE_X_SIZE;
-    sprs_ctx *c = s->ctx;
-    const bool al = ((reinterpret_cast<uintptr_t>(rhs) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
-    if (al) return s->solve_dev(P, rhs, rl, x, xl, max_iter, tol, its, res);
-    SPRS_HIP_TRY(c, hipSetDevice(c->device));
-    if (!s->rhs_buf) SPRS_HIP_TRY(c, hipMalloc((void **)&s->rhs_buf, sizeof(T) * s->stride));
-    if (!s->x_buf) SPRS_HIP_TRY(c, hipMalloc((void **)&s->x_buf, sizeof(T) * s->stride));
-    SPRS_HIP_TRY(c, hipMemcpyAsync(s->rhs_buf, rhs, sizeof(T) * rl, hipMemcpyDeviceToDevice, c->stream));
-    SPRS_HIP_TRY(c, hipMemcpyAsync(s->x_buf, x, sizeof(T) * xl, hipMemcpyDeviceToDevice, c->stream));
-    int st = s->solve_dev(P, s->rhs_buf, rl, s->x_buf, xl, max_iter, tol, its, res);
-    if (st >= SPRS_ERR_HIP) return st;
-    SPRS_HIP_TRY(c, hipMemcpyAsync(x, s->x_buf, sizeof(T) * xl, hipMemcpyDeviceToDevice, c->stream));
-    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return st;
-}
-
-template <class T, class H> BicgStab<T> *bi(H *h) { return (h && h->is_complex == (is_complex<T>::value ? 1 : 0)) ? (BicgStab<T> *)h->impl : nullptr; }
-template <class T, class H> MinRes<T> *mr(H *h) { return (h && h->is_complex == (is_complex<T>::value ? 1 : 0)) ? (MinRes<T> *)h->impl : nullptr; }
-
-}  // namespace
-
-extern "C" {
-
-int sprs_bicgstab_create_d(const sprs_csr *A, size_t n, sprs_bicgstab **out) { SPRS_GUARD_BEGIN return solver_create<sprs_bicgstab, BicgStab>(A, n, 0, out, [&](auto *s) { return s->create(A, n); }); SPRS_GUARD_END }
-int sprs_bicgstab_create_z(const sprs_csr *A, size_t n, sprs_bicgstab **out) { SPRS_GUARD_BEGIN return solver_create<sprs_bicgstab, BicgStab>(A, n, 1, out, [&](auto *s) { return s->create(A, n); }); SPRS_GUARD_END }
 int sprs_bicgstab_destroy(sprs_bicgstab *S) { return solver_destroy<sprs_bicgstab, BicgStab>(S); }
-
-int sprs_bicgstab_solve_d(sprs_bicgstab *S, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN return solve_host<double>(bi<double>(S), nullptr, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-int sprs_bicgstab_solve_z(sprs_bicgstab *S, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN return solve_host<cplx>(bi<cplx>(S), nullptr, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-int sprs_bicgstab_precond_solve_d(sprs_bicgstab *S, const sprs_diag *P, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN if (!P) return SPRS_INVALID_ARGUMENT; return solve_host<double>(bi<double>(S), P, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-int sprs_bicgstab_precond_solve_z(sprs_bicgstab *S, const sprs_diag *P, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN if (!P) return SPRS_INVALID_ARGUMENT; return solve_host<cplx>(bi<cplx>(S), P, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-int sprs_bicgstab_solve_dev_d(sprs_bicgstab *S, const sprs_diag *P, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN return solve_dev<double>(bi<double>(S), P, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-int sprs_bicgstab_solve_dev_z(sprs_bicgstab *S, const sprs_diag *P, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN return solve_dev<cplx>(bi<cplx>(S), P, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-
-int sprs_minres_create_d(const sprs_csr *A, size_t n, sprs_minres **out) { SPRS_GUARD_BEGIN return solver_create<sprs_minres, MinRes>(A, n, 0, out, [&](auto *s) { return s->create(A, n, false); }); SPRS_GUARD_END }
-int sprs_minres_create_z(const sprs_csr *A, size_t n, sprs_minres **out) { SPRS_GUARD_BEGIN return solver_create<sprs_minres, MinRes>(A, n, 1, out, [&](auto *s) { return s->create(A, n, false); }); SPRS_GUARD_END }
 int sprs_minres_destroy(sprs_minres *S) { return solver_destroy<sprs_minres, MinRes>(S); }
-int sprs_minres_solve_d(sprs_minres *S, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN return solve_host<double>(mr<double>(S), nullptr, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-int sprs_minres_solve_z(sprs_minres *S, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN return solve_host<cplx>(mr<cplx>(S), nullptr, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-int sprs_minres_precond_solve_d(sprs_minres *S, const sprs_diag *P, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN if (!P) return SPRS_INVALID_ARGUMENT; return solve_host<double>(mr<double>(S), P, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-int sprs_minres_precond_solve_z(sprs_minres *S, const sprs_diag *P, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN if (!P) return SPRS_INVALID_ARGUMENT; return solve_host<cplx>(mr<cplx>(S), P, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-int sprs_minres_solve_dev_d(sprs_minres *S, const sprs_diag *P, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN return solve_dev<double>(mr<double>(S), P, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-int sprs_minres_solve_dev_z(sprs_minres *S, const sprs_diag *P, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN return solve_dev<cplx>(mr<cplx>(S), P, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-
-int sprs_csminres_create_z(const sprs_csr *A, size_t n, sprs_csminres **out) { SPRS_GUARD_BEGIN return solver_create<sprs_csminres, MinRes>(A, n, 1, out, [&](auto *s) { return s->create(A, n, true); }); SPRS_GUARD_END }
-int sprs_csminres_create_d(const sprs_csr *A, size_t n, sprs_csminres **out) { SPRS_GUARD_BEGIN return solver_create<sprs_csminres, MinRes>(A, n, 0, out, [&](auto *s) { return s->create(A, n, true); }); SPRS_GUARD_END }
 int sprs_csminres_destroy(sprs_csminres *S) { return solver_destroy<sprs_csminres, MinRes>(S); }
-int sprs_csminres_solve_z(sprs_csminres *S, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN return solve_host<cplx>(mr<cplx>(S), nullptr, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-int sprs_csminres_solve_d(sprs_csminres *S, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN return solve_host<double>(mr<double>(S), nullptr, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-int sprs_csminres_solve_dev_z(sprs_csminres *S, const sprs_c64 *rhs, size_t rl, sprs_c64 *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN return solve_dev<cplx>(mr<cplx>(S), nullptr, (const cplx *)rhs, rl, (cplx *)x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
-int sprs_csminres_solve_dev_d(sprs_csminres *S, const double *rhs, size_t rl, double *x, size_t xl, size_t mi, double tol, size_t *its, double *res) {
-    SPRS_GUARD_BEGIN return solve_dev<double>(mr<double>(S), nullptr, rhs, rl, x, xl, mi, tol, its, res); SPRS_GUARD_END
-}
+
+// ---- everything that exists once per scalar type.  X = suffix, T = device scalar, CT = C-ABI scalar
+// (passed by value / pointer), R = T::Real
+#define SPRS_API(X, T, CT, R)                                                                                          \
+    int sprs_csr_create_##X(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int32_t *rp, const int32_t *ci,    \
+                            const CT *v, int csc, sprs_csr **out) {                                                    \
+        SPRS_G(return csr_create_host<T, int32_t>(c, nr, nc, nnz, rp, ci, (const T *)v, csc, out);)                    \
+    }                                                                                                                  \
+    int sprs_csr_create_i64_##X(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int64_t *rp,                   \
+                                const int64_t *ci, const CT *v, int csc, sprs_csr **out) {                             \
+        SPRS_G(return csr_create_host<T, int64_t>(c, nr, nc, nnz, rp, ci, (const T *)v, csc, out);)                    \
+    }                                                                                                                  \
+    int sprs_csr_create_dev_##X(sprs_ctx *c, int64_t nr, int64_t nc, int64_t nnz, const int32_t *rp,                   \
+                                const int32_t *ci, const CT *v, int adopt, sprs_csr **out) {                           \
+        SPRS_G(return csr_create_dev<T>(c, nr, nc, nnz, rp, ci, (const T *)v, adopt, out);)                            \
+    }                                                                                                                  \
+    int sprs_mul_vec_##X(const sprs_csr *A, const CT *x, size_t xl, CT *y, size_t yl) {                                \
+        SPRS_G(return mul_vec_host<T>(A, (const T *)x, xl, (T *)y, yl, nullptr);)                                      \
+    }                                                                                                                  \
+    int sprs_mul_vec_dot_##X(const sprs_csr *A, const CT *x, size_t xl, CT *y, size_t yl, CT *d) {                     \
+        SPRS_G(if (!d) return SPRS_INVALID_ARGUMENT; return mul_vec_host<T>(A, (const T *)x, xl, (T *)y, yl, (T *)d);) \
+    }                                                                                                                  \
+    int sprs_mul_vec_dev_##X(const sprs_csr *A, const CT *x, CT *y) { return mul_vec_dev<T>(A, (const T *)x, (T *)y, nullptr); } \
+    int sprs_mul_vec_dot_dev_##X(const sprs_csr *A, const CT *x, CT *y, CT *d) {                                       \
+        if (!d) return SPRS_INVALID_ARGUMENT;                                                                          \
+        return mul_vec_dev<T>(A, (const T *)x, (T *)y, (T *)d);                                                        \
+    }                                                                                                                  \
+    int sprs_mul_vec_dev_timed_##X(const sprs_csr *A, const CT *x, CT *y, int reps, double *ms) {                      \
+        return mul_vec_timed<T>(A, (const T *)x, (T *)y, reps, ms);                                                    \
+    }                                                                                                                  \
+    int sprs_dot_##X(sprs_ctx *c, size_t n, const CT *x, const CT *y, CT *o) { SPRS_CHK(c && o); return dot_host<T>(c, n, (const T *)x, (const T *)y, false, (T *)o); } \
+    int sprs_conj_dot_##X(sprs_ctx *c, size_t n, const CT *x, const CT *y, CT *o) { SPRS_CHK(c && o); return dot_host<T>(c, n, (const T *)x, (const T *)y, true, (T *)o); } \
+    int sprs_norm2_##X(sprs_ctx *c, size_t n, const CT *x, R *o) { SPRS_CHK(c && o); return norm2_host<T>(c, n, (const T *)x, o); } \
+    int sprs_scale_##X(sprs_ctx *c, size_t n, CT a, CT *x) { SPRS_CHK(c); T aa; memcpy(&aa, &a, sizeof(T)); return launch_scale<T>(c, n, aa, (T *)x); } \
+    int sprs_rscale_##X(sprs_ctx *c, size_t n, R a, CT *x) { SPRS_CHK(c); return launch_rscale<T>(c, n, a, (T *)x); }  \
+    int sprs_conj_##X(sprs_ctx *c, size_t n, const CT *in, CT *out) { SPRS_CHK(c); return launch_conj<T>(c, n, (const T *)in, (T *)out); } \
+    int sprs_axpy_##X(sprs_ctx *c, size_t n, CT a, const CT *x, CT *y) { SPRS_CHK(c); T aa; memcpy(&aa, &a, sizeof(T)); return launch_axpy<T, T>(c, n, aa, (const T *)x, (T *)y); } \
+    int sprs_axpby_##X(sprs_ctx *c, size_t n, CT a, const CT *x, CT b, CT *y) {                                        \
+        SPRS_CHK(c); T aa, bb; memcpy(&aa, &a, sizeof(T)); memcpy(&bb, &b, sizeof(T));                                 \
+        return launch_axpby<T>(c, n, aa, (const T *)x, bb, (T *)y);                                                    \
+    }                                                                                                                  \
+    int sprs_diag_mul_vec_##X(const sprs_diag *P, const CT *in, size_t il, CT *out, size_t ol) {                       \
+        SPRS_G(return diag_apply_host<T>(P, (const T *)in, il, (T *)out, ol);)                                         \
+    }                                                                                                                  \
+    int sprs_diag_mul_vec_dev_##X(const sprs_diag *P, const CT *in, CT *out) { return diag_apply_dev<T>(P, (const T *)in, (T *)out); } \
+    int sprs_bicgstab_create_##X(const sprs_csr *A, size_t n, sprs_bicgstab **out) {                                   \
+        SPRS_G(return (solver_create<T, sprs_bicgstab, BicgStab>(A, n, out, [&](auto *s) { return s->create(A, n); }));) \
+    }                                                                                                                  \
+    int sprs_minres_create_##X(const sprs_csr *A, size_t n, sprs_minres **out) {                                       \
+        SPRS_G(return (solver_create<T, sprs_minres, MinRes>(A, n, out, [&](auto *s) { return s->create(A, n, false); }));) \
+    }                                                                                                                  \
+    int sprs_csminres_create_##X(const sprs_csr *A, size_t n, sprs_csminres **out) {                                   \
+        SPRS_G(return (solver_create<T, sprs_csminres, MinRes>(A, n, out, [&](auto *s) { return s->create(A, n, true); }));) \
+    }                                                                                                                  \
+    int sprs_bicgstab_solve_##X(sprs_bicgstab *S, const CT *rhs, size_t rl, CT *x, size_t xl, size_t mi, R tol, size_t *its, R *res) { \
+        SPRS_G(return solve_host<T>(bi<T>(S), nullptr, (const T *)rhs, rl, (T *)x, xl, mi, tol, its, res);)            \
+    }                                                                                                                  \
+    int sprs_bicgstab_precond_solve_##X(sprs_bicgstab *S, const sprs_diag *P, const CT *rhs, size_t rl, CT *x, size_t xl, size_t mi, R tol, size_t *its, R *res) { \
+        SPRS_G(if (!P) return SPRS_INVALID_ARGUMENT; return solve_host<T>(bi<T>(S), P, (const T *)rhs, rl, (T *)x, xl, mi, tol, its, res);) \
+    }                                                                                                                  \
+    int sprs_bicgstab_solve_dev_##X(sprs_bicgstab *S, const sprs_diag *P, const CT *rhs, size_t rl, CT *x, size_t xl, size_t mi, R tol, size_t *its, R *res) { \
+        SPRS_G(return solve_dev<T>(bi<T>(S), P, (const T *)rhs, rl, (T *)x, xl, mi, tol, its, res);)                   \
+    }                                                                                                                  \
+    int sprs_minres_solve_##X(sprs_minres *S, const CT *rhs, size_t rl, CT *x, size_t xl, size_t mi, R tol, size_t *its, R *res) { \
+        SPRS_G(return solve_host<T>(mr<T>(S), nullptr, (const T *)rhs, rl, (T *)x, xl, mi, tol, its, res);)            \
+    }                                                                                                                  \
+    int sprs_minres_precond_solve_##X(sprs_minres *S, const sprs_diag *P, const CT *rhs, size_t rl, CT *x, size_t xl, size_t mi, R tol, size_t *its, R *res) { \
+        SPRS_G(if (!P) return SPRS_INVALID_ARGUMENT; return solve_host<T>(mr<T>(S), P, (const T *)rhs, rl, (T *)x, xl, mi, tol, its, res);) \
+    }                                                                                                                  \
+    int sprs_minres_solve_dev_##X(sprs_minres *S, const sprs_diag *P, const CT *rhs, size_t rl, CT *x, size_t xl, size_t mi, R tol, size_t *its, R *res) { \
+        SPRS_G(return solve_dev<T>(mr<T>(S), P, (const T *)rhs, rl, (T *)x, xl, mi, tol, its, res);)                   \
+    }                                                                                                                  \
+    int sprs_csminres_solve_##X(sprs_csminres *S, const CT *rhs, size_t rl, CT *x, size_t xl, size_t mi, R tol, size_t *its, R *res) { \
+        SPRS_G(return solve_host<T>(mr<T>(S), nullptr, (const T *)rhs, rl, (T *)x, xl, mi, tol, its, res);)            \
+    }                                                                                                                  \
+    int sprs_csminres_solve_dev_##X(sprs_csminres *S, const CT *rhs, size_t rl, CT *x, size_t xl, size_t mi, R tol, size_t *its, R *res) { \
+        SPRS_G(return solve_dev<T>(mr<T>(S), nullptr, (const T *)rhs, rl, (T *)x, xl, mi, tol, its, res);)             \
+    }
+
+SPRS_API(d, double, double, double)
+SPRS_API(z, cplx, sprs_c64, double)
+SPRS_API(s, float, float, float)
+SPRS_API(c, cplxf, sprs_c32, float)
+
+// complex vector, real scalar (S = Real, T = Complex; vecalg.rs:746-757)
+int sprs_axpy_zd(sprs_ctx *c, size_t n, double a, const sprs_c64 *x, sprs_c64 *y) { SPRS_CHK(c); return launch_axpy<cplx, double>(c, n, a, (const cplx *)x, (cplx *)y); }
+int sprs_axpy_cs(sprs_ctx *c, size_t n, float a, const sprs_c32 *x, sprs_c32 *y) { SPRS_CHK(c); return launch_axpy<cplxf, float>(c, n, a, (const cplxf *)x, (cplxf *)y); }
+
+// DiagPrecond<T, V>::new  (precond.rs:20-29)
+int sprs_diag_precond_create_d(sprs_ctx *c, size_t n, const double *d, sprs_diag **out) { SPRS_G(return diag_create<double>(c, n, d, DT_D, out);) }
+int sprs_diag_precond_create_zd(sprs_ctx *c, size_t n, const double *d, sprs_diag **out) { SPRS_G(return diag_create<double>(c, n, d, DT_Z, out);) }
+int sprs_diag_precond_create_z(sprs_ctx *c, size_t n, const sprs_c64 *d, sprs_diag **out) { SPRS_G(return diag_create<cplx>(c, n, (const cplx *)d, DT_Z, out);) }
+int sprs_diag_precond_create_s(sprs_ctx *c, size_t n, const float *d, sprs_diag **out) { SPRS_G(return diag_create<float>(c, n, d, DT_S, out);) }
+int sprs_diag_precond_create_cs(sprs_ctx *c, size_t n, const float *d, sprs_diag **out) { SPRS_G(return diag_create<float>(c, n, d, DT_C, out);) }
+int sprs_diag_precond_create_c(sprs_ctx *c, size_t n, const sprs_c32 *d, sprs_diag **out) { SPRS_G(return diag_create<cplxf>(c, n, (const cplxf *)d, DT_C, out);) }
 
 // ------------------------------------------------------------------------------ options / instrumentation
-// Every solver impl derives from KrylovBase<T>; pick the right instantiation from the handle.
-#define SPRS_WITH_BASE(solver, kind, body)                                                    \
-    do {                                                                                      \
-        if (!(solver)) return SPRS_INVALID_ARGUMENT;                                          \
-        int cx; void *impl;                                                                   \
-        if ((kind) == SPRS_SOLVER_BICGSTAB) { auto *h = (sprs_bicgstab *)(solver); cx = h->is_complex; impl = h->impl; } \
-        else if ((kind) == SPRS_SOLVER_MINRES) { auto *h = (sprs_minres *)(solver); cx = h->is_complex; impl = h->impl; } \
-        else if ((kind) == SPRS_SOLVER_CSMINRES) { auto *h = (sprs_csminres *)(solver); cx = h->is_complex; impl = h->impl; } \
-        else return SPRS_INVALID_ARGUMENT;                                                    \
-        if ((kind) == SPRS_SOLVER_BICGSTAB) {                                                 \
-            if (cx) { KrylovBase<cplx> *b = (BicgStab<cplx> *)impl; body; }                   \
-            else { KrylovBase<double> *b = (BicgStab<double> *)impl; body; }                  \
-        } else {                                                                              \
-            if (cx) { KrylovBase<cplx> *b = (MinRes<cplx> *)impl; body; }                     \
-            else { KrylovBase<double> *b = (MinRes<double> *)impl; body; }                    \
-        }                                                                                     \
-    } while (0)
-
 int sprs_solver_set_mode(void *solver, int kind, int mode) {
     if (mode != 0 && mode != 1) return SPRS_INVALID_ARGUMENT;
-    SPRS_WITH_BASE(solver, kind, b->mode = mode);
-    return SPRS_OK;
+    return with_base(solver, kind, [&](auto *b) { b->mode = mode; return (int)SPRS_OK; });
 }
 int sprs_solver_set_trace(void *solver, int kind, double *trace_host, size_t cap) {
-    SPRS_WITH_BASE(solver, kind, { b->trace = trace_host; b->trace_cap = trace_host ? cap : 0; b->trace_rows = 0; });
-    return SPRS_OK;
+    return with_base(solver, kind, [&](auto *b) { b->trace = trace_host; b->trace_cap = trace_host ? cap : 0; b->trace_rows = 0; return (int)SPRS_OK; });
 }
 int sprs_solver_trace_rows(const void *solver, int kind, size_t *rows_out) {
     if (!rows_out) return SPRS_INVALID_ARGUMENT;
-    SPRS_WITH_BASE(const_cast<void *>(solver), kind, *rows_out = b->trace_rows);
-    return SPRS_OK;
+    return with_base(const_cast<void *>(solver), kind, [&](auto *b) { *rows_out = b->trace_rows; return (int)SPRS_OK; });
 }
 int sprs_solver_set_profile(void *solver, int kind, int enable) {
-    SPRS_WITH_BASE(solver, kind, b->profile = enable ? 1 : 0);
-    return SPRS_OK;
+    return with_base(solver, kind, [&](auto *b) { b->profile = enable ? 1 : 0; return (int)SPRS_OK; });
 }
 int sprs_solver_get_profile(const void *solver, int kind, double *spmv_ms, int64_t *launches, double *solve_ms) {
-    SPRS_WITH_BASE(const_cast<void *>(solver), kind, {
+    return with_base(const_cast<void *>(solver), kind, [&](auto *b) {
         if (spmv_ms) *spmv_ms = b->stats.spmv_ms;
         if (launches) *launches = b->stats.spmv_launches;
         if (solve_ms) *solve_ms = b->stats.solve_ms;
+        return (int)SPRS_OK;
     });
-    return SPRS_OK;
 }
 
 }  // extern "C"

@@ -22,6 +22,20 @@ __device__ __forceinline__ cplx wave_sum(cplx v) {
     return v;
 }
 
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) v = v + __shfl_down(v, off, WAVE);
+    return v;
+}
+__device__ __forceinline__ cplxf wave_sum(cplxf v) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) {
+        v.re = v.re + __shfl_down(v.re, off, WAVE);
+        v.im = v.im + __shfl_down(v.im, off, WAVE);
+    }
+    return v;
+}
+
 // Sum over the workgroup; every thread returns the same value.  Fixed order: butterfly inside
 // each wavefront, then wave 0..3 left to right.  `smem` needs NWAVE elements; safe to call
 // back-to-back with the same buffer.

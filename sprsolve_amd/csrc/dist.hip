@@ -79,10 +79,10 @@ __global__ __launch_bounds__(sprs::BLOCK) void pack_kernel(int64_t n, const int3
 
 namespace sprs {
 
-int allreduce_sum(sprs_comm *comm, double *dev, size_t count) {
+int allreduce_sum(sprs_comm *comm, void *dev, size_t count, bool f32) {
     if (!comm) return SPRS_OK;
     sprs_ctx *c = comm->ctx;
-    SPRS_NCCL_TRY(c, rccl().AllReduce(dev, dev, count, ncclDouble, ncclSum, (ncclComm_t)comm->nccl, c->stream));
+    SPRS_NCCL_TRY(c, rccl().AllReduce(dev, dev, count, f32 ? ncclFloat : ncclDouble, ncclSum, (ncclComm_t)comm->nccl, c->stream));
     return SPRS_OK;
 }
 
@@ -101,13 +101,14 @@ static int halo_issue(const sprs_csr *A, T *x, hipStream_t pack_stream, hipStrea
         SPRS_HIP_TRY(c, hipEventRecord(D->ev_pack, pack_stream));
         SPRS_HIP_TRY(c, hipStreamWaitEvent(xfer_stream, D->ev_pack, 0));
     }
-    constexpr size_t W = sizeof(T) / sizeof(double);   // complex travels as 2 doubles
+    constexpr size_t W = sizeof(T) / sizeof(Real<T>);   // complex travels as 2 reals
+    const ncclDataType_t NT_ = sizeof(Real<T>) == 4 ? ncclFloat : ncclDouble;
     ncclComm_t comm = (ncclComm_t)D->comm->nccl;
     SPRS_NCCL_TRY(c, rccl().GroupStart());
     for (size_t p = 0; p < D->peer.size(); ++p) {
         const int64_t ns = D->send_off[p + 1] - D->send_off[p], nr = D->recv_off[p + 1] - D->recv_off[p];
-        if (ns > 0) SPRS_NCCL_TRY(c, rccl().Send(buf + D->send_off[p], (size_t)ns * W, ncclDouble, D->peer[p], comm, xfer_stream));
-        if (nr > 0) SPRS_NCCL_TRY(c, rccl().Recv(x + D->n_local + D->recv_off[p], (size_t)nr * W, ncclDouble, D->peer[p], comm, xfer_stream));
+        if (ns > 0) SPRS_NCCL_TRY(c, rccl().Send(buf + D->send_off[p], (size_t)ns * W, NT_, D->peer[p], comm, xfer_stream));
+        if (nr > 0) SPRS_NCCL_TRY(c, rccl().Recv(x + D->n_local + D->recv_off[p], (size_t)nr * W, NT_, D->peer[p], comm, xfer_stream));
     }
     SPRS_NCCL_TRY(c, rccl().GroupEnd());
     if (xfer_stream != pack_stream) SPRS_HIP_TRY(c, hipEventRecord(D->ev_halo, xfer_stream));
@@ -137,8 +138,12 @@ int halo_wait(const sprs_csr *A) {
 }
 template int halo_begin<double>(const sprs_csr *, double *);
 template int halo_begin<cplx>(const sprs_csr *, cplx *);
+template int halo_begin<float>(const sprs_csr *, float *);
+template int halo_begin<cplxf>(const sprs_csr *, cplxf *);
 template int halo_exchange<double>(const sprs_csr *, double *);
 template int halo_exchange<cplx>(const sprs_csr *, cplx *);
+template int halo_exchange<float>(const sprs_csr *, float *);
+template int halo_exchange<cplxf>(const sprs_csr *, cplxf *);
 
 // y = A_local x_ext with the halo exchange; overlapped with the interior rows when the operator was
 // split at creation.  Dot partials of the two launches are concatenated (spmv_num_partials()).
@@ -159,6 +164,8 @@ int dist_spmv(const sprs_csr *A, T *x_ext, T *y, int dot_mode, const T *u, T *pa
 }
 template int dist_spmv<double>(const sprs_csr *, double *, double *, int, const double *, double *, double *, const int *, bool);
 template int dist_spmv<cplx>(const sprs_csr *, cplx *, cplx *, int, const cplx *, cplx *, cplx *, const int *, bool);
+template int dist_spmv<float>(const sprs_csr *, float *, float *, int, const float *, float *, float *, const int *, bool);
+template int dist_spmv<cplxf>(const sprs_csr *, cplxf *, cplxf *, int, const cplxf *, cplxf *, cplxf *, const int *, bool);
 
 }  // namespace sprs
 
@@ -190,7 +197,9 @@ int dist_csr_create(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz
     }
     sprs_csr *A = nullptr;
     int st;
-    if constexpr (is_complex<T>::value) st = sprs_csr_create_dev_z(c, n_local, n_ext, nnz, d_rp, d_ci, (const sprs_c64 *)d_val, adopt, &A);
+    if constexpr (dtype_of<T>::value == DT_Z) st = sprs_csr_create_dev_z(c, n_local, n_ext, nnz, d_rp, d_ci, (const sprs_c64 *)d_val, adopt, &A);
+    else if constexpr (dtype_of<T>::value == DT_C) st = sprs_csr_create_dev_c(c, n_local, n_ext, nnz, d_rp, d_ci, (const sprs_c32 *)d_val, adopt, &A);
+    else if constexpr (dtype_of<T>::value == DT_S) st = sprs_csr_create_dev_s(c, n_local, n_ext, nnz, d_rp, d_ci, d_val, adopt, &A);
     else st = sprs_csr_create_dev_d(c, n_local, n_ext, nnz, d_rp, d_ci, d_val, adopt, &A);
     if (st != SPRS_OK) return st;
     sprs_dist_info *D = new sprs_dist_info();
@@ -275,35 +284,29 @@ int sprs_comm_destroy(sprs_comm *comm) {
 
 int sprs_comm_allreduce_sum_f64(sprs_comm *comm, double *dev, size_t count) {
     if (!comm || !dev) return SPRS_INVALID_ARGUMENT;
-    SPRS_TRY(allreduce_sum(comm, dev, count));
+    SPRS_TRY(allreduce_sum(comm, dev, count, false));
     SPRS_HIP_TRY(comm->ctx, hipStreamSynchronize(comm->ctx->stream));
     return SPRS_OK;
 }
 
-int sprs_dist_csr_create_dev_d(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz, const int32_t *rp,
-                               const int32_t *ci, const double *val, int adopt, int n_peers, const int32_t *peer_rank,
-                               const int64_t *send_off, const int32_t *send_idx_dev, const int64_t *recv_off,
-                               sprs_csr **out) {
-    try { return dist_csr_create<double>(comm, n_local, n_ext, nnz, rp, ci, val, adopt, n_peers, peer_rank, send_off, send_idx_dev, recv_off, out); }
-    catch (...) { return SPRS_ERR_HIP; }
-}
-int sprs_dist_csr_create_dev_z(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz, const int32_t *rp,
-                               const int32_t *ci, const sprs_c64 *val, int adopt, int n_peers, const int32_t *peer_rank,
-                               const int64_t *send_off, const int32_t *send_idx_dev, const int64_t *recv_off,
-                               sprs_csr **out) {
-    try { return dist_csr_create<cplx>(comm, n_local, n_ext, nnz, rp, ci, (const cplx *)val, adopt, n_peers, peer_rank, send_off, send_idx_dev, recv_off, out); }
-    catch (...) { return SPRS_ERR_HIP; }
-}
-
-// y_local = A_local * x_ext after exchanging the halo of x_ext (device vector of n_ext elements whose
-// first n_local entries are this rank's slice of x)
-int sprs_dist_mul_vec_dev_d(const sprs_csr *A, double *x_ext, double *y_local) {
-    if (!A || !A->dist || A->is_complex) return SPRS_INVALID_ARGUMENT;
-    return dist_spmv<double>(A, x_ext, y_local, 0, nullptr, nullptr, nullptr, nullptr, false);
-}
-int sprs_dist_mul_vec_dev_z(const sprs_csr *A, sprs_c64 *x_ext, sprs_c64 *y_local) {
-    if (!A || !A->dist || !A->is_complex) return SPRS_INVALID_ARGUMENT;
-    return dist_spmv<cplx>(A, (cplx *)x_ext, (cplx *)y_local, 0, nullptr, nullptr, nullptr, nullptr, false);
-}
+#define SPRS_DIST_API(X, T, CT)                                                                                          \
+    int sprs_dist_csr_create_dev_##X(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz, const int32_t *rp,    \
+                                     const int32_t *ci, const CT *val, int adopt, int n_peers, const int32_t *peer_rank, \
+                                     const int64_t *send_off, const int32_t *send_idx_dev, const int64_t *recv_off,      \
+                                     sprs_csr **out) {                                                                   \
+        try { return dist_csr_create<T>(comm, n_local, n_ext, nnz, rp, ci, (const T *)val, adopt, n_peers, peer_rank,    \
+                                        send_off, send_idx_dev, recv_off, out); }                                        \
+        catch (...) { return SPRS_ERR_HIP; }                                                                             \
+    }                                                                                                                    \
+    /* y_local = A_local * x_ext after exchanging the halo of x_ext (device vector of n_ext elements whose first        \
+       n_local entries are this rank's slice of x) */                                                                    \
+    int sprs_dist_mul_vec_dev_##X(const sprs_csr *A, CT *x_ext, CT *y_local) {                                           \
+        if (!A || !A->dist || A->dtype != dtype_of<T>::value) return SPRS_INVALID_ARGUMENT;                              \
+        return dist_spmv<T>(A, (T *)x_ext, (T *)y_local, 0, nullptr, nullptr, nullptr, nullptr, false);                  \
+    }
+SPRS_DIST_API(d, double, double)
+SPRS_DIST_API(z, cplx, sprs_c64)
+SPRS_DIST_API(s, float, float)
+SPRS_DIST_API(c, cplxf, sprs_c32)
 
 }  // extern "C"

@@ -89,7 +89,7 @@ struct sprs_dist_info {
 
 struct sprs_csr {
     sprs_ctx *ctx = nullptr;
-    int is_complex = 0;
+    int dtype = 0;               // sprs::DT_D / DT_Z / DT_S / DT_C
     int64_t nrows = 0, ncols = 0, nnz = 0;
     int32_t *row_ptr = nullptr;  // device
     int32_t *col_idx = nullptr;  // device
@@ -110,8 +110,8 @@ struct sprs_csr {
 
 struct sprs_diag {
     sprs_ctx *ctx = nullptr;
-    int t_complex = 0;  // T
-    int v_complex = 0;  // V
+    int t_dtype = 0;    // T (sprs::DT_*)
+    int v_complex = 0;  // V is complex (same precision as T)
     size_t n = 0;
     void *dinv = nullptr;  // device, V
     void *in_tmp = nullptr, *out_tmp = nullptr;
@@ -141,14 +141,14 @@ int spmv_subset_grid(const sprs_csr *A, int count);
 template <class T, class S> int launch_axpy(sprs_ctx *c, size_t n, S a, const T *x, T *y);
 template <class T> int launch_axpby(sprs_ctx *c, size_t n, T a, const T *x, T b, T *y);
 template <class T> int launch_scale(sprs_ctx *c, size_t n, T a, T *x);
-template <class T> int launch_rscale(sprs_ctx *c, size_t n, double a, T *x);
+template <class T> int launch_rscale(sprs_ctx *c, size_t n, Real<T> a, T *x);
 template <class T> int launch_conj(sprs_ctx *c, size_t n, const T *in, T *out);
 template <class T, class V> int launch_diag_apply(sprs_ctx *c, size_t n, const V *dinv, const T *in, T *out);
 template <class V> int launch_diag_inv(sprs_ctx *c, size_t n, const V *diag, V *dinv);
 // reductions: blocking, result returned to the host
 // comm != null: the locally reduced value is all-reduced over the ranks before it is returned
 template <class T> int dot_host(sprs_ctx *c, size_t n, const T *x, const T *y, bool conj, T *out, sprs_comm *comm = nullptr);
-template <class T> int norm2_host(sprs_ctx *c, size_t n, const T *x, double *out, sprs_comm *comm = nullptr);
+template <class T> int norm2_host(sprs_ctx *c, size_t n, const T *x, Real<T> *out, sprs_comm *comm = nullptr);
 // reduce `P` partials of T (or of double when T_is_real_partials) with the library's fixed order; blocking
 template <class T> int reduce_partials_host(sprs_ctx *c, const T *part, int P, T *out, sprs_comm *comm = nullptr);
 
@@ -161,7 +161,7 @@ template <class T> int halo_begin(const sprs_csr *A, T *x_ext);
 int halo_wait(const sprs_csr *A);
 template <class T>
 int dist_spmv(const sprs_csr *A, T *x_ext, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status, bool conj_x);
-int allreduce_sum(sprs_comm *comm, double *dev, size_t count);   // in place, on the ctx stream
+int allreduce_sum(sprs_comm *comm, void *dev, size_t count, bool f32 = false);   // in place, on the ctx stream; count elements of f64 (or f32)
 
 inline int grid_for(const sprs_ctx *c) {
     int g = c->grid;

@@ -26,7 +26,6 @@
 
 namespace sprs {
 
-static constexpr double EPS = DBL_EPSILON;  // T::Real::epsilon()
 
 // ======================================================================= fused kernel skeleton
 template <int PK, class F>
@@ -56,16 +55,16 @@ __device__ __forceinline__ bool first_thread() { return blockIdx.x == 0 && threa
 //   p = v*(-beta*w) + p*beta ;  p += r*1 ;  [y = M^-1 p]
 template <class T, class V, bool PC>
 struct BicgK1 {
-    BicgState<T> *S; const double *partN; const T *partRho; int P; int mode;
+    BicgState<T> *S; const Real<T> *partN; const T *partRho; int P; int mode;
     const T *v; const T *r; T *p; const V *dinv; T *y;
     T a, beta;
     __device__ __forceinline__ bool prologue() {
-        __shared__ double smD[NWAVE];
+        __shared__ Real<T> smD[NWAVE];
         __shared__ T smT[NWAVE];
         if (S->status != ST_RUNNING) return false;
-        T rho; double r_norm;
+        T rho; Real<T> r_norm;
         if (mode == 0) {
-            r_norm = sqrt(reduce_partials(partN, P, smD));          // :123
+            r_norm = ssqrt(reduce_partials(partN, P, smD));          // :123
             if (r_norm <= S->tol2) {                                // :124
                 if (first_thread()) { S->r_norm = r_norm; S->status = ST_CONVERGED; }
                 return false;
@@ -142,9 +141,9 @@ struct BicgK3 {
 template <class T, bool PC>
 struct BicgK5 {
     BicgState<T> *S; const T *partTT; const T *partTR; int P;
-    const T *y; const T *z; const T *t; const T *r0; T *x; T *r; double *partN; T *partRho;
+    const T *y; const T *z; const T *t; const T *r0; T *x; T *r; Real<T> *partN; T *partRho;
     T na, nw, w;
-    double accN; T accR;
+    Real<T> accN; T accR;
     __device__ __forceinline__ bool prologue() {
         __shared__ T smT[NWAVE];
         if (S->status != ST_RUNNING) return false;
@@ -174,9 +173,9 @@ struct BicgK5 {
         stp<T, PK>(r, i, rv);
     }
     __device__ __forceinline__ void epilogue() {
-        __shared__ double smD[NWAVE];
+        __shared__ Real<T> smD[NWAVE];
         __shared__ T smT[NWAVE];
-        const double sN = block_sum(accN, smD);
+        const Real<T> sN = block_sum(accN, smD);
         const T sR = block_sum(accR, smT);
         if (threadIdx.x == 0) { partN[blockIdx.x] = sN; partRho[blockIdx.x] = sR; }
         if (first_thread()) { S->w = w; S->rho_old = S->rho; S->its = S->its + 1; }
@@ -189,8 +188,8 @@ struct BicgK5 {
 template <class T, class V, bool PC>
 struct MinresM2 {
     MinresDev<T> *D; int par; const T *partAlpha; int P;
-    const T *v_old; const T *v; T *v_new; const V *dinv; T *w_new; double *partBeta; T *partBeta2;
-    T nb, na; double accD; T accT;
+    const T *v_old; const T *v; T *v_new; const V *dinv; T *w_new; Real<T> *partBeta; T *partBeta2;
+    T nb, na; Real<T> accD; T accT;
     __device__ __forceinline__ bool prologue() {
         __shared__ T smT[NWAVE];
         if (D->status != ST_RUNNING) return false;
@@ -222,13 +221,13 @@ struct MinresM2 {
         if (PC) stp<T, PK>(w_new, i, wv);
     }
     __device__ __forceinline__ void epilogue() {
-        __shared__ double smD[NWAVE];
+        __shared__ Real<T> smD[NWAVE];
         __shared__ T smT[NWAVE];
         if (PC) {
             const T s = block_sum(accT, smT);
             if (threadIdx.x == 0) partBeta2[blockIdx.x] = s;
         } else {
-            const double s = block_sum(accD, smD);
+            const Real<T> s = block_sum(accD, smD);
             if (threadIdx.x == 0) partBeta[blockIdx.x] = s;
         }
     }
@@ -239,33 +238,33 @@ struct MinresM2 {
 //     res_norm *= |s| ; converged?  eta *= -s
 template <class T, bool PC, bool SAUNDERS>
 struct MinresM3 {
-    MinresDev<T> *D; int par; long long its; const double *partBeta; const T *partBeta2; int P;
+    MinresDev<T> *D; int par; long long its; const Real<T> *partBeta; const T *partBeta2; int P;
     T *v_new; T *w_new; const T *q; const T *p_old; const T *p_oold; T *p; T *x;
-    double inv, r1_inv, beta_new, s_new; T nr2, nr3, coef, c_new;
+    Real<T> inv, r1_inv, beta_new, s_new; T nr2, nr3, coef, c_new;
     __device__ __forceinline__ bool prologue() {
-        __shared__ double smD[NWAVE];
+        __shared__ Real<T> smD[NWAVE];
         __shared__ T smT[NWAVE];
         if (D->status != ST_RUNNING) return false;
         const MinresState<T> &S = D->st[par];
         if (PC) {
             const T b2 = reduce_partials(partBeta2, P, smT);        // :278
-            if (sre(b2) < EPS || sim(b2) > EPS * sre(b2)) {         // :279-287
+            if (sre(b2) < seps<Real<T>>() || sim(b2) > seps<Real<T>>() * sre(b2)) {         // :279-287
                 if (first_thread()) { D->st[par].pc_re = sre(b2); D->its = its; D->status = ST_INVALID_PC; }
                 return false;
             }
-            beta_new = sqrt(sre(b2));                               // :288
+            beta_new = ssqrt(sre(b2));                               // :288
         } else {
-            beta_new = sqrt(reduce_partials(partBeta, P, smD));     // :120
+            beta_new = ssqrt(reduce_partials(partBeta, P, smD));     // :120
         }
-        inv = 1.0 / beta_new;                                       // :121 / :289
-        const double beta = S.beta;
+        inv = Real<T>(1) / beta_new;                                       // :121 / :289
+        const Real<T> beta = S.beta;
         const T c = S.c, c_old = S.c_old, alpha = S.alpha;
-        const double s = S.s, s_old = S.s_old;
-        const double r3 = s_old * beta;                                                    // :132
+        const Real<T> s = S.s, s_old = S.s_old;
+        const Real<T> r3 = s_old * beta;                                                    // :132
         const T tr = smulr(SAUNDERS ? sconj(c_old) : c_old, beta);                         // :133 / cs:120
         const T r2 = sadd(smulr(alpha, s), smul(c, tr));                                   // :134
         const T r1_hat = ssub(smul(SAUNDERS ? sconj(c) : c, alpha), smulr(tr, s));         // :136 / cs:122
-        r1_inv = 1.0 / sqrt(ssq(r1_hat) + beta_new * beta_new);                            // :139-140
+        r1_inv = Real<T>(1) / ssqrt(ssq(r1_hat) + beta_new * beta_new);                            // :139-140
         c_new = smulr(SAUNDERS ? sconj(r1_hat) : r1_hat, r1_inv);                          // :147 / cs:133
         s_new = beta_new * r1_inv;                                                         // :148
         nr2 = sneg(r2); nr3 = sfromr<T>(-r3);
@@ -303,7 +302,7 @@ struct MinresM3 {
         N.c = c_new; N.s = s_new;                                   // :147-148
         N.alpha = S.alpha;
         N.beta = beta_new; N.beta_one = S.beta_one; N.threshold = S.threshold;
-        N.res_norm = S.res_norm * fabs(s_new);                      // :164
+        N.res_norm = S.res_norm * sabs(s_new);                      // :164
         N.eta = smulr(S.eta, -s_new);                               // :168
         N.pc_re = 0.0; N.pad0 = 0.0;
         D->st[par ^ 1] = N;
@@ -322,9 +321,9 @@ int KrylovBase<T>::init(const sprs_csr *A_, size_t size, int nvec_) {
     SPRS_HIP_TRY(ctx, hipMalloc((void **)&work, sizeof(T) * stride * (size_t)nvec));
     SPRS_HIP_TRY(ctx, hipMemsetAsync(work, 0, sizeof(T) * stride * (size_t)nvec, ctx->stream));   // vec![T::zero(); size*7]
     SPRS_HIP_TRY(ctx, hipMalloc((void **)&part, sizeof(T) * MAX_GRID * 8));
-    SPRS_HIP_TRY(ctx, hipMalloc((void **)&partD, sizeof(double) * MAX_GRID * 4));
+    SPRS_HIP_TRY(ctx, hipMalloc((void **)&partD, sizeof(Real<T>) * MAX_GRID * 4));
     SPRS_HIP_TRY(ctx, hipMemsetAsync(part, 0, sizeof(T) * MAX_GRID * 8, ctx->stream));
-    SPRS_HIP_TRY(ctx, hipMemsetAsync(partD, 0, sizeof(double) * MAX_GRID * 4, ctx->stream));
+    SPRS_HIP_TRY(ctx, hipMemsetAsync(partD, 0, sizeof(Real<T>) * MAX_GRID * 4, ctx->stream));
     if (A->dist) {
         SPRS_HIP_TRY(ctx, hipMalloc((void **)&red, sizeof(double) * 32));
         SPRS_HIP_TRY(ctx, hipMemsetAsync(red, 0, sizeof(double) * 32, ctx->stream));
@@ -378,7 +377,7 @@ int KrylovBase<T>::red1(const T *a, int P, int slot, PartT *oa) {
     double *ra = red + 2 * slot;
     hipLaunchKernelGGL((finalize2_kernel<T, T>), dim3(1), dim3(BLOCK), 0, ctx->stream, a, (const T *)nullptr, P, ra, ra);
     SPRS_HIP_TRY(ctx, hipGetLastError());
-    SPRS_TRY(allreduce_sum(comm(), ra, 2));
+    SPRS_TRY(allreduce_sum(comm(), ra, 16 / sizeof(Real<T>), sizeof(Real<T>) == 4));
     *oa = PartT{reinterpret_cast<const T *>(ra), 1};
     return SPRS_OK;
 }
@@ -388,29 +387,29 @@ int KrylovBase<T>::red2(const T *a, const T *b, int P, int slot, PartT *oa, Part
     double *ra = red + 2 * slot, *rb = red + 2 * slot + 2;
     hipLaunchKernelGGL((finalize2_kernel<T, T>), dim3(1), dim3(BLOCK), 0, ctx->stream, a, b, P, ra, rb);
     SPRS_HIP_TRY(ctx, hipGetLastError());
-    SPRS_TRY(allreduce_sum(comm(), ra, 4));
+    SPRS_TRY(allreduce_sum(comm(), ra, 32 / sizeof(Real<T>), sizeof(Real<T>) == 4));
     *oa = PartT{reinterpret_cast<const T *>(ra), 1};
     *ob = PartT{reinterpret_cast<const T *>(rb), 1};
     return SPRS_OK;
 }
 template <class T>
-int KrylovBase<T>::redD1(const double *a, int P, int slot, PartD *oa) {
+int KrylovBase<T>::redD1(const Real<T> *a, int P, int slot, PartD *oa) {
     if (!A->dist) { *oa = PartD{a, P}; return SPRS_OK; }
     double *ra = red + 2 * slot;
-    hipLaunchKernelGGL((finalize2_kernel<double, double>), dim3(1), dim3(BLOCK), 0, ctx->stream, a, (const double *)nullptr, P, ra, ra);
+    hipLaunchKernelGGL((finalize2_kernel<Real<T>, Real<T>>), dim3(1), dim3(BLOCK), 0, ctx->stream, a, (const Real<T> *)nullptr, P, ra, ra);
     SPRS_HIP_TRY(ctx, hipGetLastError());
-    SPRS_TRY(allreduce_sum(comm(), ra, 2));
-    *oa = PartD{ra, 1};
+    SPRS_TRY(allreduce_sum(comm(), ra, 16 / sizeof(Real<T>), sizeof(Real<T>) == 4));
+    *oa = PartD{reinterpret_cast<const Real<T> *>(ra), 1};
     return SPRS_OK;
 }
 template <class T>
-int KrylovBase<T>::redDT(const double *a, const T *b, int P, int slot, PartD *oa, PartT *ob) {
+int KrylovBase<T>::redDT(const Real<T> *a, const T *b, int P, int slot, PartD *oa, PartT *ob) {
     if (!A->dist) { *oa = PartD{a, P}; *ob = PartT{b, P}; return SPRS_OK; }
     double *ra = red + 2 * slot, *rb = red + 2 * slot + 2;
-    hipLaunchKernelGGL((finalize2_kernel<double, T>), dim3(1), dim3(BLOCK), 0, ctx->stream, a, b, P, ra, rb);
+    hipLaunchKernelGGL((finalize2_kernel<Real<T>, T>), dim3(1), dim3(BLOCK), 0, ctx->stream, a, b, P, ra, rb);
     SPRS_HIP_TRY(ctx, hipGetLastError());
-    SPRS_TRY(allreduce_sum(comm(), ra, 4));
-    *oa = PartD{ra, 1};
+    SPRS_TRY(allreduce_sum(comm(), ra, 32 / sizeof(Real<T>), sizeof(Real<T>) == 4));
+    *oa = PartD{reinterpret_cast<const Real<T> *>(ra), 1};
     *ob = PartT{reinterpret_cast<const T *>(rb), 1};
     return SPRS_OK;
 }
@@ -521,20 +520,20 @@ void BicgStab<T>::destroy() {
 
 template <class T>
 template <class V>
-int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out, double *res_out) {
+int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> tol, size_t *its_out, Real<T> *res_out) {
     sprs_ctx *c = this->ctx;
     const size_t n = this->n;
     const bool pc = dinv != nullptr;
     *its_out = 0; *res_out = 0.0;
 
-    double rhs_norm = 0.0;
+    Real<T> rhs_norm = 0.0;
     SPRS_TRY(this->norm2(rhs, &rhs_norm));                          // :55
-    if (rhs_norm <= EPS) {                                          // :56-60
+    if (rhs_norm <= seps<Real<T>>()) {                                          // :56-60
         SPRS_TRY(dzero(c, x, n));
         *its_out = 0; *res_out = rhs_norm;
         return SPRS_OK;
     }
-    const double tol2 = tol * rhs_norm;                             // :61
+    const Real<T> tol2 = tol * rhs_norm;                             // :61
 
     // :64-69 / :234-241
     T *r = this->vec(0), *r0 = this->vec(1), *y = this->vec(2);
@@ -547,13 +546,13 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double 
     SPRS_TRY(this->spmv(x, r, 0, nullptr, nullptr, nullptr, nullptr));      // :73
     SPRS_TRY((launch_axpy<T, T>(c, n, sneg(sone<T>()), rhs, r)));           // :75
     SPRS_TRY(dcopy(c, r0, r, n));                                           // :78
-    double r0_norm = 0.0;
+    Real<T> r0_norm = 0.0;
     SPRS_TRY(this->norm2(r0, &r0_norm));                                    // :80
     if (r0_norm <= tol2) {                                                  // :81-83
         *its_out = 0; *res_out = r0_norm / rhs_norm;
         return SPRS_OK;
     }
-    double r0_norm_tol = r0_norm * EPS;                                     // :84
+    Real<T> r0_norm_tol = r0_norm * seps<Real<T>>();                                     // :84
     r0_norm_tol = r0_norm_tol * r0_norm_tol;                                // :85
 
     BicgState<T> &H = *h_state;
@@ -567,7 +566,7 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double 
 
     const int G = this->ew_grid();
     const int GS = spmv_num_partials(this->A);
-    double *partN = this->dslot(0);
+    Real<T> *partN = this->dslot(0);
     T *partRho = this->pslot(0), *partB = this->pslot(1), *partTT = this->pslot(2), *partTR = this->pslot(3);
 
     typename KrylovBase<T>::PartT qB{partB, GS}, qTT{partTT, GS}, qTR{partTR, GS}, qRho{partRho, G};
@@ -639,10 +638,10 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double 
                 SPRS_TRY(this->spmv(x, r, 0, nullptr, nullptr, nullptr, nullptr));  // :134
                 SPRS_TRY((launch_axpy<T, T>(c, n, sneg(sone<T>()), rhs, r)));       // :137
                 SPRS_TRY(dcopy(c, r0, r, n));                                       // :140
-                double rn = 0.0;
+                Real<T> rn = 0.0;
                 SPRS_TRY(this->norm2(r, &rn));                                      // :142
                 H.rho = sfromr<T>(rn * rn);                                         // :143
-                H.r0_norm_tol = sre(H.rho) * EPS * EPS;                             // :144
+                H.r0_norm_tol = sre(H.rho) * seps<Real<T>>() * seps<Real<T>>();                             // :144
                 H.status = ST_RUNNING;
                 SPRS_HIP_TRY(c, hipMemcpyAsync(d_state, &H, sizeof(H), hipMemcpyHostToDevice, c->stream));
                 its = (size_t)H.its;       // every kernel after the request was a no-op: redo from here
@@ -660,16 +659,16 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double 
 // literal mode: the reference's op list, one kernel per op, host-consumed scalars
 template <class T>
 template <class V>
-int BicgStab<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out,
-                             double *res_out) {
+int BicgStab<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> tol, size_t *its_out,
+                             Real<T> *res_out) {
     sprs_ctx *c = this->ctx;
     const size_t n = this->n;
     const bool pc = dinv != nullptr;
     *its_out = 0; *res_out = 0.0;
-    double rhs_norm = 0.0;
+    Real<T> rhs_norm = 0.0;
     SPRS_TRY(this->norm2(rhs, &rhs_norm));
-    if (rhs_norm <= EPS) { SPRS_TRY(dzero(c, x, n)); *res_out = rhs_norm; return SPRS_OK; }
-    const double tol2 = tol * rhs_norm;
+    if (rhs_norm <= seps<Real<T>>()) { SPRS_TRY(dzero(c, x, n)); *res_out = rhs_norm; return SPRS_OK; }
+    const Real<T> tol2 = tol * rhs_norm;
     T *r = this->vec(0), *r0 = this->vec(1), *y = this->vec(2);
     T *p = pc ? this->vec(3) : y;
     T *v = pc ? this->vec(4) : this->vec(3);
@@ -683,10 +682,10 @@ int BicgStab<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter,
     SPRS_TRY(mv(x, r));
     SPRS_TRY(axpy(sneg(sone<T>()), rhs, r));
     SPRS_TRY(dcopy(c, r0, r, n));
-    double r0_norm = 0.0;
+    Real<T> r0_norm = 0.0;
     SPRS_TRY(this->norm2(r0, &r0_norm));
     if (r0_norm <= tol2) { *res_out = r0_norm / rhs_norm; return SPRS_OK; }
-    double r0_norm_tol = r0_norm * EPS;
+    Real<T> r0_norm_tol = r0_norm * seps<Real<T>>();
     r0_norm_tol = r0_norm_tol * r0_norm_tol;
     T rho = sfromr<T>(r0_norm * r0_norm);
     if (pc) { SPRS_TRY(dcopy(c, p, r, n)); SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, p, y))); }
@@ -706,7 +705,7 @@ int BicgStab<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter,
     SPRS_TRY(axpy(sneg(w), t, r));
     this->trace_row(0.0, r0_norm, rho, alpha, w);
     for (size_t its = 1; its < max_iter; ++its) {
-        double r_norm = 0.0;
+        Real<T> r_norm = 0.0;
         SPRS_TRY(this->norm2(r, &r_norm));
         if (r_norm <= tol2) { *its_out = its; *res_out = r_norm / rhs_norm; return SPRS_OK; }
         const T rho_old = rho;
@@ -715,10 +714,10 @@ int BicgStab<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter,
             SPRS_TRY(mv(x, r));
             SPRS_TRY(axpy(sneg(sone<T>()), rhs, r));
             SPRS_TRY(dcopy(c, r0, r, n));
-            double rn = 0.0;
+            Real<T> rn = 0.0;
             SPRS_TRY(this->norm2(r, &rn));
             rho = sfromr<T>(rn * rn);
-            r0_norm_tol = sre(rho) * EPS * EPS;
+            r0_norm_tol = sre(rho) * seps<Real<T>>() * seps<Real<T>>();
         }
         const T beta = smul(sdiv(rho, rho_old), sdiv(alpha, w));
         SPRS_TRY(launch_axpby<T>(c, n, smul(sneg(beta), w), v, beta, p));
@@ -747,14 +746,14 @@ template <class T>
 static int check_diag(const sprs_diag *P, size_t n) {
     if (!P) return SPRS_OK;
     if (P->n != n) return SPRS_DIM_MISMATCH;
-    if (P->t_complex != (is_complex<T>::value ? 1 : 0)) return SPRS_INVALID_ARGUMENT;
+    if (P->t_dtype != dtype_of<T>::value) return SPRS_INVALID_ARGUMENT;
     return SPRS_OK;
 }
 
 template <class T>
 int BicgStab<T>::solve_dev(const sprs_diag *P, const T *rhs, size_t rhs_len, T *x, size_t x_len, size_t max_iter,
-                           double tol, size_t *its_out, double *res_out) {
-    size_t its_dummy; double res_dummy;
+                           Real<T> tol, size_t *its_out, Real<T> *res_out) {
+    size_t its_dummy; Real<T> res_dummy;
     if (!its_out) its_out = &its_dummy;
     if (!res_out) res_out = &res_dummy;
     if (rhs_len != this->n) return SPRS_INCOMPATIBLE_RHS_SIZE;             // :44-48
@@ -765,16 +764,16 @@ int BicgStab<T>::solve_dev(const sprs_diag *P, const T *rhs, size_t rhs_len, T *
     const bool lit = this->mode == 1;
     if (P && P->v_complex) {
         if constexpr (is_complex<T>::value) {
-            const cplx *d = (const cplx *)P->dinv;
-            st = lit ? run_literal<cplx>(d, rhs, x, max_iter, tol, its_out, res_out)
-                     : run<cplx>(d, rhs, x, max_iter, tol, its_out, res_out);
+            const T *d = (const T *)P->dinv;
+            st = lit ? run_literal<T>(d, rhs, x, max_iter, tol, its_out, res_out)
+                     : run<T>(d, rhs, x, max_iter, tol, its_out, res_out);
         } else {
             return SPRS_INVALID_ARGUMENT;
         }
     } else {
-        const double *d = P ? (const double *)P->dinv : nullptr;
-        st = lit ? run_literal<double>(d, rhs, x, max_iter, tol, its_out, res_out)
-                 : run<double>(d, rhs, x, max_iter, tol, its_out, res_out);
+        const Real<T> *d = P ? (const Real<T> *)P->dinv : nullptr;
+        st = lit ? run_literal<Real<T>>(d, rhs, x, max_iter, tol, its_out, res_out)
+                 : run<Real<T>>(d, rhs, x, max_iter, tol, its_out, res_out);
     }
     if (st >= SPRS_ERR_HIP) return st;
     SPRS_TRY(this->end_solve());
@@ -800,17 +799,17 @@ void MinRes<T>::destroy() {
 
 template <class T>
 template <class V>
-int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out, double *res_out) {
+int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> tol, size_t *its_out, Real<T> *res_out) {
     sprs_ctx *c = this->ctx;
     const size_t n = this->n;
     const bool pc = dinv != nullptr;
     const bool sau = saunders && is_complex<T>::value;   // conj() is the identity on real data
     *its_out = 0; *res_out = 0.0;
 
-    double rhs_norm = 0.0;
+    Real<T> rhs_norm = 0.0;
     SPRS_TRY(this->norm2(rhs, &rhs_norm));                          // :51
-    if (rhs_norm <= EPS) { SPRS_TRY(dzero(c, x, n)); *res_out = rhs_norm; return SPRS_OK; }   // :52-56
-    const double threshold = tol * rhs_norm;                                // :57
+    if (rhs_norm <= seps<Real<T>>()) { SPRS_TRY(dzero(c, x, n)); *res_out = rhs_norm; return SPRS_OK; }   // :52-56
+    const Real<T> threshold = tol * rhs_norm;                                // :57
 
     T *v_old = this->vec(0), *v_new = this->vec(1), *v = this->vec(2);      // :68-70
     T *p_old = this->vec(3), *p_oold = this->vec(4), *p = this->vec(5);     // :71-73
@@ -819,24 +818,24 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double to
     SPRS_TRY(dcopy(c, v_new, rhs, n));                                      // :77
     SPRS_TRY(this->spmv(x, v_old, 0, nullptr, nullptr, nullptr, nullptr));  // :78
     SPRS_TRY((launch_axpy<T, T>(c, n, sneg(sone<T>()), v_old, v_new)));     // :80
-    double res_norm = 0.0;
+    Real<T> res_norm = 0.0;
     SPRS_TRY(this->norm2(v_new, &res_norm));                        // :81
-    double beta_new;
+    Real<T> beta_new;
     if (pc) {
         SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, v_new, w_new)));      // :233
         T b2;
         SPRS_TRY(this->cdot(v_new, w_new, &b2));               // :235
-        if (sre(b2) < EPS || sim(b2) > EPS * sre(b2)) {                     // :236-244
+        if (sre(b2) < seps<Real<T>>() || sim(b2) > seps<Real<T>>() * sre(b2)) {                     // :236-244
             *its_out = 0; *res_out = sre(b2);
             return SPRS_INVALID_PRECOND;
         }
-        beta_new = sqrt(sre(b2));                                           // :245
-        const double ts = 1.0 / beta_new;                                   // :248
+        beta_new = ssqrt(sre(b2));                                           // :245
+        const Real<T> ts = Real<T>(1) / beta_new;                                   // :248
         SPRS_TRY(launch_rscale<T>(c, n, ts, v_new));                        // :249
         SPRS_TRY(launch_rscale<T>(c, n, ts, w_new));                        // :250
     } else {
         beta_new = res_norm;                                                // :82
-        SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, v_new));            // :84
+        SPRS_TRY(launch_rscale<T>(c, n, Real<T>(1) / beta_new, v_new));            // :84
     }
     SPRS_TRY(dzero(c, v, n)); SPRS_TRY(dzero(c, p_old, n)); SPRS_TRY(dzero(c, p, n));   // :86-88
 
@@ -855,7 +854,7 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double to
     const int G = this->ew_grid();
     const int GS = spmv_num_partials(this->A);
     T *partAlpha = this->pslot(0), *partBeta2 = this->pslot(1);
-    double *partBeta = this->dslot(0);
+    Real<T> *partBeta = this->dslot(0);
 
     auto fetch = [&]() -> int {
         SPRS_HIP_TRY(c, hipMemcpyAsync(&H, d_state, sizeof(H), hipMemcpyDeviceToHost, c->stream));
@@ -927,19 +926,19 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, double to
 
 template <class T>
 template <class V>
-int MinRes<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out,
-                           double *res_out) {
+int MinRes<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> tol, size_t *its_out,
+                           Real<T> *res_out) {
     sprs_ctx *c = this->ctx;
     const size_t n = this->n;
     const bool pc = dinv != nullptr;
     const bool sau = saunders;
     *its_out = 0; *res_out = 0.0;
-    double rhs_norm = 0.0;
+    Real<T> rhs_norm = 0.0;
     SPRS_TRY(this->norm2(rhs, &rhs_norm));
-    if (rhs_norm <= EPS) { SPRS_TRY(dzero(c, x, n)); *res_out = rhs_norm; return SPRS_OK; }
-    const double threshold = tol * rhs_norm;
+    if (rhs_norm <= seps<Real<T>>()) { SPRS_TRY(dzero(c, x, n)); *res_out = rhs_norm; return SPRS_OK; }
+    const Real<T> threshold = tol * rhs_norm;
     T cc = sone<T>(), c_old = sone<T>(), eta = sone<T>();
-    double s = 0.0, s_old = 0.0;
+    Real<T> s = 0.0, s_old = 0.0;
     T *v_old = this->vec(0), *v_new = this->vec(1), *v = this->vec(2);
     T *p_old = this->vec(3), *p_oold = this->vec(4), *p = this->vec(5);
     T *w = this->vec(6), *w_new = this->vec(7), *tvec = this->vec(6);
@@ -948,24 +947,24 @@ int MinRes<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, d
     SPRS_TRY(dcopy(c, v_new, rhs, n));
     SPRS_TRY(mv(x, v_old));
     SPRS_TRY(axpy(sneg(sone<T>()), v_old, v_new));
-    double res_norm = 0.0;
+    Real<T> res_norm = 0.0;
     SPRS_TRY(this->norm2(v_new, &res_norm));
-    double beta_new, beta_one;
+    Real<T> beta_new, beta_one;
     if (pc) {
         SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, v_new, w_new)));
         T b2;
         SPRS_TRY(this->cdot(v_new, w_new, &b2));
-        if (sre(b2) < EPS || sim(b2) > EPS * sre(b2)) { *res_out = sre(b2); return SPRS_INVALID_PRECOND; }
-        beta_new = sqrt(sre(b2)); beta_one = beta_new;
-        SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, v_new));
-        SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, w_new));
+        if (sre(b2) < seps<Real<T>>() || sim(b2) > seps<Real<T>>() * sre(b2)) { *res_out = sre(b2); return SPRS_INVALID_PRECOND; }
+        beta_new = ssqrt(sre(b2)); beta_one = beta_new;
+        SPRS_TRY(launch_rscale<T>(c, n, Real<T>(1) / beta_new, v_new));
+        SPRS_TRY(launch_rscale<T>(c, n, Real<T>(1) / beta_new, w_new));
     } else {
         beta_new = res_norm; beta_one = beta_new;
-        SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, v_new));
+        SPRS_TRY(launch_rscale<T>(c, n, Real<T>(1) / beta_new, v_new));
     }
     SPRS_TRY(dzero(c, v, n)); SPRS_TRY(dzero(c, p_old, n)); SPRS_TRY(dzero(c, p, n));
     for (size_t its = 0; its < max_iter; ++its) {
-        const double beta = beta_new;
+        const Real<T> beta = beta_new;
         { T *tp = v_old; v_old = v; v = v_new; v_new = tp; }
         T alpha;
         const T *q;
@@ -990,19 +989,19 @@ int MinRes<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, d
             SPRS_TRY((launch_diag_apply<T, V>(c, n, dinv, v_new, w_new)));
             T b2;
             SPRS_TRY(this->cdot(v_new, w_new, &b2));
-            if (sre(b2) < EPS || sim(b2) > EPS * sre(b2)) { *its_out = its; *res_out = sre(b2); return SPRS_INVALID_PRECOND; }
-            beta_new = sqrt(sre(b2));
-            SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, v_new));
-            SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, w_new));
+            if (sre(b2) < seps<Real<T>>() || sim(b2) > seps<Real<T>>() * sre(b2)) { *its_out = its; *res_out = sre(b2); return SPRS_INVALID_PRECOND; }
+            beta_new = ssqrt(sre(b2));
+            SPRS_TRY(launch_rscale<T>(c, n, Real<T>(1) / beta_new, v_new));
+            SPRS_TRY(launch_rscale<T>(c, n, Real<T>(1) / beta_new, w_new));
         } else {
             SPRS_TRY(this->norm2(v_new, &beta_new));
-            SPRS_TRY(launch_rscale<T>(c, n, 1.0 / beta_new, v_new));
+            SPRS_TRY(launch_rscale<T>(c, n, Real<T>(1) / beta_new, v_new));
         }
-        const double r3 = s_old * beta;
+        const Real<T> r3 = s_old * beta;
         const T tr = smulr(sau ? sconj(c_old) : c_old, beta);
         const T r2 = sadd(smulr(alpha, s), smul(cc, tr));
         const T r1_hat = ssub(smul(sau ? sconj(cc) : cc, alpha), smulr(tr, s));
-        const double r1_inv = 1.0 / sqrt(ssq(r1_hat) + beta_new * beta_new);
+        const Real<T> r1_inv = Real<T>(1) / ssqrt(ssq(r1_hat) + beta_new * beta_new);
         c_old = cc; s_old = s;
         cc = smulr(sau ? sconj(r1_hat) : r1_hat, r1_inv);
         s = beta_new * r1_inv;
@@ -1012,7 +1011,7 @@ int MinRes<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, d
         SPRS_TRY(axpy(sfromr<T>(-r3), p_oold, p));
         SPRS_TRY(launch_rscale<T>(c, n, r1_inv, p));
         SPRS_TRY(axpy(smulr(smul(cc, eta), beta_one), p, x));
-        res_norm *= fabs(s);
+        res_norm *= sabs(s);
         this->trace_row((double)its, beta_new, alpha, cc, sfromr<T>(s));
         if (this->trace && this->trace_rows) this->trace[8 * (this->trace_rows - 1) + 7] = res_norm;
         if (res_norm < threshold) { *its_out = its; *res_out = res_norm / rhs_norm; return SPRS_OK; }
@@ -1024,8 +1023,8 @@ int MinRes<T>::run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, d
 
 template <class T>
 int MinRes<T>::solve_dev(const sprs_diag *P, const T *rhs, size_t rhs_len, T *x, size_t x_len, size_t max_iter,
-                         double tol, size_t *its_out, double *res_out) {
-    size_t its_dummy; double res_dummy;
+                         Real<T> tol, size_t *its_out, Real<T> *res_out) {
+    size_t its_dummy; Real<T> res_dummy;
     if (!its_out) its_out = &its_dummy;
     if (!res_out) res_out = &res_dummy;
     if (rhs_len != this->n) return SPRS_INCOMPATIBLE_RHS_SIZE;             // minres.rs:40-44
@@ -1037,16 +1036,16 @@ int MinRes<T>::solve_dev(const sprs_diag *P, const T *rhs, size_t rhs_len, T *x,
     const bool lit = this->mode == 1;
     if (P && P->v_complex) {
         if constexpr (is_complex<T>::value) {
-            const cplx *d = (const cplx *)P->dinv;
-            st = lit ? run_literal<cplx>(d, rhs, x, max_iter, tol, its_out, res_out)
-                     : run<cplx>(d, rhs, x, max_iter, tol, its_out, res_out);
+            const T *d = (const T *)P->dinv;
+            st = lit ? run_literal<T>(d, rhs, x, max_iter, tol, its_out, res_out)
+                     : run<T>(d, rhs, x, max_iter, tol, its_out, res_out);
         } else {
             return SPRS_INVALID_ARGUMENT;
         }
     } else {
-        const double *d = P ? (const double *)P->dinv : nullptr;
-        st = lit ? run_literal<double>(d, rhs, x, max_iter, tol, its_out, res_out)
-                 : run<double>(d, rhs, x, max_iter, tol, its_out, res_out);
+        const Real<T> *d = P ? (const Real<T> *)P->dinv : nullptr;
+        st = lit ? run_literal<Real<T>>(d, rhs, x, max_iter, tol, its_out, res_out)
+                 : run<Real<T>>(d, rhs, x, max_iter, tol, its_out, res_out);
     }
     if (st >= SPRS_ERR_HIP) return st;
     SPRS_TRY(this->end_solve());
@@ -1054,10 +1053,16 @@ int MinRes<T>::solve_dev(const sprs_diag *P, const T *rhs, size_t rhs_len, T *x,
 }
 
 template class KrylovBase<double>;
+template class KrylovBase<float>;
+template class KrylovBase<cplxf>;
 template class KrylovBase<cplx>;
 template class BicgStab<double>;
+template class BicgStab<float>;
+template class BicgStab<cplxf>;
 template class BicgStab<cplx>;
 template class MinRes<double>;
+template class MinRes<float>;
+template class MinRes<cplxf>;
 template class MinRes<cplx>;
 
 }  // namespace sprs

@@ -8,7 +8,7 @@ namespace sprs {
 template <class T>
 struct BicgState {
     T rho, rho_old, alpha, w, beta;
-    double r_norm, r0_norm_tol, tol2, pad0;
+    Real<T> r_norm, r0_norm_tol, tol2, pad0;
     long long its;
     int status, pad1;
 };
@@ -19,7 +19,7 @@ struct BicgState {
 template <class T>
 struct MinresState {
     T c, c_old, eta, alpha;
-    double s, s_old, beta, beta_one, res_norm, threshold, pc_re, pad0;
+    Real<T> s, s_old, beta, beta_one, res_norm, threshold, pc_re, pad0;
 };
 template <class T>
 struct MinresDev {
@@ -43,7 +43,7 @@ class KrylovBase {
     T *work = nullptr;           // nvec * stride
     T *rhs_buf = nullptr, *x_buf = nullptr;
     T *part = nullptr;           // NSLOT * MAX_GRID partials of T
-    double *partD = nullptr;     // NSLOT * MAX_GRID real partials
+    Real<T> *partD = nullptr;    // NSLOT * MAX_GRID real partials
     int mode = 0;
     double *trace = nullptr;
     size_t trace_cap = 0, trace_rows = 0;
@@ -59,7 +59,7 @@ class KrylovBase {
     void destroy();
     T *vec(int i) { return work + (size_t)i * stride; }
     T *pslot(int s) { return part + (size_t)s * MAX_GRID; }
-    double *dslot(int s) { return partD + (size_t)s * MAX_GRID; }
+    Real<T> *dslot(int s) { return partD + (size_t)s * MAX_GRID; }
     int spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, const int *status, bool conj_x = false);
     int begin_solve();
     int end_solve();
@@ -73,12 +73,12 @@ class KrylovBase {
     // P partials itself.  Distributed: reduce locally (fixed order), all-reduce over the ranks, and
     // the consumer reads one value.  `slot` picks a 16-byte cell of `red`.
     struct PartT { const T *p; int P; };
-    struct PartD { const double *p; int P; };
+    struct PartD { const Real<T> *p; int P; };
     int red1(const T *a, int P, int slot, PartT *oa);
     int red2(const T *a, const T *b, int P, int slot, PartT *oa, PartT *ob);
-    int redD1(const double *a, int P, int slot, PartD *oa);
-    int redDT(const double *a, const T *b, int P, int slot, PartD *oa, PartT *ob);
-    int norm2(const T *x, double *out) { return norm2_host<T>(ctx, n, x, out, comm()); }
+    int redD1(const Real<T> *a, int P, int slot, PartD *oa);
+    int redDT(const Real<T> *a, const T *b, int P, int slot, PartD *oa, PartT *ob);
+    int norm2(const T *x, Real<T> *out) { return norm2_host<T>(ctx, n, x, out, comm()); }
     int cdot(const T *x, const T *y, T *out) { return dot_host<T>(ctx, n, x, y, true, out, comm()); }
 };
 
@@ -88,14 +88,14 @@ class BicgStab : public KrylovBase<T> {
     BicgState<T> *d_state = nullptr, *h_state = nullptr;
     int create(const sprs_csr *A, size_t size);
     void destroy();
-    int solve_dev(const sprs_diag *P, const T *rhs, size_t rhs_len, T *x, size_t x_len, size_t max_iter, double tol,
-                  size_t *its_out, double *res_out);
+    int solve_dev(const sprs_diag *P, const T *rhs, size_t rhs_len, T *x, size_t x_len, size_t max_iter, Real<T> tol,
+                  size_t *its_out, Real<T> *res_out);
 
    private:
     template <class V>
-    int run(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out, double *res_out);
+    int run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> tol, size_t *its_out, Real<T> *res_out);
     template <class V>
-    int run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out, double *res_out);
+    int run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> tol, size_t *its_out, Real<T> *res_out);
 };
 
 template <class T>
@@ -105,14 +105,14 @@ class MinRes : public KrylovBase<T> {
     bool saunders = false;  // CSMINRES
     int create(const sprs_csr *A, size_t size, bool saunders_);
     void destroy();
-    int solve_dev(const sprs_diag *P, const T *rhs, size_t rhs_len, T *x, size_t x_len, size_t max_iter, double tol,
-                  size_t *its_out, double *res_out);
+    int solve_dev(const sprs_diag *P, const T *rhs, size_t rhs_len, T *x, size_t x_len, size_t max_iter, Real<T> tol,
+                  size_t *its_out, Real<T> *res_out);
 
    private:
     template <class V>
-    int run(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out, double *res_out);
+    int run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> tol, size_t *its_out, Real<T> *res_out);
     template <class V>
-    int run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, double tol, size_t *its_out, double *res_out);
+    int run_literal(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> tol, size_t *its_out, Real<T> *res_out);
 };
 
 template <class T>
@@ -138,14 +138,14 @@ int KrylovBase<T>::solve_host(const T *rhs, size_t rhs_len, T *x, size_t x_len, 
 
 // opaque C handles: type-erased over T
 struct sprs_bicgstab {
-    int is_complex;
+    int dtype;
     void *impl;
 };
 struct sprs_minres {
-    int is_complex;
+    int dtype;
     void *impl;
 };
 struct sprs_csminres {
-    int is_complex;
+    int dtype;
     void *impl;
 };

@@ -29,14 +29,17 @@ constexpr uint32_t VEC_FLAG = 0x80000000u;
 
 struct BlkDescHost { int32_t ra, rb, pa, nn; };   // == BlkDesc (device side)
 
-template <class T> struct nnz_cap { static constexpr int value = 2048; };       // 16 KiB LDS
+template <class T> struct nnz_cap { static constexpr int value = 2048; };       // f64: 16 KiB LDS
 template <> struct nnz_cap<cplx> { static constexpr int value = 1280; };        // 20 KiB LDS
+template <> struct nnz_cap<float> { static constexpr int value = 2048; };       //  8 KiB LDS
+template <> struct nnz_cap<cplxf> { static constexpr int value = 2048; };       // 16 KiB LDS
+static inline int nnz_cap_of(int dtype) { return dtype == DT_Z ? nnz_cap<cplx>::value : 2048; }
 
 int build_schedule(sprs_csr *A, const std::vector<int32_t> &blk);
 
 // Host-side analysis: greedy partition of the rows into blocks (see header comment).
 int build_rowblocks(sprs_csr *A, const int32_t *rp) {
-    const int cap = A->is_complex ? nnz_cap<cplx>::value : nnz_cap<double>::value;
+    const int cap = nnz_cap_of(A->dtype);
     std::vector<int32_t> blk;
     blk.reserve((size_t)(A->nrows / ROWS_CAP + 16));
     int64_t r = 0;
@@ -102,6 +105,11 @@ __device__ __forceinline__ cplx ld_stream_c(const cplx *p, bool nt) {
 }
 template <bool NT> __device__ __forceinline__ double ld_val(const double *p) { return ld_stream<NT>(p); }
 template <bool NT> __device__ __forceinline__ cplx ld_val(const cplx *p) { return ld_stream_c(p, NT); }
+template <bool NT> __device__ __forceinline__ float ld_val(const float *p) { return ld_stream<NT>(p); }
+template <bool NT> __device__ __forceinline__ cplxf ld_val(const cplxf *p) {
+    if (NT) return cplxf{__builtin_nontemporal_load(&p->re), __builtin_nontemporal_load(&p->im)};
+    return *p;
+}
 
 // Row-block descriptor, precomputed at handle creation so that one 16-byte load tells a workgroup
 // everything about its next block (no dependent rowblk -> row_ptr -> row_ptr chain per block).
@@ -271,10 +279,7 @@ int rowblk_spans(const sprs_csr *A, std::vector<int32_t> &lo, std::vector<int32_
     SPRS_HIP_TRY(c, hipMalloc((void **)&d_lo, sizeof(int32_t) * nb));
     SPRS_HIP_TRY(c, hipMalloc((void **)&d_hi, sizeof(int32_t) * nb));
     const int g = nb < 2048 ? nb : 2048;
-    if (A->is_complex)
-        hipLaunchKernelGGL((rowblk_span_kernel<cplx>), dim3(g), dim3(BLOCK), 0, c->stream, nb, A->rowblk, A->row_ptr, A->col_idx, d_lo, d_hi);
-    else
-        hipLaunchKernelGGL((rowblk_span_kernel<double>), dim3(g), dim3(BLOCK), 0, c->stream, nb, A->rowblk, A->row_ptr, A->col_idx, d_lo, d_hi);
+    hipLaunchKernelGGL((rowblk_span_kernel<double>), dim3(g), dim3(BLOCK), 0, c->stream, nb, A->rowblk, A->row_ptr, A->col_idx, d_lo, d_hi);
     hipError_t e1 = hipMemcpyAsync(lo.data(), d_lo, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream);
     hipError_t e2 = hipMemcpyAsync(hi.data(), d_hi, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream);
     hipError_t e3 = hipStreamSynchronize(c->stream);
@@ -323,7 +328,7 @@ int build_schedule(sprs_csr *A, const std::vector<int32_t> &blk) {
     if (reach.size() < 64) return SPRS_OK;
     std::nth_element(reach.begin(), reach.begin() + reach.size() / 2, reach.end());
     const int64_t P = reach[reach.size() / 2];
-    const size_t sT = A->is_complex ? 16 : 8;
+    const size_t sT = dtype_size(A->dtype);
     std::vector<int32_t> order(nb);
     if (strip == -1 || strip == 1) {
         // ---- XCD-period placement (experimental).
@@ -367,7 +372,7 @@ int build_schedule(sprs_csr *A, const std::vector<int32_t> &blk) {
 // (profiles/r01_tuning.md): they want one contiguous chunk of row blocks per XCD (x stays in that XCD's
 // L2); HBM-bound ones want the row blocks dealt round-robin over the XCDs.
 static inline bool is_cache_resident(const sprs_csr *A) {
-    const double s = A->is_complex ? 16.0 : 8.0;
+    const double s = (double)dtype_size(A->dtype);
     return (double)A->nnz * (s + 4) + 3.0 * A->nrows * s < 192.0 * 1024 * 1024;
 }
 static inline int base_grid(const sprs_csr *A) {
@@ -436,9 +441,12 @@ int spmv_num_partials(const sprs_csr *A) {
     return spmv_grid(A);
 }
 
-template int launch_spmv<double>(const sprs_csr *, const double *, double *, int, const double *, double *, double *, const int *, bool);
-template int launch_spmv<cplx>(const sprs_csr *, const cplx *, cplx *, int, const cplx *, cplx *, cplx *, const int *, bool);
-template int launch_spmv_subset<double>(const sprs_csr *, const int32_t *, int, const double *, double *, int, const double *, double *, double *, const int *, bool);
-template int launch_spmv_subset<cplx>(const sprs_csr *, const int32_t *, int, const cplx *, cplx *, int, const cplx *, cplx *, cplx *, const int *, bool);
+#define SPRS_INST_SPMV(T)                                                                                              \
+    template int launch_spmv<T>(const sprs_csr *, const T *, T *, int, const T *, T *, T *, const int *, bool);        \
+    template int launch_spmv_subset<T>(const sprs_csr *, const int32_t *, int, const T *, T *, int, const T *, T *, T *, const int *, bool);
+SPRS_INST_SPMV(double)
+SPRS_INST_SPMV(cplx)
+SPRS_INST_SPMV(float)
+SPRS_INST_SPMV(cplxf)
 
 }  // namespace sprs

@@ -6,14 +6,15 @@ import numpy as np
 from . import _lib
 from .error import check
 
-_DTYPES = {np.dtype(np.float64): "d", np.dtype(np.complex128): "z"}
+_DTYPES = {np.dtype(np.float64): "d", np.dtype(np.complex128): "z", np.dtype(np.float32): "s", np.dtype(np.complex64): "c"}
+NP_OF = {"d": np.float64, "z": np.complex128, "s": np.float32, "c": np.complex64}
 
 
 def sfx(dtype):
     try:
         return _DTYPES[np.dtype(dtype)]
     except KeyError:
-        raise TypeError("sprsolve_amd implements f64 and Complex<f64> (got %s); f32/c32 are SURVEY §8f-3" % dtype)
+        raise TypeError("sprsolve_amd implements f32 / f64 / Complex<f32> / Complex<f64> (got %s)" % dtype)
 
 
 class Context:
@@ -131,8 +132,7 @@ def dev_sfx(a):
     if isinstance(a, DevVec):
         return sfx(a.dtype)
     name = str(a.dtype)
-    if name.endswith("float64"):
-        return "d"
-    if name.endswith("complex128"):
-        return "z"
+    for key, s in (("float64", "d"), ("complex128", "z"), ("float32", "s"), ("complex64", "c")):
+        if name.endswith(key):
+            return s
     raise TypeError("unsupported device dtype %s" % name)

@@ -57,8 +57,8 @@ class DistCsr(HipCsr):
             send_off.ctypes.data_as(C.c_void_p), dev_ptr(send_idx_dev) if send_idx_dev is not None else None,
             recv_off.ctypes.data_as(C.c_void_p), C.byref(h))
         check(st, comm.ctx.h)
-        dt = np.float64 if s == "d" else np.complex128
-        A = cls(h, comm.ctx, dt, (plan["n_local"], plan["n_ext"]), keepalive=(indptr_dev, plan["col_ext"], data_dev, send_idx_dev))
+        from .device import NP_OF
+        A = cls(h, comm.ctx, NP_OF[s], (plan["n_local"], plan["n_ext"]), keepalive=(indptr_dev, plan["col_ext"], data_dev, send_idx_dev))
         A.comm, A.plan = comm, plan
         return A
 
@@ -69,7 +69,7 @@ class DistCsr(HipCsr):
     def mul_vec_ext(self, x_ext, y_local):
         """y_local = A_local * x after the halo exchange; x_ext has n_ext entries, owned slice first."""
         pre_sync(x_ext, y_local)
-        st = getattr(_lib.lib(), "sprs_dist_mul_vec_dev_" + ("z" if self.dtype == np.complex128 else "d"))(
+        st = getattr(_lib.lib(), "sprs_dist_mul_vec_dev_" + self._s())(
             self.h, dev_ptr(x_ext), dev_ptr(y_local))
         check(st, self.ctx.h)
         self.ctx.sync()

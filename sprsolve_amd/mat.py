@@ -79,8 +79,8 @@ class HipCsr(MatVecMul):
             ctx.h, int(shape[0]), int(shape[1]), int(nnz), dev_ptr(indptr_dev), dev_ptr(indices_dev),
             dev_ptr(data_dev), 1 if adopt else 0, C.byref(h))
         check(st, ctx.h)
-        dt = np.float64 if s == "d" else np.complex128
-        return cls(h, ctx, dt, shape, keepalive=(indptr_dev, indices_dev, data_dev) if adopt else None)
+        from .device import NP_OF
+        return cls(h, ctx, NP_OF[s], shape, keepalive=(indptr_dev, indices_dev, data_dev) if adopt else None)
 
     # -------------------------------------------------------------- accessors
     def rows(self):
@@ -119,11 +119,11 @@ class HipCsr(MatVecMul):
         x = np.ascontiguousarray(v_in, dtype=self.dtype)
         assert isinstance(v_out, np.ndarray) and v_out.dtype == self.dtype and v_out.flags.c_contiguous
         s = self._s()
-        out = C.c_double() if s == "d" else _lib.c64()
+        out = _lib.SCALAR[s]()
         st = getattr(_lib.lib(), "sprs_mul_vec_dot_" + s)(
             self.h, x.ctypes.data_as(C.c_void_p), x.size, v_out.ctypes.data_as(C.c_void_p), v_out.size, C.byref(out))
         check(st, self.ctx.h)
-        return out.value if s == "d" else out.py()
+        return out.value if s in "ds" else out.py()
 
     def mul_vec_unchecked(self, v_in, v_out):
         """mat.rs:68-143 on device vectors (no dimension check, nothing crosses PCIe).  Blocking."""
@@ -136,10 +136,10 @@ class HipCsr(MatVecMul):
         """mat.rs:145-152 on device vectors."""
         s = self._s()
         pre_sync(v_in, v_out)
-        out = C.c_double() if s == "d" else _lib.c64()
+        out = _lib.SCALAR[s]()
         st = getattr(_lib.lib(), "sprs_mul_vec_dot_dev_" + s)(self.h, dev_ptr(v_in), dev_ptr(v_out), C.byref(out))
         check(st, self.ctx.h)
-        return out.value if s == "d" else out.py()
+        return out.value if s in "ds" else out.py()
 
     def time_mul_vec(self, v_in, v_out, reps=20):
         """Mean device milliseconds of one SpMV launch (HIP events on the library's stream)."""

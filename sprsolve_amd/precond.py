@@ -21,11 +21,15 @@ class DiagPrecond(MatVecMul):
         """precond.rs:20-29: stores 1/diag (no zero check, as upstream)."""
         ctx = ctx or default_ctx()
         diag = np.ascontiguousarray(diag)
-        if diag.dtype == np.complex128:
-            name, t = "sprs_diag_precond_create_z", np.complex128
-        elif diag.dtype == np.float64:
-            t = np.dtype(t_dtype or np.float64)
-            name = "sprs_diag_precond_create_zd" if t == np.complex128 else "sprs_diag_precond_create_d"
+        if diag.dtype in (np.complex128, np.complex64):
+            name, t = "sprs_diag_precond_create_" + ("z" if diag.dtype == np.complex128 else "c"), diag.dtype
+        elif diag.dtype in (np.float64, np.float32):
+            t = np.dtype(t_dtype or diag.dtype)
+            cx = t in (np.complex128, np.complex64)
+            if (t in (np.complex64, np.float32)) != (diag.dtype == np.float32):
+                raise TypeError("diagonal and vector precision must match (T: Mul<V>)")
+            name = "sprs_diag_precond_create_" + {(np.float64, False): "d", (np.float64, True): "zd",
+                                                  (np.float32, False): "s", (np.float32, True): "cs"}[(diag.dtype.type, cx)]
         else:
             raise TypeError(diag.dtype)
         h = C.c_void_p()
@@ -33,7 +37,8 @@ class DiagPrecond(MatVecMul):
         return cls(h, ctx, t, diag.size)
 
     def _s(self):
-        return "z" if self.dtype == np.complex128 else "d"
+        from .device import sfx
+        return sfx(self.dtype)
 
     def mul_vec(self, v_in, v_out):
         """precond.rs:37-45 (checked)."""

@@ -44,7 +44,7 @@ def _ctx(ctx):
 
 
 def _scalar(a, s):
-    return C.c_double(float(a)) if s == "d" else _lib.c64.of(a)
+    return _lib.SCALAR[s](float(a)) if s in "ds" else _lib.SCALAR[s].of(a)
 
 
 def _same_len(*vs):
@@ -69,17 +69,18 @@ def _dot(name, vec1, vec2, ctx):
     with _Staged(vec1, ctx=ctx) as x, _Staged(vec2, ctx=ctx) as y:
         s = dev_sfx(x)
         n = _same_len(x, y)
-        out = C.c_double() if s == "d" else _lib.c64()
+        out = _lib.SCALAR[s]()
         check(getattr(_lib.lib(), name + s)(ctx.h, n, dev_ptr(x), dev_ptr(y), C.byref(out)), ctx.h)
-        return out.value if s == "d" else out.py()
+        return out.value if s in "ds" else out.py()
 
 
 def norm2(vec, ctx=None):
     """vecalg.rs:63-69: sqrt(sum |x|^2), unscaled."""
     ctx = _ctx(ctx)
     with _Staged(vec, ctx=ctx) as x:
-        out = C.c_double()
-        check(getattr(_lib.lib(), "sprs_norm2_" + dev_sfx(x))(ctx.h, dev_len(x), dev_ptr(x), C.byref(out)), ctx.h)
+        s = dev_sfx(x)
+        out = _lib.REAL[s]()
+        check(getattr(_lib.lib(), "sprs_norm2_" + s)(ctx.h, dev_len(x), dev_ptr(x), C.byref(out)), ctx.h)
         return out.value
 
 
@@ -115,8 +116,9 @@ def axpy(a, vec1, vec2, ctx=None):
     with _Staged(vec1, ctx=ctx) as x, _Staged(vec2, out=True, ctx=ctx) as y:
         s = dev_sfx(y)
         n = _same_len(x, y)
-        if s == "z" and isinstance(a, (int, float, np.floating, np.integer)):
-            check(_lib.lib().sprs_axpy_zd(ctx.h, n, float(a), dev_ptr(x), dev_ptr(y)), ctx.h)
+        if s in "zc" and isinstance(a, (int, float, np.floating, np.integer)):
+            fn = _lib.lib().sprs_axpy_zd if s == "z" else _lib.lib().sprs_axpy_cs
+            check(fn(ctx.h, n, float(a), dev_ptr(x), dev_ptr(y)), ctx.h)
         else:
             check(getattr(_lib.lib(), "sprs_axpy_" + s)(ctx.h, n, _scalar(a, s), dev_ptr(x), dev_ptr(y)), ctx.h)
         ctx.sync()

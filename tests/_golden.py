@@ -18,22 +18,26 @@ def cplx(a):
     return (a[..., 0] + 1j * a[..., 1]).astype(np.complex128)
 
 
+NP = {"f64": np.float64, "c64": np.complex128, "f32": np.float32, "c32": np.complex64}
+
+
 def vec(spec, dtype):
-    """{"fill": v, "n": n} or {"array": [...]} -> ndarray of dtype 'f64' / 'c64'."""
+    """{"fill": v, "n": n} or {"array": [...]} -> ndarray of dtype 'f64' / 'c64' / 'f32' / 'c32'."""
+    npd = NP[dtype]
     if "fill" in spec:
         v = spec["fill"]
-        if dtype == "c64":
+        if dtype in ("c64", "c32"):
             v = complex(*v) if isinstance(v, list) else complex(v)
-            return np.full(spec["n"], v, dtype=np.complex128)
-        return np.full(spec["n"], float(v), dtype=np.float64)
+            return np.full(spec["n"], v, dtype=npd)
+        return np.full(spec["n"], float(v), dtype=npd)
     a = spec["array"]
-    if dtype == "c64":
-        return cplx(a)
-    return np.asarray(a, dtype=np.float64)
+    if dtype in ("c64", "c32"):
+        return cplx(a).astype(npd)
+    return np.asarray(a, dtype=npd)
 
 
 def scalar(v, dtype):
-    if dtype == "c64":
+    if dtype in ("c64", "c32"):
         return complex(*v) if isinstance(v, list) else complex(v)
     return float(v)
 

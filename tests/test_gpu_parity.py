@@ -9,6 +9,13 @@ import _golden as G
 pytestmark = pytest.mark.gpu
 
 RED_RTOL = 1e-13      # dot / nrm2: same terms, different summation order (relative to sum |terms|)
+RED_RTOL_F32 = 2e-5   # the same in single precision (the oracle's serial f32 fold is the less accurate side)
+ALL_DTYPES = [np.float64, np.complex128, np.float32, np.complex64]
+ALL_IDS = ["f64", "c64", "f32", "c32"]
+
+
+def is_single(dtype):
+    return np.dtype(dtype) in (np.dtype(np.float32), np.dtype(np.complex64))
 TRACE_RTOL = 1e-9     # lock-step scalar trace over the first iterations (SURVEY §7 hard parts (ii))
 
 
@@ -22,14 +29,15 @@ def sa():
 
 
 def bits(a):
-    return np.ascontiguousarray(a).view(np.uint64)
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint64) if a.dtype.itemsize in (8, 16) and a.dtype.kind != "c" or a.dtype == np.complex128 else a.view(np.uint32)
 
 
 def rand_vec(n, dtype, seed):
     rng = np.random.default_rng(seed)
-    if np.dtype(dtype) == np.complex128:
-        return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex128)
-    return rng.uniform(-1, 1, n)
+    if np.dtype(dtype).kind == "c":
+        return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(dtype)
+    return rng.uniform(-1, 1, n).astype(dtype)
 
 
 # ------------------------------------------------------------------ SpMV
@@ -81,7 +89,7 @@ def random_csr(n, seed, dtype, long_rows=True):
     return indptr.astype(np.int32), indices.astype(np.int32), data, cnt
 
 
-@pytest.mark.parametrize("dtype", [np.float64, np.complex128], ids=["f64", "c64"])
+@pytest.mark.parametrize("dtype", ALL_DTYPES, ids=ALL_IDS)
 @pytest.mark.parametrize("n", [1, 63, 257, 5000, 40001])
 def test_spmv_random_ragged(sa, oracle, dtype, n):
     indptr, indices, data, cnt = random_csr(n, 100 + n, dtype)
@@ -95,7 +103,7 @@ def test_spmv_random_ragged(sa, oracle, dtype, n):
     if (~short).any():
         # wavefront-per-row path: re-associated sum, tolerance relative to sum |x*val|
         absA = oracle.spmv(indptr, indices, np.abs(data).astype(dtype), np.abs(x).astype(dtype))
-        assert np.all(np.abs(y[~short] - ref[~short]) <= RED_RTOL * np.abs(absA[~short]))
+        assert np.all(np.abs(y[~short] - ref[~short]) <= (RED_RTOL_F32 if is_single(dtype) else RED_RTOL) * np.abs(absA[~short]))
     # i64 / u32 index ingest (mat.rs:196-199) gives the same bits
     for idt in (np.int64, np.uint32, np.uint64):
         B = sa.HipCsr.new((n, n), indptr.astype(idt), indices.astype(idt), data)
@@ -191,14 +199,16 @@ def test_vecalg_golden(sa, case):
         assert np.all(np.abs(got - G.vec({"array": case["expected_array"]}, dt)) <= eps)
 
 
-@pytest.mark.parametrize("dtype", [np.float64, np.complex128], ids=["f64", "c64"])
+@pytest.mark.parametrize("dtype", ALL_DTYPES, ids=ALL_IDS)
 @pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1023, 100003, 1 << 20])
 def test_vecalg_random_vs_oracle(sa, oracle, dtype, n):
     va = sa.vecalg
     x = rand_vec(n, dtype, 11); y = rand_vec(n, dtype, 12)
     a = rand_vec(1, dtype, 13)[0]; b = rand_vec(1, dtype, 14)[0]
-    a = complex(a) if dtype == np.complex128 else float(a)
-    b = complex(b) if dtype == np.complex128 else float(b)
+    cx = np.dtype(dtype).kind == "c"
+    a = complex(a) if cx else float(a)
+    b = complex(b) if cx else float(b)
+    tol = RED_RTOL_F32 if is_single(dtype) else RED_RTOL
     # element-wise ops: same rounding sequence => bit-exact
     yy = y.copy(); va.axpy(a, x, yy)
     assert np.array_equal(bits(yy), bits(oracle.axpy(a, x, y.copy())))
@@ -210,14 +220,17 @@ def test_vecalg_random_vs_oracle(sa, oracle, dtype, n):
     assert np.array_equal(bits(xx), bits(oracle.rscale(0.3, x.copy())))
     out = np.empty_like(x); va.conj(x, out)
     assert np.array_equal(bits(out), bits(oracle.conj(x)))
-    if dtype == np.complex128:
-        yy = y.copy(); va.axpy(0.7, x, yy)        # S = f64, T = Complex<f64>
+    if cx:
+        yy = y.copy(); va.axpy(0.7, x, yy)        # S = Real, T = Complex
         assert np.array_equal(bits(yy), bits(oracle.axpy(0.7, x, y.copy())))
     # reductions: tolerance relative to the sum of magnitudes
-    mag = float(np.sum(np.abs(x) * np.abs(y)))
-    assert abs(va.dot(x, y) - oracle.dot(x, y)) <= RED_RTOL * max(mag, 1e-300)
-    assert abs(va.conj_dot(x, y) - oracle.conj_dot(x, y)) <= RED_RTOL * max(mag, 1e-300)
-    assert abs(va.norm2(x) - oracle.norm2(x)) <= RED_RTOL * max(oracle.norm2(x), 1e-300)
+    mag = float(np.sum(np.abs(x).astype(np.float64) * np.abs(y).astype(np.float64)))
+    assert abs(va.dot(x, y) - oracle.dot(x, y)) <= tol * max(mag, 1e-300)
+    assert abs(va.conj_dot(x, y) - oracle.conj_dot(x, y)) <= tol * max(mag, 1e-300)
+    exact = float(np.linalg.norm(x.astype(np.complex128 if cx else np.float64)))
+    # single precision: the GPU tree sum is the more accurate side; both must be near the f64 value
+    assert abs(va.norm2(x) - oracle.norm2(x)) <= (2e-3 if is_single(dtype) else RED_RTOL) * max(exact, 1e-300)
+    assert abs(va.norm2(x) - exact) <= (2e-5 if is_single(dtype) else 1e-13) * max(exact, 1e-300)
 
 
 def test_vecalg_unaligned_device_views(sa, oracle):
@@ -552,3 +565,65 @@ def test_cfg4_complex_symmetric_500k(sa):
     x[:] = 0
     its, res = b.precond_solve(P, rhs, x, 5000, 1e-10)
     assert np.max(np.abs(x - gen.grid_exact_solution(rows, cols))) < 1e-5 * max(rows, cols)
+
+
+# ------------------------------------------------------------------ f32 / Complex<f32>
+def test_f32_solvers_against_oracle(sa, oracle):
+    """The reference is generic over cauchy::Scalar; its f32/c32 unit tests are BLAS-1 only, so the
+    solver path in single precision is checked against the oracle's f32 instantiation."""
+    from sprsolve_amd import gen
+    indptr, indices, data = gen.grid_laplacian_dirichlet(20, 20)
+    rhs = gen.dirichlet_rhs(20, 20).astype(np.float32)
+    data = data.astype(np.float32)
+    n = 400
+    A = sa.HipCsr.new((n, n), indptr, indices, data)
+    s = sa.BiCGStab.new(A, n); s.set_trace(4)
+    x = np.zeros(n, np.float32)
+    its, res = s.solve(rhs, x, 500, 1e-5)
+    ref = oracle.bicgstab(indptr, indices, data, rhs, np.zeros(n, np.float32), 500, 1e-5, trace_cap=4)
+    assert ref.status == oracle.OK and ref.x.dtype == np.float32
+    i, j = np.meshgrid(np.arange(20), np.arange(20), indexing="ij")
+    exact = (i + j).ravel()
+    assert np.max(np.abs(x - exact)) < 2e-3 and np.max(np.abs(ref.x - exact)) < 2e-3
+    assert np.allclose(s.trace()[0], ref.trace[0], rtol=1e-5)          # unrolled iteration, f32 rounding
+    assert isinstance(res, float) and res <= 1e-5
+    # Jacobi in f32 and the literal mode
+    P = sa.DiagPrecond.new(np.where(np.diff(indptr) == 1, 1.0, -4.0).astype(np.float32))
+    s.set_mode("literal"); x[:] = 0
+    its, res = s.precond_solve(P, rhs, x, 500, 1e-5)
+    assert np.max(np.abs(x - exact)) < 2e-3
+    # c32: MINRES on the Hermitian grid of tests/test_complex_solve.rs, real f32 Jacobi
+    ip, ix, d, b, dg = gen.complex_hermitian_grid(8, 8)
+    d = d.astype(np.complex64); b = b.astype(np.complex64)
+    Az = sa.HipCsr.new((64, 64), ip, ix, d)
+    m = sa.MinRes.new(Az, 64)
+    xz = np.zeros(64, np.complex64)
+    its, res = m.solve(b, xz, 300, 1e-5)
+    refz = oracle.minres(ip, ix, d, b, np.zeros(64, np.complex64), 300, 1e-5)
+    assert refz.status == oracle.OK and abs(its - refz.its) <= 5
+    assert np.max(np.abs(xz - gen.grid_exact_solution(8, 8))) < 5e-3
+    Pz = sa.DiagPrecond.new(dg.astype(np.float32), t_dtype=np.complex64)      # DiagPrecond<Complex32, f32>
+    xz[:] = 0
+    its, res = m.precond_solve(Pz, b, xz, 300, 1e-5)
+    assert np.max(np.abs(xz - gen.grid_exact_solution(8, 8))) < 5e-3
+    # c32 CSMINRES on the complex-symmetric grid
+    ip, ix, d, b, dg = gen.complex_symmetric_grid(8, 8)
+    Ac = sa.HipCsr.new((64, 64), ip, ix, d.astype(np.complex64))
+    cs = sa.CSMinRes.new(Ac, 64)
+    xz[:] = 0
+    its, res = cs.solve(b.astype(np.complex64), xz, 500, 1e-5)
+    assert np.max(np.abs(xz - gen.grid_exact_solution(8, 8))) < 5e-3
+
+
+def test_f32_jacobi_and_mul_vec_dot(sa, oracle):
+    n = 3001
+    d = (rand_vec(n, np.float32, 1) + 2).astype(np.float32)
+    v = rand_vec(n, np.complex64, 2)
+    P = sa.DiagPrecond.new(d, t_dtype=np.complex64)
+    out = np.empty(n, np.complex64); P.mul_vec(v, out)
+    assert np.array_equal(bits(out), bits(oracle.diag_apply(oracle.diag_inv(d), v)))
+    dz = (rand_vec(n, np.complex64, 3) + 2).astype(np.complex64)
+    Pz = sa.DiagPrecond.new(dz); Pz.mul_vec(v, out)
+    assert np.array_equal(bits(out), bits(oracle.diag_apply(oracle.diag_inv(dz), v)))
+    with pytest.raises(TypeError):
+        sa.DiagPrecond.new(d, t_dtype=np.complex128)       # T: Mul<V> needs matching precision
