@@ -259,7 +259,9 @@ int csr_create_dev(sprs_ctx *c, int64_t nrows, int64_t ncols, int64_t nnz, const
         }
         if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(SPRS_ERR_HIP);
     }
-    int st = build_rowblocks(A, rp.data());
+    int st = validate_cols_device(A);
+    if (st != SPRS_OK) return fail(st);
+    st = build_rowblocks(A, rp.data());
     if (st != SPRS_OK) return fail(st);
     *out = A;
     return SPRS_OK;

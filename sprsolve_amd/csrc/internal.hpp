@@ -127,6 +127,7 @@ template <class T>
 int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status,
                 bool conj_x = false);
 int build_rowblocks(sprs_csr *A, const int32_t *host_row_ptr);
+int validate_cols_device(const sprs_csr *A);   // SPRS_INVALID_ARGUMENT if any col_idx is outside [0, ncols)
 int spmv_num_partials(const sprs_csr *A);  // workgroups launch_spmv uses == partials it writes
 // per-row-block column span (device kernel + D2H): lo/hi sized n_rowblk
 int rowblk_spans(const sprs_csr *A, std::vector<int32_t> &lo, std::vector<int32_t> &hi);

@@ -270,6 +270,31 @@ __global__ __launch_bounds__(BLOCK) void rowblk_span_kernel(int n_rowblk, const 
     }
 }
 
+// Device-side validation of a CSR that was built in HBM (the host never sees col_idx): every column
+// index must address x.  A malformed matrix must be refused here, not fault the GPU in the SpMV.
+__global__ __launch_bounds__(BLOCK) void validate_cols_kernel(int64_t nnz, const int32_t *__restrict__ col_idx, int32_t ncols,
+                                                              int *__restrict__ bad) {
+    int local = 0;
+    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * BLOCK) {
+        const int32_t cidx = col_idx[k];
+        local |= (cidx < 0) | (cidx >= ncols);
+    }
+    if (local) atomicOr(bad, 1);
+}
+int validate_cols_device(const sprs_csr *A) {
+    sprs_ctx *c = A->ctx;
+    if (A->nnz == 0) return SPRS_OK;
+    int *d_bad = reinterpret_cast<int *>(c->d_scal);
+    SPRS_HIP_TRY(c, hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
+    const int g = (int)std::min<int64_t>((A->nnz + BLOCK - 1) / BLOCK, 2048);
+    hipLaunchKernelGGL(validate_cols_kernel, dim3(g), dim3(BLOCK), 0, c->stream, A->nnz, A->col_idx, (int32_t)A->ncols, d_bad);
+    SPRS_HIP_TRY(c, hipGetLastError());
+    int bad = 0;
+    SPRS_HIP_TRY(c, hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return bad ? SPRS_INVALID_ARGUMENT : SPRS_OK;
+}
+
 int rowblk_spans(const sprs_csr *A, std::vector<int32_t> &lo, std::vector<int32_t> &hi) {
     sprs_ctx *c = A->ctx;
     const int nb = A->n_rowblk;

@@ -108,6 +108,27 @@ def test_comm_allreduce_world1(env):
     assert t.cpu().tolist() == list(range(8))
 
 
+def test_device_built_matrix_is_validated(env):
+    """A CSR assembled in HBM never passes through host validation: out-of-range columns and a
+    broken row_ptr must be refused at creation instead of faulting the GPU in the SpMV."""
+    torch, sa, dev = env["torch"], env["sa"], env["dev"]
+    from sprsolve_amd import gen
+    indptr, indices, data = gen.grid_laplacian_dirichlet(16, 16)
+    n, nnz = 256, int(indptr[-1])
+    ip = torch.from_numpy(indptr).to(dev); dv = torch.from_numpy(data).to(dev)
+    bad = indices.copy(); bad[77] = n + 5
+    with pytest.raises(ValueError):
+        sa.HipCsr.from_device((n, n), nnz, ip, torch.from_numpy(bad).to(dev), dv)
+    bad = indices.copy(); bad[3] = -1
+    with pytest.raises(ValueError):
+        sa.HipCsr.from_device((n, n), nnz, ip, torch.from_numpy(bad).to(dev), dv)
+    ipb = indptr.copy(); ipb[10] = ipb[11] + 1
+    with pytest.raises(ValueError):
+        sa.HipCsr.from_device((n, n), nnz, torch.from_numpy(ipb).to(dev), torch.from_numpy(indices).to(dev), dv)
+    A = sa.HipCsr.from_device((n, n), nnz, ip, torch.from_numpy(indices).to(dev), dv)
+    assert A.nnz() == nnz
+
+
 def test_invalid_plan_is_rejected(env):
     torch, sa, sdist, dev = env["torch"], env["sa"], env["sdist"], env["dev"]
     from sprsolve_amd import gen
