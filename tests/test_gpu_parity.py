@@ -627,3 +627,39 @@ def test_f32_jacobi_and_mul_vec_dot(sa, oracle):
     assert np.array_equal(bits(out), bits(oracle.diag_apply(oracle.diag_inv(dz), v)))
     with pytest.raises(TypeError):
         sa.DiagPrecond.new(d, t_dtype=np.complex128)       # T: Mul<V> needs matching precision
+
+
+def test_cfg5_poisson3d_50m_properties(sa):
+    """BASELINE cfg 5 at full size (50 M rows, 349.1 M nnz), built in HBM: exact identities and the
+    known solution (the oracle is far too slow here; size-independent properties instead)."""
+    import torch
+    from sprsolve_amd import gen_torch
+    dev = torch.device("cuda", 0)
+    nx, ny, nz = 500, 500, 200
+    ip, ix, dv, rhs = gen_torch.poisson3d(nx, ny, nz, device=dev)
+    n = nx * ny * nz
+    nnz = int(ip[-1].item())
+    assert nnz == 349_100_000
+    A = sa.HipCsr.from_device((n, n), nnz, ip, ix, dv, adopt=True)
+    ones = torch.ones(n, dtype=torch.float64, device=dev)
+    y = torch.empty_like(ones)
+    A.mul_vec_unchecked(ones, y)
+    assert torch.equal(y, rhs)                                # A*1 = row sums, small integers: exact
+    # linearity with an exactly representable scale, and symmetry: u.(A v) == v.(A u) to rounding
+    u = torch.rand(n, dtype=torch.float64, device=dev) - 0.5
+    v = torch.rand(n, dtype=torch.float64, device=dev) - 0.5
+    Au = torch.empty_like(u); Av = torch.empty_like(u); A4u = torch.empty_like(u)
+    A.mul_vec_unchecked(u, Au); A.mul_vec_unchecked(v, Av); A.mul_vec_unchecked(4.0 * u, A4u)
+    assert torch.equal(A4u, 4.0 * Au)
+    d1 = sa.vecalg.dot(v, Au); d2 = sa.vecalg.dot(u, Av)
+    assert abs(d1 - d2) <= 1e-10 * float(Au.abs().sum().item()) * 0.5
+    # mul_vec_dot == conj_dot(x, A x)
+    d = A.mul_vec_dot_unchecked(u, y)
+    assert abs(d - sa.vecalg.conj_dot(u, Au)) <= 1e-12 * float((u.abs() * Au.abs()).sum().item())
+    # BiCGStab reaches the known solution (all ones)
+    s = sa.BiCGStab.new(A, n)
+    x = torch.zeros(n, dtype=torch.float64, device=dev)
+    its, res = s.solve(rhs, x, 5000, 1e-8)
+    assert res <= 1e-8 and float((x - 1.0).abs().max().item()) < 1e-4
+    A.mul_vec_unchecked(x, y)
+    assert float(torch.linalg.vector_norm(y - rhs) / torch.linalg.vector_norm(rhs)) < 2e-8
