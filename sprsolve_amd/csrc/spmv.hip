@@ -3,10 +3,10 @@
 // Design (MI355X-first, not a translation of the rayon loop):
 //  * The HBM-resident stream is (col_idx, val): 12 B/nnz for f64.  It is read with fully
 //    coalesced loads — consecutive lanes take consecutive nnz — regardless of row length.
-//  * "stream" row blocks (rows of <= LONG_ROW nnz; every BASELINE config): a workgroup takes a
-//    run of consecutive rows whose nnz fit in LDS, writes the products x[col]*val into LDS in
-//    nnz order, then one lane per row adds its row's products left to right starting from
-//    zero.  That is exactly the reference's fold (mat.rs:100-105: acc + x[col]*val, unfused),
+//  * "stream" row blocks (rows of <= LONG_ROW nnz; every BASELINE config): a WAVEFRONT takes a
+//    run of <= 64 consecutive rows whose nnz fit in its private LDS slice, writes the products
+//    x[col]*val into LDS in nnz order, then one lane per row adds its row's products left to right
+//    starting from zero (no workgroup barrier: a wavefront's LDS operations execute in order).  That is exactly the reference's fold (mat.rs:100-105: acc + x[col]*val, unfused),
 //    so y is BIT-IDENTICAL to the reference for these rows.
 //  * "vector" row blocks (rows longer than LONG_ROW): one wavefront per row, lanes stride the
 //    row with coalesced loads, 64-lane __shfl_down butterfly.  Sums are re-associated
@@ -23,17 +23,18 @@
 
 namespace sprs {
 
-constexpr int ROWS_CAP = BLOCK;   // rows per stream block: one lane per row in the reduce phase
+constexpr int ROWS_CAP = WAVE;    // rows per stream block: one wavefront owns a block, one lane per row in the reduce phase
 constexpr int LONG_ROW = 96;      // rows longer than this go to the wavefront-per-row path
 constexpr uint32_t VEC_FLAG = 0x80000000u;
 
 struct BlkDescHost { int32_t ra, rb, pa, nn; };   // == BlkDesc (device side)
 
-template <class T> struct nnz_cap { static constexpr int value = 2048; };       // f64: 16 KiB LDS
-template <> struct nnz_cap<cplx> { static constexpr int value = 1280; };        // 20 KiB LDS
-template <> struct nnz_cap<float> { static constexpr int value = 2048; };       //  8 KiB LDS
-template <> struct nnz_cap<cplxf> { static constexpr int value = 2048; };       // 16 KiB LDS
-static inline int nnz_cap_of(int dtype) { return dtype == DT_Z ? nnz_cap<cplx>::value : 2048; }
+// nnz per stream block = per wavefront (its private LDS slice; x4 wavefronts per workgroup)
+template <class T> struct nnz_cap { static constexpr int value = 512; };        // f64: 4 KiB per wavefront
+template <> struct nnz_cap<cplx> { static constexpr int value = 320; };         // 5 KiB
+template <> struct nnz_cap<float> { static constexpr int value = 512; };        // 2 KiB
+template <> struct nnz_cap<cplxf> { static constexpr int value = 512; };        // 4 KiB
+static inline int nnz_cap_of(int dtype) { return dtype == DT_Z ? nnz_cap<cplx>::value : 512; }
 
 int build_schedule(sprs_csr *A, const std::vector<int32_t> &blk);
 
@@ -46,11 +47,9 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
     const int64_t n = A->nrows;
     while (r < n) {
         int64_t len = (int64_t)rp[r + 1] - rp[r];
-        if (len > LONG_ROW) {  // vector block: up to NWAVE consecutive long rows
-            int64_t e = r + 1;
-            while (e < n && e - r < NWAVE && (int64_t)rp[e + 1] - rp[e] > LONG_ROW) ++e;
+        if (len > LONG_ROW) {  // vector block: one long row, its wavefront strides it
             blk.push_back((int32_t)((uint32_t)r | VEC_FLAG));
-            r = e;
+            r = r + 1;
         } else {
             int64_t e = r + 1;
             const int64_t base = rp[r];
@@ -84,15 +83,6 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
     return build_schedule(A, blk);
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
-// global load and store (s_waitcnt vmcnt(0)), which would serialise the HBM stream behind each barrier;
-// here only this wave's LDS operations are waited for, global memory operations stay in flight.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 // streaming (read-once) loads: keep the matrix stream from evicting the gathered x lines
 template <bool NT, class U>
 __device__ __forceinline__ U ld_stream(const U *p) {
@@ -120,6 +110,15 @@ struct alignas(16) BlkDesc {
     int32_t nn;      // nnz in the block
 };
 
+// Ordering point between a wavefront's LDS writes and its own later LDS reads (and vice versa).  LDS
+// operations of one wavefront execute in issue order, so no s_barrier and no wait is needed — this only
+// stops the compiler from moving LDS accesses across it.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
 template <class T, int DOT, bool CONJX, bool NT>
 __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk, const BlkDesc *__restrict__ desc,
                                                      const int32_t *__restrict__ order,
@@ -128,42 +127,45 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
                                                      const T *__restrict__ x, T *__restrict__ y,
                                                      const T *__restrict__ u, T *__restrict__ part0,
                                                      T *__restrict__ part1, const int *__restrict__ status) {
-    constexpr int CAP = nnz_cap<T>::value;
-    constexpr int ITEMS = CAP / BLOCK;
-    __shared__ T prod[CAP];
+    constexpr int CAP = nnz_cap<T>::value;      // per wavefront
+    constexpr int ITEMS = CAP / WAVE;
+    __shared__ T prod_all[NWAVE][CAP];
     __shared__ T red[NWAVE];
     if (status != nullptr && *status != ST_RUNNING) return;
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+    T *prod = prod_all[wv];
     T d0 = szero<T>(), d1 = szero<T>();
 
-    // persistent walk over row blocks; with xcd_chunk the 8 XCDs (workgroup id mod 8, observed
-    // round-robin placement — a locality hint only, never needed for correctness) each own a
-    // contiguous eighth of the row blocks.
+    // Persistent walk: every WAVEFRONT owns whole row blocks (<= 64 rows, <= CAP nnz) and a private LDS
+    // slice, so there is no workgroup barrier anywhere in the loop — wavefronts progress independently and
+    // a slow gather stalls one wavefront, not four (measured +3.6 % over the workgroup-wide variant).  The 4
+    // wavefronts of a workgroup take 4 consecutive row blocks, workgroups are dealt round-robin.
+    // With xcd_chunk the 8 XCDs (workgroup id mod 8, observed round-robin placement — a locality hint
+    // only, never needed for correctness) each own a contiguous eighth of the row blocks.
     int b, bstep, bend;
     if (xcd_chunk) {
         const int chunk = (n_rowblk + 7) >> 3;
         const int xcd = blockIdx.x & 7;
-        b = xcd * chunk + (blockIdx.x >> 3);
-        bstep = gridDim.x >> 3;
+        b = xcd * chunk + (blockIdx.x >> 3) * NWAVE + wv;
+        bstep = (gridDim.x >> 3) * NWAVE;
         bend = min(n_rowblk, (xcd + 1) * chunk);
     } else {
-        b = blockIdx.x; bstep = gridDim.x; bend = n_rowblk;
+        b = blockIdx.x * NWAVE + wv; bstep = gridDim.x * NWAVE; bend = n_rowblk;
     }
 
     // Every stream load is unconditional on a clamped (always valid) address so the compiler issues
     // them back to back — 2*ITEMS stream loads, then ITEMS gathers, all in flight together (per-element
     // `if (k < nn)` branches made it serialise every gather behind an s_waitcnt vmcnt(0)); clamped
-    // duplicates hit the same cache line.  (Requesting block i+1's stream before block i's barriers was
-    // measured too: no gain — the kernel is HBM-bound — at +30 VGPRs, so it is not done.)
+    // duplicates hit the same cache line.
     for (; b < bend; b += bstep) {
         const BlkDesc d = desc[order ? order[b] : b];
         const int ra = d.ra, rb = d.rb & 0x7fffffff;
         if (d.rb >= 0) {
             // ---------------- stream block: products to LDS, then one lane per row
             const int pa = d.pa, nn = d.nn;
-            // row extents and the dot operand for the reduce phase: requested now, used after the barrier
-            const int r = ra + tid;
+            // row extents and the dot operand for the reduce phase: requested now, used after the products
+            const int r = ra + lane;
             const bool has_row = r < rb;
             const int rcl = has_row ? r : rb - 1;
             const int s = row_ptr[rcl] - pa, e = row_ptr[rcl + 1] - pa;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
                 T vv[ITEMS], xg[ITEMS];
 #pragma unroll
                 for (int i = 0; i < ITEMS; ++i) {
-                    const int k = min(tid + i * BLOCK, last);
+                    const int k = min(lane + i * WAVE, last);
                     cidx[i] = ld_stream<NT>(col_idx + pa + k);
                     vv[i] = ld_val<NT>(val + pa + k);
                 }
@@ -183,11 +185,11 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
                 for (int i = 0; i < ITEMS; ++i) xg[i] = x[cidx[i]];
 #pragma unroll
                 for (int i = 0; i < ITEMS; ++i) {
-                    const int k = tid + i * BLOCK;
+                    const int k = lane + i * WAVE;
                     if (k < nn) prod[k] = smul(CONJX ? sconj(xg[i]) : xg[i], vv[i]);   // mat.rs:104  x[col] * val
                 }
             }
-            lds_barrier();
+            wave_lds_fence();
             if (has_row) {
                 T acc = szero<T>();                               // mat.rs:103  fold(T::zero(), ..)
                 const int len = e - s;
@@ -206,21 +208,18 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
                 if (DOT == 1) d0 = sadd(d0, smul(sconj(uu), acc));
                 if (DOT == 2) { d0 = sadd(d0, smul(sconj(acc), acc)); d1 = sadd(d1, smul(sconj(acc), uu)); }
             }
-            lds_barrier();  // prod[] is rewritten by the next row block
+            wave_lds_fence();  // prod[] is rewritten by this wavefront's next row block
         } else {
-            // ---------------- vector block: one wavefront per (long) row
-            const int lane = tid & (WAVE - 1);
-            const int r = ra + (tid >> 6);
-            if (r < rb) {
-                const int s = row_ptr[r], e = row_ptr[r + 1];
-                T acc = szero<T>();
-                for (int k = s + lane; k < e; k += WAVE) { const int cj = ld_stream<NT>(col_idx + k); const T vj = ld_val<NT>(val + k); acc = sadd(acc, smul(CONJX ? sconj(x[cj]) : x[cj], vj)); }
-                acc = wave_sum(acc);
-                if (lane == 0) {
-                    y[r] = acc;
-                    if (DOT == 1) d0 = sadd(d0, smul(sconj(u[r]), acc));
-                    if (DOT == 2) { d0 = sadd(d0, smul(sconj(acc), acc)); d1 = sadd(d1, smul(sconj(acc), u[r])); }
-                }
+            // ---------------- vector block: this wavefront strides one long row
+            const int r = ra;
+            const int s = row_ptr[r], e = row_ptr[r + 1];
+            T acc = szero<T>();
+            for (int k = s + lane; k < e; k += WAVE) { const int cj = ld_stream<NT>(col_idx + k); const T vj = ld_val<NT>(val + k); acc = sadd(acc, smul(CONJX ? sconj(x[cj]) : x[cj], vj)); }
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                y[r] = acc;
+                if (DOT == 1) d0 = sadd(d0, smul(sconj(u[r]), acc));
+                if (DOT == 2) { d0 = sadd(d0, smul(sconj(acc), acc)); d1 = sadd(d1, smul(sconj(acc), u[r])); }
             }
         }
     }
@@ -235,38 +234,20 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row-block schedule for matrices with far bands.
-//
-// A 3-D stencil row i gathers x[i], x[i +- nx] and x[i +- P] (P = nx*ny rows, 2 MB of x apart for
-// cfg 5).  Swept in natural order the three x streams of one XCD are 2P rows apart, more than its
-// 4 MiB L2 holds, so every x line is fetched from the fabric several times (measured: 5.5 reads of
-// x instead of 1, profiles/r01_pmc_summary.json).  Row blocks are independent, so they may be
-// processed in any order: fold the row index at period P and walk "strip-major" — all periods of
-// one strip of S rows before the next strip.  Consecutive blocks in time then touch x cells
-// (strip, k-1), (strip, k), (strip, k+1), each S*8 bytes, which stay L2-resident until reused.
-// The result vector is unchanged (each row is still summed by one lane in nnz order).
-// The period is detected from the per-block column span; matrices without far bands keep the
-// natural order.
-template <class T>
+// Row-block column spans (used by the optional schedules and by the distributed interior/boundary split).
 __global__ __launch_bounds__(BLOCK) void rowblk_span_kernel(int n_rowblk, const int32_t *__restrict__ rowblk,
                                                             const int32_t *__restrict__ row_ptr,
                                                             const int32_t *__restrict__ col_idx, int32_t *__restrict__ lo,
                                                             int32_t *__restrict__ hi) {
-    __shared__ int smin[NWAVE], smax[NWAVE];
-    for (int b = blockIdx.x; b < n_rowblk; b += gridDim.x) {
+    // one wavefront per row block
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (int b = blockIdx.x * NWAVE + (threadIdx.x >> 6); b < n_rowblk; b += gridDim.x * NWAVE) {
         const int ra = (int)((uint32_t)rowblk[b] & ~VEC_FLAG), rb = (int)((uint32_t)rowblk[b + 1] & ~VEC_FLAG);
         const int pa = row_ptr[ra], pb = row_ptr[rb];
         int mn = INT32_MAX, mx = -1;
-        for (int k = pa + threadIdx.x; k < pb; k += BLOCK) { const int cidx = col_idx[k]; mn = min(mn, cidx); mx = max(mx, cidx); }
+        for (int k = pa + lane; k < pb; k += WAVE) { const int cidx = col_idx[k]; mn = min(mn, cidx); mx = max(mx, cidx); }
         for (int off = WAVE / 2; off > 0; off >>= 1) { mn = min(mn, __shfl_down(mn, off, WAVE)); mx = max(mx, __shfl_down(mx, off, WAVE)); }
-        __syncthreads();
-        if ((threadIdx.x & (WAVE - 1)) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < NWAVE; ++w) { mn = min(mn, smin[w]); mx = max(mx, smax[w]); }
-            mn = min(mn, smin[0]); mx = max(mx, smax[0]);
-            lo[b] = mn; hi[b] = mx;
-        }
+        if (lane == 0) { lo[b] = mn; hi[b] = mx; }
     }
 }
 
@@ -303,8 +284,8 @@ int rowblk_spans(const sprs_csr *A, std::vector<int32_t> &lo, std::vector<int32_
     int32_t *d_lo = nullptr, *d_hi = nullptr;
     SPRS_HIP_TRY(c, hipMalloc((void **)&d_lo, sizeof(int32_t) * nb));
     SPRS_HIP_TRY(c, hipMalloc((void **)&d_hi, sizeof(int32_t) * nb));
-    const int g = nb < 2048 ? nb : 2048;
-    hipLaunchKernelGGL((rowblk_span_kernel<double>), dim3(g), dim3(BLOCK), 0, c->stream, nb, A->rowblk, A->row_ptr, A->col_idx, d_lo, d_hi);
+    const int g = std::max(1, std::min(2048, (nb + NWAVE - 1) / NWAVE));
+    hipLaunchKernelGGL(rowblk_span_kernel, dim3(g), dim3(BLOCK), 0, c->stream, nb, A->rowblk, A->row_ptr, A->col_idx, d_lo, d_hi);
     hipError_t e1 = hipMemcpyAsync(lo.data(), d_lo, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream);
     hipError_t e2 = hipMemcpyAsync(hi.data(), d_hi, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream);
     hipError_t e3 = hipStreamSynchronize(c->stream);
@@ -409,8 +390,8 @@ static inline int base_grid(const sprs_csr *A) {
 }
 static inline int grid_for_blocks(const sprs_csr *A, int count) {
     const int g = base_grid(A);
-    // at least one row block per workgroup, keep it a multiple of 8 (one slice per XCD)
-    int need = ((count + 7) / 8) * 8;
+    // at least one row block per wavefront, keep it a multiple of 8 (one slice per XCD)
+    int need = (((count + NWAVE - 1) / NWAVE + 7) / 8) * 8;
     if (need < 8) need = 8;
     return g < need ? g : need;
 }
