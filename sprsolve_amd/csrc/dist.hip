@@ -14,6 +14,7 @@
 // RCCL is bound with dlopen so that libsprsolve_hip.so has no link-time dependency on it (and
 // shares whichever librccl.so.1 the process — e.g. PyTorch — has already loaded).
 #include <dlfcn.h>
+#include <cstdlib>
 #include <rccl/rccl.h>
 
 #include "device.hpp"
@@ -37,9 +38,12 @@ struct Rccl {
 Rccl &rccl() {
     static Rccl r;
     if (r.so || r.ok) return r;
+    // SPRS_RCCL_LIB selects another build of the library (the tests point it at a shared-memory
+    // stand-in so that several ranks can share the single GPU of a test box)
+    if (const char *alt = getenv("SPRS_RCCL_LIB")) r.so = dlopen(alt, RTLD_NOW | RTLD_LOCAL);
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (r.so) break;
+        r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!r.so) return r;
 #define SPRS_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.so, sym))

@@ -1,0 +1,75 @@
+"""One rank of tests/test_gpu_dist_multirank.py: several processes share GPU 0; the library's RCCL calls go
+to tests/mock_rccl (SPRS_RCCL_LIB).  Bootstrap over gloo; data path = the real C++ recurrence + real kernels."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main(rank, world, port, kind, outdir):
+    import torch
+    import torch.distributed as tdist
+    tdist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    import sprsolve_amd as sa
+    from sprsolve_amd import dist as sdist, gen, partition
+    dev = torch.device("cuda", 0)
+    ctx = sa.default_ctx(0)
+    if kind == "poisson3d":
+        nx, ny, nz = 24, 20, 18
+        plane = nx * ny
+        starts = partition.slab_starts(nz, plane, world)
+        ip, ix, d, rhs = gen.poisson3d(nx, ny, nz, int(starts[rank] // plane), int(starts[rank + 1] // plane))
+        n = nx * ny * nz
+        solver_cls, pdiag = sa.BiCGStab, np.full(rhs.size, 6.0)
+    else:   # symmetric banded, MINRES, rows split unevenly
+        n = 30011
+        gip, gix, gd, grhs = gen.symmetric_banded(n, hbw=4)
+        starts = partition.row_starts(n, world)
+        r0, r1 = int(starts[rank]), int(starts[rank + 1])
+        ip = (gip[r0:r1 + 1] - gip[r0]).astype(np.int32); ix = gix[gip[r0]:gip[r1]]; d = gd[gip[r0]:gip[r1]]; rhs = grhs[r0:r1]
+        solver_cls, pdiag = sa.MinRes, None
+
+    def gather(obj):
+        out = [None] * world
+        tdist.all_gather_object(out, obj)
+        return out
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    plan = partition.build_plan(t(ix), starts, rank, gather)
+    comm = sdist.Comm(ctx, rank, world, tdist)
+    A = sdist.DistCsr.from_plan(comm, plan, int(ip[-1]), t(ip), t(d), adopt=True, to_device=t)
+    n_loc = plan["n_local"]
+    # distributed SpMV of a global test vector
+    xg = np.linspace(-1.0, 1.0, n) ** 3
+    x_ext = torch.zeros(plan["n_ext"], dtype=torch.float64, device=dev)
+    x_ext[:n_loc] = t(xg[int(starts[rank]):int(starts[rank + 1])])
+    y = torch.empty(n_loc, dtype=torch.float64, device=dev)
+    A.mul_vec_ext(x_ext, y)
+    # distributed solves: plain and Jacobi (BiCGStab) / plain (MINRES), fused and literal
+    res = {}
+    for mode in ("fused", "literal"):
+        s = solver_cls.new(A, n_loc); s.set_mode(mode); s.set_trace(6)
+        xs = torch.zeros(n_loc, dtype=torch.float64, device=dev)
+        its, rr = s.solve(t(rhs), xs, 3000, 1e-10)
+        res[mode] = (its, rr, xs.cpu().numpy(), s.trace())
+    extra = None
+    if pdiag is not None:
+        P = sa.DiagPrecond.new(pdiag)
+        s = solver_cls.new(A, n_loc)
+        xs = torch.zeros(n_loc, dtype=torch.float64, device=dev)
+        its, rr = s.precond_solve(P, t(rhs), xs, 3000, 1e-10)
+        extra = (its, rr, xs.cpu().numpy())
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), y=y.cpu().numpy(),
+             x_fused=res["fused"][2], its_fused=res["fused"][0], res_fused=res["fused"][1], trace_fused=res["fused"][3],
+             x_lit=res["literal"][2], its_lit=res["literal"][0], trace_lit=res["literal"][3],
+             x_pc=extra[2] if extra else np.zeros(0), its_pc=extra[0] if extra else -1,
+             n_ext=plan["n_ext"], n_loc=n_loc, overlap=int(A.h is not None))
+    tdist.barrier()
+    comm.close()
+    tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5])

@@ -1,0 +1,72 @@
+"""The distributed solvers with REAL separate ranks on one GPU.
+
+RCCL refuses two ranks on one device, so the library is pointed (SPRS_RCCL_LIB) at tests/mock_rccl — a
+shared-memory stand-in for the nine RCCL calls it makes.  Everything else is the product: the exchange plan
+(partition.py), pack kernel, grouped send/recv per neighbour, interior/boundary overlap, SpMV, the fused C++
+recurrences with all-reduced scalars.  Results are compared with the single-process oracle."""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def mock_lib():
+    out = os.path.join(tempfile.mkdtemp(prefix="sprs_mock_"), "libmock_rccl.so")
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(HERE, "mock_rccl", "mock_rccl.cpp"), "-o", out, "-L/opt/rocm/lib", "-lamdhip64",
+                           "-lrt", "-lpthread"])
+    return out
+
+
+def _run(world, kind, mock_lib):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = tempfile.mkdtemp(prefix="sprs_distgpu_")
+    env = dict(os.environ, SPRS_RCCL_LIB=mock_lib, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_gpu_worker.py"), str(r), str(world), str(port), kind, out], env=env)
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    return [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,kind", [(2, "poisson3d"), (3, "poisson3d"), (2, "banded")])
+def test_real_ranks_match_single_process(oracle, mock_lib, world, kind):
+    from sprsolve_amd import gen
+    if kind == "poisson3d":
+        ip, ix, d, rhs = gen.poisson3d(24, 20, 18)
+        ref = oracle.bicgstab(ip, ix, d, rhs, np.zeros(rhs.size), 3000, 1e-10, trace_cap=6)
+        refpc = oracle.bicgstab(ip, ix, d, rhs, np.zeros(rhs.size), 3000, 1e-10, precond_diag=np.full(rhs.size, 6.0))
+    else:
+        ip, ix, d, rhs = gen.symmetric_banded(30011, hbw=4)
+        ref = oracle.minres(ip, ix, d, rhs, np.zeros(rhs.size), 3000, 1e-10, trace_cap=6)
+        refpc = None
+    assert ref.status == oracle.OK
+    n = rhs.size
+    res = _run(world, kind, mock_lib)
+    # SpMV through the real halo exchange: bit-identical to the reference fold on the global matrix
+    xg = np.linspace(-1.0, 1.0, n) ** 3
+    y = np.concatenate([r["y"] for r in res])
+    yref = oracle.spmv(ip, ix, d, xg)
+    assert np.array_equal(y.view(np.uint64), yref.view(np.uint64))
+    for key in ("fused", "lit"):
+        its = [int(r["its_" + key]) for r in res]
+        assert len(set(its)) == 1, "ranks disagree on the iteration count: %s" % its
+        assert abs(its[0] - ref.its) <= max(3, ref.its // 10), (its, ref.its)
+        x = np.concatenate([r["x_" + key] for r in res])
+        assert np.max(np.abs(x - ref.x)) <= 1e-7 * max(1.0, np.max(np.abs(ref.x)))
+        tr = res[0]["trace_" + key]
+        for r in res[1:]:
+            assert np.array_equal(r["trace_" + key], tr), "ranks must hold bit-identical scalars"
+        assert np.allclose(tr[:4], ref.trace[:4], rtol=1e-9, atol=1e-12)
+    if refpc is not None:
+        x = np.concatenate([r["x_pc"] for r in res])
+        assert np.max(np.abs(x - refpc.x)) <= 1e-7
+        assert len({int(r["its_pc"]) for r in res}) == 1
