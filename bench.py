@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the bootstrap (gloo + SPRS_BENCH_DEVICE + SPRS_RCCL_LIB rehearse "
+                         "the N>1 leg with several ranks on one GPU)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the distributed (RCCL) code path even with one rank — rehearsal of the N>1 leg on a 1-GPU box")
     return ap.parse_args()
@@ -66,6 +69,14 @@ def run_fixed_iterations(solver, precond, rhs, x, steps):
     raise RuntimeError("the fixed-iteration solve returned early: timing would be invalid")
 
 
+def allreduce_scalar(torch, dist, value, op):
+    """All-reduce one float over the ranks (CUDA tensor under nccl, CPU tensor under gloo)."""
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=op)
+    return float(t.item())
+
+
 def time_solve(torch, dist, solver, precond, rhs, x, steps, warmup, world, profile=True):
     """W untimed warm-up iterations, then exactly K timed ones; returns seconds (max over ranks).
     profile: bracket every SpMV launch with HIP events on the solver's stream (2 event records per
@@ -85,9 +96,7 @@ def time_solve(torch, dist, solver, precond, rhs, x, steps, warmup, world, profi
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = allreduce_scalar(torch, dist, dt, dist.ReduceOp.MAX)
     prof = solver.profile()
     solver.set_profile(False)
     return dt, prof
@@ -155,9 +164,13 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    local_rank = int(os.environ.get("SPRS_BENCH_DEVICE", local_rank))   # rehearsal: several ranks on one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     elif args.force_dist:
         dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
                                 device_id=torch.device("cuda", local_rank))
@@ -244,7 +257,8 @@ def main():
                     achieved=bs / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=bs / t_spmv / 1e9 / HBM_PEAK_GBS,
                     traffic=traffic, traffic_note=traffic_note, algorithmic_bytes_per_launch=bs,
                     avg_launch_us=t_spmv * 1e6, launches=prof["spmv_launches"],
-                    note="per rank; algorithmic bytes = nnz*12 + (n+1)*4 + 2*n*8 (SURVEY §8d), x counted once")
+                    note="per rank; algorithmic bytes = nnz*12 + (n+1)*4 + 2*n*8 (SURVEY §8d), x counted once"
+                         + ("; N>1: the bracketed time includes the wait for the halo exchange of the boundary rows" if world > 1 else ""))
         out = dict(metric="BiCGStab iterations/s (f64, 50M-row 7-point 3-D Poisson) + CSR SpMV GB/s vs HBM roofline",
                    value=args.steps / dt, unit="iterations/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None,

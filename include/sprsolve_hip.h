@@ -99,7 +99,10 @@ int64_t sprs_csr_cols(const sprs_csr *A);
 int64_t sprs_csr_nnz(const sprs_csr *A);
 
 /* MatVecMul::mul_vec / mul_vec_dot (mat.rs:49-64): host slices, checked — returns
- * SPRS_DIM_MISMATCH where the reference panics.  y = A x ; *dot_out = conj(x) . y */
+ * SPRS_DIM_MISMATCH where the reference panics.  y = A x ; *dot_out = conj(x) . y
+ * Thread-safety: the handle is immutable after creation, but the host-slice entry points stage x / y
+ * through per-handle device buffers — concurrent callers need one handle (or one external lock) each;
+ * sprs_mul_vec_dev_* without a dot result touches no shared scratch. */
 int sprs_mul_vec_d(const sprs_csr *A, const double *x_host, size_t x_len, double *y_host, size_t y_len);
 int sprs_mul_vec_z(const sprs_csr *A, const sprs_c64 *x_host, size_t x_len, sprs_c64 *y_host, size_t y_len);
 int sprs_mul_vec_dot_d(const sprs_csr *A, const double *x_host, size_t x_len, double *y_host, size_t y_len, double *dot_out);

@@ -102,10 +102,12 @@ def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, t
     bs = nnz_loc * 12 + (n_loc + 1) * 4 + 2 * n_loc * 8
     x.zero_()
     its, res = s.solve(rhs, x, 5000, 1e-8)
-    err = torch.tensor([float((x - 1.0).abs().max().item())], dtype=torch.float64, device=dev)
-    tdist.all_reduce(err, op=tdist.ReduceOp.MAX)
-    tot = torch.tensor([float(nnz_loc)], dtype=torch.float64, device=dev)
-    tdist.all_reduce(tot)
-    check_ = dict(tol=1e-8, iters=its, rel_res=res, max_abs_err_vs_exact=float(err.item()),
+    def reduce_scalar(v, op):
+        t_ = torch.tensor([float(v)], dtype=torch.float64, device=dev if tdist.get_backend() == "nccl" else "cpu")
+        tdist.all_reduce(t_, op=op)
+        return float(t_.item())
+    err = reduce_scalar(float((x - 1.0).abs().max().item()), tdist.ReduceOp.MAX)
+    tot = reduce_scalar(nnz_loc, tdist.ReduceOp.SUM)
+    check_ = dict(tol=1e-8, iters=its, rel_res=res, max_abs_err_vs_exact=err,
                   halo_entries_per_rank=int(plan["n_ext"] - n_loc), peers=[int(p) for p in plan["peers"]])
-    return dt, prof, t_spmv, bs, check_, nx * ny * nz, int(tot.item())
+    return dt, prof, t_spmv, bs, check_, nx * ny * nz, int(tot)
