@@ -138,10 +138,12 @@ __global__ __launch_bounds__(BLOCK) void spmv2(int nblk, const Desc *__restrict_
 
 
 // wave-independent variant: each wavefront owns 64 rows (<= 512 nnz) and a private LDS slice; no s_barrier
-template <int WITEMS>
+template <int WITEMS, int NG = 1>
 __global__ __launch_bounds__(BLOCK) void spmv3(int ndesc, const Desc *__restrict__ desc, const int *__restrict__ row_ptr,
                                                const int *__restrict__ col_idx, const double *__restrict__ val,
-                                               const double *__restrict__ x, double *__restrict__ y) {
+                                               const double *__restrict__ x, double *__restrict__ y,
+                                               const double *__restrict__ x2 = nullptr, const double *__restrict__ x3 = nullptr,
+                                               double a = 0.5, double bb = 0.25, double *__restrict__ y2 = nullptr) {
     constexpr int WCAP = 64 * WITEMS;
     __shared__ double prod_all[4][WCAP];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -157,6 +159,21 @@ __global__ __launch_bounds__(BLOCK) void spmv3(int ndesc, const Desc *__restrict
         for (int i = 0; i < WITEMS; ++i) { int k = min(lane + i * 64, last); cidx[i] = col_idx[pa + k]; vv[i] = val[pa + k]; }
 #pragma unroll
         for (int i = 0; i < WITEMS; ++i) xg[i] = x[cidx[i]];
+        if (NG >= 2) {
+            double g2[WITEMS];
+#pragma unroll
+            for (int i = 0; i < WITEMS; ++i) g2[i] = x2[cidx[i]];
+            if (NG >= 3) {
+                double g3[WITEMS];
+#pragma unroll
+                for (int i = 0; i < WITEMS; ++i) g3[i] = x3[cidx[i]];
+#pragma unroll
+                for (int i = 0; i < WITEMS; ++i) xg[i] = (g2[i] * a + g3[i] * bb) + xg[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < WITEMS; ++i) xg[i] = xg[i] + g2[i] * a;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < WITEMS; ++i) { int k = lane + i * 64; if (k < nn) prod[k] = xg[i] * vv[i]; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -169,7 +186,51 @@ __global__ __launch_bounds__(BLOCK) void spmv3(int ndesc, const Desc *__restrict
 #pragma unroll
             for (int j = 0; j < 8; ++j) if (j < len) acc += pv[j];
             y[r] = acc;
+            if (NG >= 2) y2[r] = x[r] + x2[r] * a + (NG >= 3 ? x3[r] * bb : 0.0);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    }
+}
+
+
+// spmv4: stage (col, val) through LDS, then lane = row: the x gathers of 64 consecutive rows at the same
+// in-row position are (for stencil / banded matrices) 64 consecutive addresses -> coalesced in the TA
+template <int WITEMS>
+__global__ __launch_bounds__(BLOCK) void spmv4(int ndesc, const Desc *__restrict__ desc, const int *__restrict__ row_ptr,
+                                               const int *__restrict__ col_idx, const double *__restrict__ val,
+                                               const double *__restrict__ x, double *__restrict__ y) {
+    constexpr int WCAP = 64 * WITEMS;
+    __shared__ double lv_all[4][WCAP];
+    __shared__ int lc_all[4][WCAP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *lv = lv_all[w]; int *lc = lc_all[w];
+    const int nw = gridDim.x * 4;
+    for (int b = blockIdx.x * 4 + w; b < ndesc; b += nw) {
+        const Desc d = desc[b];
+        const int pa = d.pa, nn = d.nn, last = nn - 1;
+        const int r = d.ra + lane; const bool has_row = r < d.rb; const int rcl = has_row ? r : d.rb - 1;
+        const int s = row_ptr[rcl] - pa, e = row_ptr[rcl + 1] - pa;
+        int cidx[WITEMS]; double vv[WITEMS];
+#pragma unroll
+        for (int i = 0; i < WITEMS; ++i) { int k = min(lane + i * 64, last); cidx[i] = col_idx[pa + k]; vv[i] = val[pa + k]; }
+#pragma unroll
+        for (int i = 0; i < WITEMS; ++i) { int k = lane + i * 64; if (k < nn) { lc[k] = cidx[i]; lv[k] = vv[i]; } }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        const int len = e - s;
+        if (has_row && len > 0) {
+            int cc[8]; double v8[8], x8[8]; double acc = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { int idx = min(s + j, e - 1); cc[j] = lc[idx]; v8[j] = lv[idx]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x8[j] = x[cc[j]];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j < len) acc += x8[j] * v8[j];
+            y[r] = acc;
+        } else if (has_row) y[r] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
@@ -233,11 +294,38 @@ int main(int argc, char **argv) {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
             printf("spmv3 (wave-independent) grid %d : %8.1f us  %7.1f GB/s\n", grid, ms * 1e3, bytes / ms / 1e6);
         }
+        {
+            double *xb, *xc, *yb; CK(hipMalloc(&xb, n * 8)); CK(hipMalloc(&xc, n * 8)); CK(hipMalloc(&yb, n * 8));
+            CK(hipMemset(xb, 0, n * 8)); CK(hipMemset(xc, 0, n * 8));
+            for (int rnd = 0; rnd < 2; ++rnd) for (int ng = 1; ng <= 3; ++ng) {
+                auto launch = [&]() {
+                    if (ng == 1) spmv3<8, 1><<<1024, BLOCK>>>((int)hd.size(), dd, rp, ci, val, x, y);
+                    else if (ng == 2) spmv3<8, 2><<<1024, BLOCK>>>((int)hd.size(), dd, rp, ci, val, x, y, xb, xc, 0.5, 0.25, yb);
+                    else spmv3<8, 3><<<1024, BLOCK>>>((int)hd.size(), dd, rp, ci, val, x, y, xb, xc, 0.5, 0.25, yb);
+                };
+                for (int w = 0; w < 3; ++w) launch();
+                CK(hipEventRecord(e0)); for (int it = 0; it < 20; ++it) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+                printf("spmv3 with %d gathered vectors (+1 extra output for >1): %8.1f us\n", ng, ms * 1e3);
+            }
+        }
+        for (int rnd = 0; rnd < 2; ++rnd) for (int grid : {1024, 2048}) for (int var = 3; var <= 4; ++var) {
+            auto launch = [&]() {
+                if (var == 3) spmv3<8><<<grid, BLOCK>>>((int)hd.size(), dd, rp, ci, val, x, y);
+                else spmv4<8><<<grid, BLOCK>>>((int)hd.size(), dd, rp, ci, val, x, y);
+            };
+            for (int w = 0; w < 3; ++w) launch();
+            CK(hipEventRecord(e0)); for (int it = 0; it < 20; ++it) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+            printf("A/B spmv%d grid %d : %8.1f us  %7.1f GB/s\n", var, grid, ms * 1e3, bytes / ms / 1e6);
+        }
         // correctness vs spmv2<1>
         std::vector<double> hx(n); for (long i = 0; i < n; ++i) hx[i] = (double)((i * 2654435761u) % 1000) / 1000.0 - 0.5;
         CK(hipMemcpy(x, hx.data(), n * 8, hipMemcpyHostToDevice));
         double *y2; CK(hipMalloc(&y2, n * 8));
         spmv3<8><<<1024, BLOCK>>>((int)hd.size(), dd, rp, ci, val, x, y2);
+        double *y4; CK(hipMalloc(&y4, n * 8));
+        spmv4<8><<<1024, BLOCK>>>((int)hd.size(), dd, rp, ci, val, x, y4);
         std::vector<Desc> hb;
         for (long r = 0; r < n; r += 256) { long e = std::min<long>(r + 256, n); hb.push_back({(int)r, (int)e, hrp[r], hrp[e] - hrp[r]}); }
         Desc *db; CK(hipMalloc(&db, hb.size() * sizeof(Desc))); CK(hipMemcpy(db, hb.data(), hb.size() * sizeof(Desc), hipMemcpyHostToDevice));
@@ -246,6 +334,9 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(a.data(), y, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), y2, n * 8, hipMemcpyDeviceToHost));
         long bad = 0; for (long i = 0; i < n; ++i) bad += (a[i] != b[i]);
         printf("spmv3 vs spmv2 mismatches: %ld\n", bad);
+        CK(hipMemcpy(b.data(), y4, n * 8, hipMemcpyDeviceToHost));
+        bad = 0; for (long i = 0; i < n; ++i) bad += (a[i] != b[i]);
+        printf("spmv4 vs spmv2 mismatches: %ld\n", bad);
     }
     return 0;
 }
