@@ -663,3 +663,27 @@ def test_cfg5_poisson3d_50m_properties(sa):
     assert res <= 1e-8 and float((x - 1.0).abs().max().item()) < 1e-4
     A.mul_vec_unchecked(x, y)
     assert float(torch.linalg.vector_norm(y - rhs) / torch.linalg.vector_norm(rhs)) < 2e-8
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES, ids=ALL_IDS)
+def test_spmv_row_length_boundaries(sa, oracle, dtype):
+    """Row lengths around every threshold of the kernel: 0, 1, 8/9 (register fast path), 96/97
+    (stream vs wavefront-per-row), 320/321 and 512/513 (LDS slice capacities), plus a 5000-nnz row."""
+    rng = np.random.default_rng(11)
+    lens = [0, 1, 8, 9, 7, 96, 97, 95, 320, 321, 64, 512, 513, 2, 5000, 3, 96, 96, 96, 96, 96, 96, 0, 0, 5]
+    n = 6000
+    cnt = np.array(lens * 3, dtype=np.int64)
+    m = cnt.size
+    indptr = np.zeros(m + 1, dtype=np.int64); np.cumsum(cnt, out=indptr[1:])
+    indices = np.concatenate([np.sort(rng.choice(n, c, replace=False)) for c in cnt]).astype(np.int32)
+    data = rand_vec(int(indptr[-1]), dtype, 5)
+    x = rand_vec(n, dtype, 6)
+    A = sa.HipCsr.new((m, n), indptr.astype(np.int32), indices, data)
+    y = np.empty(n, dtype=dtype)                      # checked mul_vec wants len(y) == len(x) == cols
+    A.mul_vec(x, y)
+    ref = oracle.spmv(indptr, indices, data, x)
+    short = cnt <= 96
+    assert np.array_equal(bits(y[:m][short]), bits(ref[short]))
+    tol = RED_RTOL_F32 if is_single(dtype) else RED_RTOL
+    absA = oracle.spmv(indptr, indices, np.abs(data).astype(dtype), np.abs(x).astype(dtype))
+    assert np.all(np.abs(y[:m][~short] - ref[~short]) <= tol * np.abs(absA[~short]))
