@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the bootstrap (gloo + SPRS_BENCH_DEVICE + SPRS_RCCL_LIB rehearse "
                          "the N>1 leg with several ranks on one GPU)")
+    ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
+                    help="N>1 SpMV input exchange: sparse halo (default) or north_star's literal full all-gather of x")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the distributed (RCCL) code path even with one rank — rehearsal of the N>1 leg on a 1-GPU box")
     return ap.parse_args()
@@ -242,7 +244,8 @@ def main():
             n_glob, nnz_glob = n, nnz
         else:
             from sprsolve_amd import dist as sdist
-            res_ = sdist.bench_poisson3d(torch, dist, ctx, rank, world, nx, ny, nz, args.steps, args.warmup, time_solve)
+            res_ = sdist.bench_poisson3d(torch, dist, ctx, rank, world, nx, ny, nz, args.steps, args.warmup, time_solve,
+                                         exchange=args.exchange)
             dt, prof, t_spmv, bs, check, n_glob, nnz_glob = res_
         it_bytes = 2 * spmv_bytes(n_glob, nnz_glob, 8) + 26 * n_glob * 8
         traffic, traffic_note = None, "no PMC summary found"

@@ -300,6 +300,14 @@ int sprs_dist_csr_create_dev_z(sprs_comm *comm, int64_t n_local, int64_t n_ext, 
                                const int32_t *dev_row_ptr, const int32_t *dev_col_idx_ext, const sprs_c64 *dev_val, int adopt,
                                int n_peers, const int32_t *peer_rank, const int64_t *send_off,
                                const int32_t *send_idx_dev, const int64_t *recv_off, sprs_csr **out);
+/* north_star's literal exchange instead of the sparse halo: before every SpMV an ncclAllGather of all ranks'
+ * x slices (each padded to `slice` >= max n_local elements, the same value on every rank).  Column indices
+ * address the gathered vector: col = owner_rank * slice + (global_col - first_row_of_owner).  Moves
+ * world*slice elements per SpMV (400 MB for cfg 5) — kept for comparison; the sparse halo is the default. */
+int sprs_dist_csr_create_allgather_dev_d(sprs_comm *comm, int64_t n_local, int64_t slice, int64_t nnz, const int32_t *dev_row_ptr, const int32_t *dev_col_idx_gathered, const double *dev_val, int adopt, sprs_csr **out);
+int sprs_dist_csr_create_allgather_dev_z(sprs_comm *comm, int64_t n_local, int64_t slice, int64_t nnz, const int32_t *dev_row_ptr, const int32_t *dev_col_idx_gathered, const sprs_c64 *dev_val, int adopt, sprs_csr **out);
+int sprs_dist_csr_create_allgather_dev_s(sprs_comm *comm, int64_t n_local, int64_t slice, int64_t nnz, const int32_t *dev_row_ptr, const int32_t *dev_col_idx_gathered, const float *dev_val, int adopt, sprs_csr **out);
+int sprs_dist_csr_create_allgather_dev_c(sprs_comm *comm, int64_t n_local, int64_t slice, int64_t nnz, const int32_t *dev_row_ptr, const int32_t *dev_col_idx_gathered, const sprs_c32 *dev_val, int adopt, sprs_csr **out);
 /* y_local = A_local * x after exchanging the halo tail of x_ext (n_ext elements, owned slice first) */
 int sprs_dist_mul_vec_dev_d(const sprs_csr *A, double *x_ext_dev, double *y_local_dev);
 int sprs_dist_mul_vec_dev_z(const sprs_csr *A, sprs_c64 *x_ext_dev, sprs_c64 *y_local_dev);

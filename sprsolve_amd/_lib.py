@@ -116,6 +116,7 @@ def _protos():
     for s in ("d", "z", "s", "c"):
         P["sprs_dist_csr_create_dev_" + s] = [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _pp]
         P["sprs_dist_mul_vec_dev_" + s] = [_vp, _vp, _vp]
+        P["sprs_dist_csr_create_allgather_dev_" + s] = [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _pp]
     P["sprs_solver_set_mode"] = [_vp, _int, _int]
     P["sprs_solver_set_trace"] = [_vp, _int, _vp, _sz]
     P["sprs_solver_trace_rows"] = [_vp, _int, _psz]

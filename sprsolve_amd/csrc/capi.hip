@@ -502,6 +502,7 @@ int sprs_csr_destroy(sprs_csr *A) {
     if (A->dist) {
         if (A->dist->send_idx) (void)hipFree(A->dist->send_idx);
         if (A->dist->send_buf) (void)hipFree(A->dist->send_buf);
+        if (A->dist->ag_buf) (void)hipFree(A->dist->ag_buf);
         if (A->dist->order_int) (void)hipFree(A->dist->order_int);
         if (A->dist->order_bnd) (void)hipFree(A->dist->order_bnd);
         if (A->dist->ev_pack) (void)hipEventDestroy(A->dist->ev_pack);

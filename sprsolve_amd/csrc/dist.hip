@@ -27,6 +27,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -51,13 +52,14 @@ Rccl &rccl() {
     SPRS_SYM(CommInitRank, "ncclCommInitRank");
     SPRS_SYM(CommDestroy, "ncclCommDestroy");
     SPRS_SYM(AllReduce, "ncclAllReduce");
+    SPRS_SYM(AllGather, "ncclAllGather");
     SPRS_SYM(Send, "ncclSend");
     SPRS_SYM(Recv, "ncclRecv");
     SPRS_SYM(GroupStart, "ncclGroupStart");
     SPRS_SYM(GroupEnd, "ncclGroupEnd");
     SPRS_SYM(GetErrorString, "ncclGetErrorString");
 #undef SPRS_SYM
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.Send && r.Recv && r.GroupStart &&
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.AllGather && r.Send && r.Recv && r.GroupStart &&
            r.GroupEnd && r.GetErrorString;
     return r;
 }
@@ -155,6 +157,14 @@ template <class T>
 int dist_spmv(const sprs_csr *A, T *x_ext, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status,
               bool conj_x) {
     const sprs_dist_info *D = A->dist;
+    if (D->ag_slice > 0) {
+        // literal north_star exchange: all-gather the x slices of all ranks, then multiply
+        sprs_ctx *c = A->ctx;
+        constexpr size_t W = sizeof(T) / sizeof(Real<T>);
+        SPRS_NCCL_TRY(c, rccl().AllGather(x_ext, D->ag_buf, (size_t)D->ag_slice * W, sizeof(Real<T>) == 4 ? ncclFloat : ncclDouble,
+                                          (ncclComm_t)D->comm->nccl, c->stream));
+        return launch_spmv<T>(A, reinterpret_cast<const T *>(D->ag_buf), y, dot_mode, u, part0, part1, status, conj_x);
+    }
     if (!D->order_int) {
         SPRS_TRY(halo_exchange<T>(A, x_ext));
         return launch_spmv<T>(A, x_ext, y, dot_mode, u, part0, part1, status, conj_x);
@@ -246,6 +256,29 @@ int dist_csr_create(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz
     *out = A;
     return SPRS_OK;
 }
+template <class T>
+int dist_csr_create_allgather(sprs_comm *comm, int64_t n_local, int64_t slice, int64_t nnz, const int32_t *d_rp,
+                              const int32_t *d_ci, const T *d_val, int adopt, sprs_csr **out) {
+    if (!comm || !out || slice < n_local || n_local < 0) return SPRS_INVALID_ARGUMENT;
+    if ((int64_t)comm->world * slice >= INT32_MAX) return SPRS_INVALID_ARGUMENT;
+    sprs_ctx *c = comm->ctx;
+    sprs_csr *A = nullptr;
+    const int64_t n_ext = (int64_t)comm->world * slice;
+    int st;
+    if constexpr (dtype_of<T>::value == DT_Z) st = sprs_csr_create_dev_z(c, n_local, n_ext, nnz, d_rp, d_ci, (const sprs_c64 *)d_val, adopt, &A);
+    else if constexpr (dtype_of<T>::value == DT_C) st = sprs_csr_create_dev_c(c, n_local, n_ext, nnz, d_rp, d_ci, (const sprs_c32 *)d_val, adopt, &A);
+    else if constexpr (dtype_of<T>::value == DT_S) st = sprs_csr_create_dev_s(c, n_local, n_ext, nnz, d_rp, d_ci, d_val, adopt, &A);
+    else st = sprs_csr_create_dev_d(c, n_local, n_ext, nnz, d_rp, d_ci, d_val, adopt, &A);
+    if (st != SPRS_OK) return st;
+    sprs_dist_info *D = new sprs_dist_info();
+    D->comm = comm; D->n_local = n_local; D->n_ext = n_ext; D->ag_slice = slice;
+    D->send_off.assign(1, 0); D->recv_off.assign(1, 0);
+    A->dist = D;
+    if (hipMalloc(&D->ag_buf, sizeof(T) * (size_t)n_ext) != hipSuccess ||
+        hipMemset(D->ag_buf, 0, sizeof(T) * (size_t)n_ext) != hipSuccess) { sprs_csr_destroy(A); return SPRS_ERR_HIP; }
+    *out = A;
+    return SPRS_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -300,6 +333,12 @@ int sprs_comm_allreduce_sum_f64(sprs_comm *comm, double *dev, size_t count) {
                                      sprs_csr **out) {                                                                   \
         try { return dist_csr_create<T>(comm, n_local, n_ext, nnz, rp, ci, (const T *)val, adopt, n_peers, peer_rank,    \
                                         send_off, send_idx_dev, recv_off, out); }                                        \
+        catch (...) { return SPRS_ERR_HIP; }                                                                             \
+    }                                                                                                                    \
+    int sprs_dist_csr_create_allgather_dev_##X(sprs_comm *comm, int64_t n_local, int64_t slice, int64_t nnz,              \
+                                               const int32_t *rp, const int32_t *ci, const CT *val, int adopt,            \
+                                               sprs_csr **out) {                                                         \
+        try { return dist_csr_create_allgather<T>(comm, n_local, slice, nnz, rp, ci, (const T *)val, adopt, out); }      \
         catch (...) { return SPRS_ERR_HIP; }                                                                             \
     }                                                                                                                    \
     /* y_local = A_local * x_ext after exchanging the halo of x_ext (device vector of n_ext elements whose first        \

@@ -80,6 +80,10 @@ struct sprs_dist_info {
     std::vector<int64_t> send_off, recv_off;   // n_peers + 1 each (elements)
     int32_t *send_idx = nullptr;               // device: local indices to pack, grouped by peer
     void *send_buf = nullptr;                  // device: packed values
+    // north_star's literal exchange: ncclAllGather of every rank's (padded) x slice into ag_buf, column
+    // indices address ag_buf = [rank 0 slice | rank 1 slice | ...]; ag_slice == 0 selects the sparse halo
+    int64_t ag_slice = 0;
+    void *ag_buf = nullptr;
     // overlap of the halo exchange with the SpMV of the rows that need no halo entry
     int32_t *order_int = nullptr, *order_bnd = nullptr;   // device: interior / boundary row blocks
     int32_t n_int = 0, n_bnd = 0;

@@ -19,6 +19,7 @@
 //    consumes them.  Slow (5 host syncs per iteration); kept as the on-GPU cross-check.
 #include "krylov.hpp"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
@@ -314,7 +315,8 @@ struct MinresM3 {
 template <class T>
 int KrylovBase<T>::init(const sprs_csr *A_, size_t size, int nvec_) {
     A = A_; ctx = A_->ctx; n = size; nvec = nvec_;
-    const size_t nx = A->dist ? (size_t)A->ncols : n;   // distributed: every work vector carries the halo tail
+    // distributed: every work vector carries the halo tail (sparse halo) or is padded to the all-gather slice
+    const size_t nx = !A->dist ? n : (A->dist->ag_slice > 0 ? std::max<size_t>(n, (size_t)A->dist->ag_slice) : (size_t)A->ncols);
     stride = (nx + 31) & ~(size_t)31;
     if (stride == 0) stride = 32;
     SPRS_HIP_TRY(ctx, hipSetDevice(ctx->device));

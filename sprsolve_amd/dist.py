@@ -62,6 +62,20 @@ class DistCsr(HipCsr):
         A.comm, A.plan = comm, plan
         return A
 
+    @classmethod
+    def from_allgather_plan(cls, comm, plan, nnz, indptr_dev, data_dev, adopt=True):
+        """plan: partition.allgather_plan(...) — full all-gather of x before every SpMV (north_star's literal design)."""
+        s = dev_sfx(data_dev)
+        h = C.c_void_p()
+        st = getattr(_lib.lib(), "sprs_dist_csr_create_allgather_dev_" + s)(
+            comm.h, plan["n_local"], plan["slice"], int(nnz), dev_ptr(indptr_dev), dev_ptr(plan["col_ext"]),
+            dev_ptr(data_dev), 1 if adopt else 0, C.byref(h))
+        check(st, comm.ctx.h)
+        from .device import NP_OF
+        A = cls(h, comm.ctx, NP_OF[s], (plan["n_local"], plan["slice"] * comm.world), keepalive=(indptr_dev, plan["col_ext"], data_dev))
+        A.comm, A.plan = comm, plan
+        return A
+
     def cols(self):
         # the solvers are created with the number of OWNED entries
         return self.shape[0]
@@ -75,7 +89,7 @@ class DistCsr(HipCsr):
         self.ctx.sync()
 
 
-def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, time_solve):
+def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, time_solve, exchange="halo"):
     """N > 1 leg of bench.py: cfg 5 row-partitioned in z-slabs, strong scaling."""
     import sprsolve_amd as sa
     from . import gen_torch
@@ -90,10 +104,15 @@ def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, t
         out = [None] * world
         tdist.all_gather_object(out, obj)
         return out
-    plan = partition.build_plan(ix, starts, rank, gather)
     comm = Comm(ctx, rank, world, tdist)
-    A = DistCsr.from_plan(comm, plan, nnz_loc, ip, dv, adopt=True,
-                          to_device=lambda a: torch.from_numpy(a).to(dev))
+    if exchange == "allgather":
+        plan = partition.allgather_plan(ix, starts, rank)
+        plan.update(n_ext=plan["slice"] * world, peers=list(range(world)))
+        A = DistCsr.from_allgather_plan(comm, plan, nnz_loc, ip, dv, adopt=True)
+    else:
+        plan = partition.build_plan(ix, starts, rank, gather)
+        A = DistCsr.from_plan(comm, plan, nnz_loc, ip, dv, adopt=True,
+                              to_device=lambda a: torch.from_numpy(a).to(dev))
     n_loc = plan["n_local"]
     s = sa.BiCGStab.new(A, n_loc)
     x = torch.zeros(n_loc, dtype=torch.float64, device=dev)
@@ -109,5 +128,5 @@ def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, t
     err = reduce_scalar(float((x - 1.0).abs().max().item()), tdist.ReduceOp.MAX)
     tot = reduce_scalar(nnz_loc, tdist.ReduceOp.SUM)
     check_ = dict(tol=1e-8, iters=its, rel_res=res, max_abs_err_vs_exact=err,
-                  halo_entries_per_rank=int(plan["n_ext"] - n_loc), peers=[int(p) for p in plan["peers"]])
+                  exchange=exchange, halo_entries_per_rank=int(plan["n_ext"] - n_loc), peers=[int(p) for p in plan["peers"]])
     return dt, prof, t_spmv, bs, check_, nx * ny * nz, int(tot)

@@ -135,3 +135,23 @@ def build_plan(col_global, starts, rank, all_gather_object):
     n_local = int(starts[rank + 1] - starts[rank])
     return dict(col_ext=col_ext, n_local=n_local, n_ext=n_local + int(r_off[-1]), peers=peers,
                 send_off=s_off, send_idx=s_idx, recv_off=r_off)
+
+
+def allgather_plan(col_global, starts, rank):
+    """The literal north_star exchange: every rank all-gathers every x slice.  Column indices are renumbered into
+    the gathered vector [rank 0 slice | rank 1 slice | ...] whose slices are padded to `slice` = max rows per rank
+    (rounded up to 2 so every slice stays 16-byte aligned).  Returns dict(col_ext, n_local, slice, mode)."""
+    xp = _xp(col_global)
+    st = np.asarray(starts, dtype=np.int64)
+    slice_ = int(np.max(np.diff(st)))
+    slice_ += slice_ & 1
+    cg = xp.as_i64(col_global)
+    if isinstance(col_global, np.ndarray):
+        owner = np.searchsorted(st, cg, side="right") - 1
+        col = owner * slice_ + (cg - st[owner])
+    else:
+        t = xp.t
+        stt = t.from_numpy(st).to(cg.device)
+        owner = t.searchsorted(stt, cg, right=True) - 1
+        col = owner * slice_ + (cg - stt[owner])
+    return dict(col_ext=xp.as_i32(col), n_local=int(st[rank + 1] - st[rank]), slice=slice_, mode="allgather")

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(rank, world, port, kind, outdir):
+def main(rank, world, port, kind, outdir, exchange="halo"):
     import torch
     import torch.distributed as tdist
     tdist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
@@ -37,9 +37,14 @@ def main(rank, world, port, kind, outdir):
         tdist.all_gather_object(out, obj)
         return out
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    plan = partition.build_plan(t(ix), starts, rank, gather)
     comm = sdist.Comm(ctx, rank, world, tdist)
-    A = sdist.DistCsr.from_plan(comm, plan, int(ip[-1]), t(ip), t(d), adopt=True, to_device=t)
+    if exchange == "allgather":
+        plan = partition.allgather_plan(t(ix), starts, rank)
+        plan["n_ext"] = plan["slice"]            # the SpMV input only needs this rank's (padded) slice
+        A = sdist.DistCsr.from_allgather_plan(comm, plan, int(ip[-1]), t(ip), t(d), adopt=True)
+    else:
+        plan = partition.build_plan(t(ix), starts, rank, gather)
+        A = sdist.DistCsr.from_plan(comm, plan, int(ip[-1]), t(ip), t(d), adopt=True, to_device=t)
     n_loc = plan["n_local"]
     # distributed SpMV of a global test vector
     xg = np.linspace(-1.0, 1.0, n) ** 3
@@ -72,4 +77,4 @@ def main(rank, world, port, kind, outdir):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5])
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6] if len(sys.argv) > 6 else "halo")

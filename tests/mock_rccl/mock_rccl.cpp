@@ -140,6 +140,19 @@ ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataT
     return ncclSuccess;
 }
 
+ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataType_t t, void *comm, hipStream_t st) {
+    Comm *c = (Comm *)comm;
+    const size_t bytes = count * esize(t);
+    if (bytes > BOX) return ncclInvalidArgument;
+    if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipMemcpy(box(c, c->rank, c->rank), send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    barrier(c);
+    for (int r = 0; r < c->n; ++r)
+        if (hipMemcpy((char *)recv + (size_t)r * bytes, box(c, r, r), bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    barrier(c);
+    return ncclSuccess;
+}
+
 ncclResult_t ncclGroupStart() { g_grouped = true; g_ops.clear(); return ncclSuccess; }
 ncclResult_t ncclGroupEnd() {
     g_grouped = false;

@@ -26,19 +26,20 @@ def mock_lib():
     return out
 
 
-def _run(world, kind, mock_lib):
+def _run(world, kind, mock_lib, exchange="halo"):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = tempfile.mkdtemp(prefix="sprs_distgpu_")
     env = dict(os.environ, SPRS_RCCL_LIB=mock_lib, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_gpu_worker.py"), str(r), str(world), str(port), kind, out], env=env)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_gpu_worker.py"), str(r), str(world), str(port), kind, out, exchange], env=env)
              for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
     return [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
 
 
-@pytest.mark.parametrize("world,kind", [(2, "poisson3d"), (3, "poisson3d"), (2, "banded")])
-def test_real_ranks_match_single_process(oracle, mock_lib, world, kind):
+@pytest.mark.parametrize("world,kind,exchange", [(2, "poisson3d", "halo"), (3, "poisson3d", "halo"), (2, "banded", "halo"),
+                                                 (3, "poisson3d", "allgather"), (2, "banded", "allgather")])
+def test_real_ranks_match_single_process(oracle, mock_lib, world, kind, exchange):
     from sprsolve_amd import gen
     if kind == "poisson3d":
         ip, ix, d, rhs = gen.poisson3d(24, 20, 18)
@@ -50,7 +51,7 @@ def test_real_ranks_match_single_process(oracle, mock_lib, world, kind):
         refpc = None
     assert ref.status == oracle.OK
     n = rhs.size
-    res = _run(world, kind, mock_lib)
+    res = _run(world, kind, mock_lib, exchange)
     # SpMV through the real halo exchange: bit-identical to the reference fold on the global matrix
     xg = np.linspace(-1.0, 1.0, n) ** 3
     y = np.concatenate([r["y"] for r in res])

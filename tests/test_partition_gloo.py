@@ -76,3 +76,29 @@ def test_partition_helpers():
     assert np.array_equal(a[0], b[0].numpy()) and a[3] == b[3] and np.array_equal(a[2], b[2])
     assert all(np.array_equal(a[1][p], b[1][p]) for p in a[1])
     assert a[0].max() == 40 + 2 * 20 - 1
+
+
+def test_allgather_plan_renumbering():
+    """north_star's literal exchange: columns renumbered into [rank 0 slice | rank 1 slice | ...] with padded slices."""
+    import torch
+    from sprsolve_amd import gen, partition as P
+    ip, ix, d, rhs = gen.symmetric_banded(1003, hbw=4)
+    starts = P.row_starts(1003, 3)                      # 334 / 334 / 335 rows -> slice 336 (even)
+    for rank in range(3):
+        r0, r1 = int(starts[rank]), int(starts[rank + 1])
+        cols = ix[ip[r0]:ip[r1]]
+        a = P.allgather_plan(cols, starts, rank)
+        b = P.allgather_plan(torch.from_numpy(cols), starts, rank)
+        assert a["slice"] == 336 and a["n_local"] == r1 - r0
+        assert np.array_equal(a["col_ext"], b["col_ext"].numpy())
+        owner = np.searchsorted(starts, cols, side="right") - 1
+        assert np.array_equal(a["col_ext"], owner * 336 + (cols - starts[owner]))
+        # a gathered vector built that way reproduces the global SpMV rows of this rank
+        xg = np.linspace(-1, 1, 1003)
+        gathered = np.zeros(3 * 336)
+        for q in range(3):
+            gathered[q * 336: q * 336 + int(starts[q + 1] - starts[q])] = xg[int(starts[q]):int(starts[q + 1])]
+        import scipy.sparse as sp
+        loc = sp.csr_matrix((d[ip[r0]:ip[r1]], a["col_ext"], ip[r0:r1 + 1] - ip[r0]), shape=(r1 - r0, 3 * 336))
+        glob = sp.csr_matrix((d, ix, ip), shape=(1003, 1003))
+        assert np.array_equal(loc @ gathered, (glob @ xg)[r0:r1])
