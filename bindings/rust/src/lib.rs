@@ -24,6 +24,7 @@ pub mod sys {
     #[repr(C)] pub struct sprs_bicgstab { _p: [u8; 0] }
     #[repr(C)] pub struct sprs_minres { _p: [u8; 0] }
     #[repr(C)] pub struct sprs_csminres { _p: [u8; 0] }
+    #[repr(C)] pub struct sprs_gauss_seidel { _p: [u8; 0] }
 
     pub const SPRS_OK: c_int = 0;
     pub const SPRS_INCOMPATIBLE_RHS_SIZE: c_int = 1;
@@ -32,6 +33,9 @@ pub mod sys {
     pub const SPRS_BREAKDOWN: c_int = 4;
     pub const SPRS_INVALID_PRECOND: c_int = 5;
     pub const SPRS_DIM_MISMATCH: c_int = 6;
+    pub const SPRS_ZERO_DIAGONAL: c_int = 8;
+    pub const SPRS_NOT_SQUARE: c_int = 9;
+    pub const SPRS_NOT_CSR: c_int = 10;
 
     extern "C" {
         pub fn sprs_ctx_create(device: c_int, stream: *mut c_void, out: *mut *mut sprs_ctx) -> c_int;
@@ -86,6 +90,10 @@ pub mod sys {
 
         pub fn sprs_csminres_create_z(a: *const sprs_csr, size: usize, out: *mut *mut sprs_csminres) -> c_int;
         pub fn sprs_csminres_destroy(s: *mut sprs_csminres) -> c_int;
+        pub fn sprs_gauss_seidel_create(a: *const sprs_csr, out: *mut *mut sprs_gauss_seidel) -> c_int;
+        pub fn sprs_gauss_seidel_destroy(g: *mut sprs_gauss_seidel) -> c_int;
+        pub fn sprs_gauss_seidel_solve_d(g: *mut sprs_gauss_seidel, rhs: *const f64, rhs_len: usize, x: *mut f64, x_len: usize,
+            max_iter: usize, eps: f64, its: *mut usize, res: *mut f64) -> c_int;
         pub fn sprs_csminres_solve_z(s: *mut sprs_csminres, rhs: *const Complex64, rhs_len: usize, x: *mut Complex64,
             x_len: usize, max_iter: usize, tol: f64, its: *mut usize, res: *mut f64) -> c_int;
     }
@@ -102,6 +110,9 @@ fn map_status(st: c_int, its: usize, res: f64) -> SolveResult<(usize, f64)> {
         sys::SPRS_INSUFFICIENT_ITER => Err(SolverError::InsufficientIterNum(its)),
         sys::SPRS_BREAKDOWN => Err(SolverError::BreakDown(its)),
         sys::SPRS_INVALID_PRECOND => Err(SolverError::InvalidPreconditioner(format!("beta_{} [{}] is not positive", its, res))),
+        sys::SPRS_ZERO_DIAGONAL => Err(SolverError::ZeorDiagonalElem(its)),
+        sys::SPRS_NOT_SQUARE => Err(SolverError::IncompatibleMatrixFormat(String::from("Not a square matrix"))),
+        sys::SPRS_NOT_CSR => Err(SolverError::IncompatibleMatrixFormat(String::from("Not in CSR format"))),
         sys::SPRS_DIM_MISMATCH => panic!("Dimension mismatch"),
         e => panic!("sprsolve_hip backend error {}", e), // HIP / RCCL failure (cf. mkl_mat.rs:188-193)
     }
@@ -257,3 +268,21 @@ impl<'data> HipCSMinRes<'data> {
     }
 }
 impl<'data> Drop for HipCSMinRes<'data> { fn drop(&mut self) { unsafe { sys::sprs_csminres_destroy(self.handle); } } }
+
+/// `GaussSeidel` on the device (src/gauss_seidel.rs:8-141): level-scheduled sweeps, iterates bit-identical to
+/// the serial sweep.  `solve` returns the ABSOLUTE residual norm like the reference (:107,136).
+pub struct HipGaussSeidel<'data> { _a: &'data HipCsr<f64>, handle: *mut sys::sprs_gauss_seidel }
+impl<'data> HipGaussSeidel<'data> {
+    pub fn new(a: &'data HipCsr<f64>) -> SolveResult<Self> {
+        let mut h = ptr::null_mut();
+        let st = unsafe { sys::sprs_gauss_seidel_create(a.raw(), &mut h) };
+        map_status(st, 0, 0.0).map(|_| HipGaussSeidel { _a: a, handle: h })
+    }
+    pub fn solve(&mut self, rhs: &[f64], x: &mut [f64], max_iter: usize, eps: f64) -> SolveResult<(usize, f64)> {
+        let (mut its, mut res) = (0usize, 0f64);
+        let st = unsafe { sys::sprs_gauss_seidel_solve_d(self.handle, rhs.as_ptr(), rhs.len(), x.as_mut_ptr(), x.len(),
+                                                         max_iter, eps, &mut its, &mut res) };
+        map_status(st, its, res)
+    }
+}
+impl<'data> Drop for HipGaussSeidel<'data> { fn drop(&mut self) { unsafe { sys::sprs_gauss_seidel_destroy(self.handle); } } }

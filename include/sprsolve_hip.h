@@ -39,6 +39,9 @@ enum {
     SPRS_INVALID_PRECOND = 5,       /* InvalidPreconditioner(..)      minres.rs:236-244,279-287 (*its_out = its, *res_out = re(beta^2)) */
     SPRS_DIM_MISMATCH = 6,          /* panic!("Dimension mismatch")   mat.rs:50-52 */
     SPRS_INVALID_ARGUMENT = 7,      /* null handle, index out of i32 range, malformed CSR */
+    SPRS_ZERO_DIAGONAL = 8,         /* ZeorDiagonalElem(row)          gauss_seidel.rs:72-78 (*its_out = row) */
+    SPRS_NOT_SQUARE = 9,            /* IncompatibleMatrixFormat("Not a square matrix")  gauss_seidel.rs:16-20 */
+    SPRS_NOT_CSR = 10,              /* IncompatibleMatrixFormat("Not in CSR format")    gauss_seidel.rs:22-26 */
     SPRS_ERR_HIP = 100,             /* a HIP runtime call failed; see sprs_last_error() */
     SPRS_ERR_RCCL = 101,            /* an RCCL call failed */
     SPRS_ERR_NO_DEVICE = 102        /* no usable gfx950 device */
@@ -51,6 +54,7 @@ typedef struct sprs_bicgstab sprs_bicgstab; /* BiCGStab<T,M>                 (bi
 typedef struct sprs_minres sprs_minres;     /* MinRes<T,M>                   (minres.rs:13-27)    */
 typedef struct sprs_csminres sprs_csminres; /* CSMinRes<T,M>                 (cs_minres.rs:11-25) */
 typedef struct sprs_comm sprs_comm;         /* RCCL communicator of this rank (multi-GPU section)  */
+typedef struct sprs_gauss_seidel sprs_gauss_seidel; /* GaussSeidel<T>        (gauss_seidel.rs:8-31) */
 
 /* ---------------------------------------------------------------- context */
 /* device: HIP device ordinal.  stream: an existing hipStream_t to run on (e.g. the caller's
@@ -62,7 +66,8 @@ const char *sprs_last_error(const sprs_ctx *ctx);  /* text of the last SPRS_ERR_
 const char *sprs_status_str(int status);
 int sprs_version(void);
 /* tuning knobs (defaults chosen for MI355X): key = "grid" (blocks of the streaming kernels),
- * "xcd_chunk" (1: contiguous row-block chunk per XCD), "poll" (iterations between host polls) */
+ * "xcd_chunk" (1: contiguous row-block chunk per XCD), "poll" (iterations between host polls),
+ * "gs_graph" (1: Gauss-Seidel replays a sweep's level launches from a hipGraph; default 0) */
 int sprs_ctx_set(sprs_ctx *ctx, const char *key, int64_t value);
 int64_t sprs_ctx_get(const sprs_ctx *ctx, const char *key);
 
@@ -203,6 +208,20 @@ int sprs_csminres_solve_dev_z(sprs_csminres *S, const sprs_c64 *rhs_dev, size_t 
                               size_t max_iter, double tol, size_t *its_out, double *res_out);
 int sprs_csminres_solve_dev_d(sprs_csminres *S, const double *rhs_dev, size_t rhs_len, double *x_dev, size_t x_len,
                               size_t max_iter, double tol, size_t *its_out, double *res_out);
+
+/* ---------------------------------------------------------------- Gauss-Seidel (src/gauss_seidel.rs)
+ * `GaussSeidel::new(A.view())` / `::solve(rhs, x, max_iter, eps)`; real scalars only (the reference bounds
+ * T: PartialOrd).  The serial sweep is made data-parallel by dependency levels (rows of one level per launch)
+ * without changing its arithmetic: x after k sweeps is bit-identical to the reference's.  On SPRS_OK
+ * (*its_out, *res_out) = Ok((iters, ABSOLUTE residual norm)) exactly as gauss_seidel.rs:107,136 return them.
+ * create: SPRS_NOT_SQUARE / SPRS_NOT_CSR (the handle was built from CSC arrays) as the reference's `new`. */
+int sprs_gauss_seidel_create(const sprs_csr *A, sprs_gauss_seidel **out);
+int sprs_gauss_seidel_destroy(sprs_gauss_seidel *G);
+int64_t sprs_gauss_seidel_levels(const sprs_gauss_seidel *G);   /* number of dependency levels (launches per sweep) */
+int sprs_gauss_seidel_solve_d(sprs_gauss_seidel *G, const double *rhs, size_t rhs_len, double *x, size_t x_len, size_t max_iter, double eps, size_t *its_out, double *res_out);
+int sprs_gauss_seidel_solve_s(sprs_gauss_seidel *G, const float *rhs, size_t rhs_len, float *x, size_t x_len, size_t max_iter, float eps, size_t *its_out, float *res_out);
+int sprs_gauss_seidel_solve_dev_d(sprs_gauss_seidel *G, const double *rhs_dev, size_t rhs_len, double *x_dev, size_t x_len, size_t max_iter, double eps, size_t *its_out, double *res_out);
+int sprs_gauss_seidel_solve_dev_s(sprs_gauss_seidel *G, const float *rhs_dev, size_t rhs_len, float *x_dev, size_t x_len, size_t max_iter, float eps, size_t *its_out, float *res_out);
 
 /* ---------------------------------------------------------------- f32 / Complex<f32>
  * The reference is generic over cauchy::Scalar = {f32, f64, c32, c64} and its unit tests exercise f32 / c32

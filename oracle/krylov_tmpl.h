@@ -391,5 +391,55 @@ int FN(minres)(int saunders, int64_t size, const int64_t *indptr, const int64_t 
     return ORC_INSUFFICIENT_ITER;
 }
 
+
+/* ------------------------------------------------------------------ gauss_seidel.rs:33-140
+ * (the reference bounds T: PartialOrd, i.e. real scalars; instantiated for all T here, used for f64/f32)
+ * work: 2*n scalars (:29).  Returns ORC_ZERO_DIAG with *its_out = row for ZeorDiagonalElem(row). */
+#if !SFX_IS_COMPLEX
+int FN(gauss_seidel)(int64_t size, const int64_t *indptr, const int64_t *indices, const T *data, const T *rhs,
+                     int64_t rhs_len, T *x, int64_t x_len, int64_t max_iter, R eps, T *work, int64_t *its_out,
+                     R *res_out) {
+    FN(csr) A = {size, indptr, indices, data, 0};
+    *its_out = 0; *res_out = 0.0;
+    if (rhs_len != size) return ORC_INCOMPATIBLE_RHS;            /* :41-45 */
+    if (rhs_len != x_len) return ORC_INCOMPATIBLE_X;             /* :46-50 */
+    if (max_iter == 0) { *its_out = 0; return ORC_INSUFFICIENT_ITER; }   /* :52-54 */
+    const int64_t n = rhs_len;
+    R b_norm = 0;                                                /* :57 */
+    for (int64_t row = 0; row < n; ++row) {                      /* :60 unrolled first sweep */
+        T sigma = S(zero)();
+        int have_diag = 0; T diag = S(zero)();
+        for (int64_t k = indptr[row]; k < indptr[row + 1]; ++k) {
+            if (indices[k] != row) sigma = S(add)(sigma, S(mul)(data[k], x[indices[k]]));   /* :66 */
+            else { diag = data[k]; have_diag = 1; }              /* :69 */
+        }
+        if (!have_diag) { *its_out = row; return ORC_ZERO_DIAG; }            /* :72-74 */
+        if (S(sq)(diag) < R_EPS) { *its_out = row; return ORC_ZERO_DIAG; }   /* :76-78 */
+        work[n + row] = diag;                                    /* :81 */
+        b_norm = b_norm + S(sq)(rhs[row]);                       /* :83 */
+        x[row] = S(div)(S(sub)(rhs[row], sigma), diag);          /* :84 */
+    }
+    const R tol2 = eps * R_SQRT(b_norm);                         /* :87 */
+    FN(mv)(&A, x, work);                                         /* :90 */
+    FN(axpy)(n, S(neg)(S(one)()), rhs, work);                    /* :97 */
+    R res = FN(norm2)(n, work);                                  /* :104 */
+    if (res <= tol2) { *its_out = 1; *res_out = res; return ORC_OK; }   /* :106-108 */
+    for (int64_t it = 1; it < max_iter; ++it) {                  /* :110 */
+        for (int64_t row = 0; row < n; ++row) {
+            T sigma = S(zero)();
+            for (int64_t k = indptr[row]; k < indptr[row + 1]; ++k)
+                if (indices[k] != row) sigma = S(add)(sigma, S(mul)(data[k], x[indices[k]]));   /* :116 */
+            x[row] = S(div)(S(sub)(rhs[row], sigma), work[n + row]);         /* :123 */
+        }
+        FN(mv)(&A, x, work);                                     /* :128 */
+        FN(axpy)(n, S(neg)(S(one)()), rhs, work);                /* :131 */
+        res = FN(norm2)(n, work);                                /* :133 */
+        if (res <= tol2) { *its_out = it; *res_out = res; return ORC_OK; }   /* :135-137 */
+    }
+    *its_out = max_iter;                                         /* :139 */
+    return ORC_INSUFFICIENT_ITER;
+}
+#endif
+
 #undef FN
 #undef S

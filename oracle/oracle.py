@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsprs_oracle.so")
 
 OK, INCOMPATIBLE_RHS, INCOMPATIBLE_X, INSUFFICIENT_ITER, BREAKDOWN, INVALID_PRECOND, DIM_MISMATCH = range(7)
+ZERO_DIAG = 8
 
 
 def build(force=False):
@@ -275,3 +276,20 @@ def minres(indptr, indices, data, rhs, x0, max_iter, tol, precond_diag=None, **k
 def csminres(indptr, indices, data, rhs, x0, max_iter, tol, **kw):
     """CSMinRes::solve (src/cs_minres.rs:29-158)."""
     return _solve("csminres", indptr, indices, data, rhs, x0, max_iter, tol, None, **kw)
+
+
+def gauss_seidel(indptr, indices, data, rhs, x0, max_iter, eps):
+    """GaussSeidel::solve (src/gauss_seidel.rs:33-140), real scalars.  Result.res is the ABSOLUTE residual norm the
+    reference returns; Result.its is the row index when status == ZERO_DIAG."""
+    s = _sfx(data.dtype)
+    assert s in "ds", "the reference bounds GaussSeidel to T: PartialOrd (real scalars)"
+    data = _arr(data, data.dtype); rhs = _arr(rhs, data.dtype)
+    x = np.array(x0, dtype=data.dtype, copy=True)
+    indptr = _i64(indptr); indices = _i64(indices)
+    n = indptr.size - 1
+    work = np.zeros(2 * max(n, 1), dtype=data.dtype)
+    its = C.c_int64(0); res = (C.c_double if s == "d" else C.c_float)(0.0)
+    st = getattr(lib(), "orc_gauss_seidel_" + s)(C.c_int64(n), _p(indptr), _p(indices), _p(data), _p(rhs), C.c_int64(rhs.size),
+                                                  _p(x), C.c_int64(x.size), C.c_int64(max_iter), _real(eps, s), _p(work),
+                                                  C.byref(its), C.byref(res))
+    return Result(int(st), int(its.value), float(res.value), x, np.zeros((0, 8)))

@@ -35,6 +35,7 @@
 #define ORC_BREAKDOWN 4
 #define ORC_INVALID_PRECOND 5
 #define ORC_DIM_MISMATCH 6
+#define ORC_ZERO_DIAG 8
 
 #define ORC_CAT2_(a, b) a##b
 #define ORC_CAT2(a, b) ORC_CAT2_(a, b)

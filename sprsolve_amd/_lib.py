@@ -13,6 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 (OK, INCOMPATIBLE_RHS_SIZE, INCOMPATIBLE_X_SIZE, INSUFFICIENT_ITER, BREAKDOWN, INVALID_PRECOND, DIM_MISMATCH,
  INVALID_ARGUMENT) = range(8)
+ZERO_DIAGONAL, NOT_SQUARE, NOT_CSR = 8, 9, 10
 ERR_HIP, ERR_RCCL, ERR_NO_DEVICE = 100, 101, 102
 SOLVER_BICGSTAB, SOLVER_MINRES, SOLVER_CSMINRES = 1, 2, 3
 
@@ -117,6 +118,11 @@ def _protos():
         P["sprs_dist_csr_create_dev_" + s] = [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _pp]
         P["sprs_dist_mul_vec_dev_" + s] = [_vp, _vp, _vp]
         P["sprs_dist_csr_create_allgather_dev_" + s] = [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _pp]
+    P["sprs_gauss_seidel_create"] = [_vp, _pp]
+    P["sprs_gauss_seidel_destroy"] = [_vp]
+    for s in ("d", "s"):
+        P["sprs_gauss_seidel_solve_" + s] = [_vp, _vp, _sz, _vp, _sz, _sz, REAL[s], _psz, C.POINTER(REAL[s])]
+        P["sprs_gauss_seidel_solve_dev_" + s] = [_vp, _vp, _sz, _vp, _sz, _sz, REAL[s], _psz, C.POINTER(REAL[s])]
     P["sprs_solver_set_mode"] = [_vp, _int, _int]
     P["sprs_solver_set_trace"] = [_vp, _int, _vp, _sz]
     P["sprs_solver_trace_rows"] = [_vp, _int, _psz]
@@ -128,7 +134,7 @@ def _protos():
 PROTOTYPES = _protos()
 # entry points declared in include/sprsolve_hip.h that return something other than int
 _SPECIAL_RET = {"sprs_last_error": C.c_char_p, "sprs_status_str": C.c_char_p, "sprs_ctx_get": _i64,
-                "sprs_csr_rows": _i64, "sprs_csr_cols": _i64, "sprs_csr_nnz": _i64, "sprs_version": _int}
+                "sprs_gauss_seidel_levels": _i64, "sprs_csr_rows": _i64, "sprs_csr_cols": _i64, "sprs_csr_nnz": _i64, "sprs_version": _int}
 
 
 def lib():
@@ -157,6 +163,7 @@ def lib():
         for n in ("rows", "cols", "nnz"):
             f = getattr(L, "sprs_csr_" + n); f.argtypes = [_vp]; f.restype = _i64
         L.sprs_version.argtypes = []; L.sprs_version.restype = _int
+        L.sprs_gauss_seidel_levels.argtypes = [_vp]; L.sprs_gauss_seidel_levels.restype = _i64
         _lib = L
     return _lib
 

@@ -35,6 +35,9 @@ const char *sprs_status_str(int s) {
         case SPRS_INVALID_PRECOND: return "Invalid preconditioner";
         case SPRS_DIM_MISMATCH: return "Dimension mismatch";
         case SPRS_INVALID_ARGUMENT: return "Invalid argument";
+        case SPRS_ZERO_DIAGONAL: return "Matrix has zero diagonal element";
+        case SPRS_NOT_SQUARE: return "Incompatible input matrix format: Not a square matrix";
+        case SPRS_NOT_CSR: return "Incompatible input matrix format: Not in CSR format";
         case SPRS_ERR_HIP: return "HIP runtime error";
         case SPRS_ERR_RCCL: return "RCCL error";
         case SPRS_ERR_NO_DEVICE: return "No usable GPU device";
@@ -101,6 +104,7 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     else if (k == "spmv_nt") c->spmv_nt = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_strip") c->spmv_strip = (int)value;
     else if (k == "halo_overlap") c->halo_overlap = value ? 1 : 0;
+    else if (k == "gs_graph") c->gs_graph = value ? 1 : 0;
     else if (k == "poll") { if (value < 1) return SPRS_INVALID_ARGUMENT; c->poll = (int)value; }
     else return SPRS_INVALID_ARGUMENT;
     return SPRS_OK;
@@ -114,6 +118,7 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     if (k == "spmv_nt") return c->spmv_nt;
     if (k == "spmv_strip") return c->spmv_strip;
     if (k == "halo_overlap") return c->halo_overlap;
+    if (k == "gs_graph") return c->gs_graph;
     if (k == "poll") return c->poll;
     if (k == "num_cu") return c->num_cu;
     if (k == "device") return c->device;
@@ -207,7 +212,7 @@ int csr_create_host(sprs_ctx *c, int64_t nrows, int64_t ncols, int64_t nnz, cons
     }
     sprs_csr *A = new sprs_csr();
     A->ctx = c; A->dtype = dtype_of<T>::value;
-    A->nrows = nrows; A->ncols = ncols; A->nnz = nnz; A->owns_arrays = true;
+    A->nrows = nrows; A->ncols = ncols; A->nnz = nnz; A->owns_arrays = true; A->was_csc = storage_csc != 0;
     auto fail = [&](int st) { sprs_csr_destroy(A); return st; };
     if (hipSetDevice(c->device) != hipSuccess) return fail(SPRS_ERR_HIP);
     if (hipMalloc((void **)&A->row_ptr, sizeof(int32_t) * ((size_t)nrows + 1)) != hipSuccess) return fail(SPRS_ERR_HIP);

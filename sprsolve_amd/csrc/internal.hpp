@@ -39,6 +39,7 @@ struct sprs_ctx {
     // (5-10 % slower).  Both kept as experiments — see profiles/r01_tuning.md.
     int spmv_strip = 0;
     int halo_overlap = 1;  // distributed SpMV: run the halo-free rows while the halo travels
+    int gs_graph = 0;    // Gauss-Seidel: 1 = replay a sweep's level launches from a hipGraph (measured: no gain, r01_tuning.md)
     int poll = 16;       // iterations between host polls of the device status word
     double *d_part = nullptr;  // reduction partials for the stand-alone vecalg entry points
     double *d_scal = nullptr;  // small device result buffer
@@ -99,6 +100,7 @@ struct sprs_csr {
     int32_t *col_idx = nullptr;  // device
     void *val = nullptr;         // device, T
     bool owns_arrays = true;
+    bool was_csc = false;        // created from CSC arrays (GaussSeidel::new rejects those, gauss_seidel.rs:22-26)
     int32_t *rowblk = nullptr;   // device: n_rowblk+1 row starts, bit31 set on vector-mode blocks
     int32_t n_rowblk = 0;
     void *blk_desc = nullptr;      // device: one 16-byte {ra, rb|flag, pa, nn} descriptor per row block

@@ -16,7 +16,7 @@ class IncompatibleMatrixFormat(SolverError):
 
 
 class ZeorDiagonalElem(SolverError):
-    """src/error.rs:12-13 (Gauss-Seidel only; kept for API completeness, spelling as upstream)."""
+    """src/error.rs:12-13 (raised by GaussSeidel.solve, gauss_seidel.rs:72-78; spelling as upstream)."""
 
     def __init__(self, row):
         super().__init__("Matrix has zero diagonal element at %d" % row)
@@ -63,6 +63,10 @@ def check(status, ctx=None):
         raise DimensionMismatch("Dimension mismatch")
     if status == _lib.INVALID_ARGUMENT:
         raise ValueError("sprsolve_hip: invalid argument")
+    if status == _lib.NOT_SQUARE:
+        raise IncompatibleMatrixFormat("Not a square matrix")
+    if status == _lib.NOT_CSR:
+        raise IncompatibleMatrixFormat("Not in CSR format")
     detail = ""
     if ctx is not None and status >= _lib.ERR_HIP:
         detail = ": " + (_lib.lib().sprs_last_error(ctx) or b"").decode(errors="replace")
@@ -84,4 +88,6 @@ def solve_result(status, its, res, ctx=None):
         raise BreakDown(its)
     if status == _lib.INVALID_PRECOND:
         raise InvalidPreconditioner("beta_%d [%r] is not positive" % (its, res))
+    if status == _lib.ZERO_DIAGONAL:
+        raise ZeorDiagonalElem(its)
     check(status, ctx)

@@ -86,3 +86,14 @@ def solver_problem(case):
     if case["precond"] is None:
         diag = None
     return dict(indptr=indptr, indices=indices, data=data, rhs=rhs, diag=diag, exact=exact)
+
+
+def gs_problem(case):
+    """-> dict(indptr, indices, data, rhs, exact) for a tests/golden/gs_kat.json case (dtype applied)."""
+    from sprsolve_amd import gen
+    rows, cols = case["shape"]
+    dt = np.float64 if case["dtype"] == "f64" else np.float32
+    indptr, indices, data = gen.grid_laplacian_dirichlet(rows, cols)
+    rhs = gen.dirichlet_rhs(rows, cols)
+    i, j = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+    return dict(indptr=indptr, indices=indices, data=data.astype(dt), rhs=rhs.astype(dt), exact=(i + j).ravel().astype(dt))
