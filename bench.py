@@ -47,6 +47,11 @@ def parse():
                          "the N>1 leg with several ranks on one GPU)")
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
                     help="N>1 SpMV input exchange: sparse halo (default) or north_star's literal full all-gather of x")
+    ap.add_argument("--stream", default="auto", choices=["auto", "csr", "offsets", "dict"],
+                    help="SpMV stream: plain CSR (12 B/nnz), one-byte column-offset codes, offset + value codes; "
+                         "auto = the most compact one the matrix qualifies for (csrc/spmv_dict.hip)")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                    help="library tuning knob (sprs_ctx_set), e.g. --set spmv_grid=2048; experiments only")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the distributed (RCCL) code path even with one rank — rehearsal of the N>1 leg on a 1-GPU box")
     return ap.parse_args()
@@ -182,6 +187,10 @@ def main():
     import sprsolve_amd as sa
     from sprsolve_amd import gen_torch
     ctx = sa.default_ctx(local_rank)
+    ctx.set("spmv_dict", {"auto": -1, "csr": 0, "offsets": 1, "dict": 2}[args.stream])
+    for kv in args.set:
+        k, v = kv.split("=")
+        ctx.set(k, int(v))
     dev = torch.device("cuda", local_rank)
     out = None
     also = {}

@@ -103,6 +103,7 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     else if (k == "xcd_chunk") c->xcd_chunk = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_nt") c->spmv_nt = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_strip") c->spmv_strip = (int)value;
+    else if (k == "spmv_dict") { if (value < -1 || value > 2) return SPRS_INVALID_ARGUMENT; c->spmv_dict = (int)value; }
     else if (k == "halo_overlap") c->halo_overlap = value ? 1 : 0;
     else if (k == "gs_graph") c->gs_graph = value ? 1 : 0;
     else if (k == "poll") { if (value < 1) return SPRS_INVALID_ARGUMENT; c->poll = (int)value; }
@@ -117,6 +118,7 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     if (k == "spmv_grid") return c->spmv_grid;
     if (k == "spmv_nt") return c->spmv_nt;
     if (k == "spmv_strip") return c->spmv_strip;
+    if (k == "spmv_dict") return c->spmv_dict;
     if (k == "halo_overlap") return c->halo_overlap;
     if (k == "gs_graph") return c->gs_graph;
     if (k == "poll") return c->poll;
@@ -501,6 +503,7 @@ int sprs_csr_destroy(sprs_csr *A) {
     if (A->rowblk) (void)hipFree(A->rowblk);
     if (A->blk_order) (void)hipFree(A->blk_order);
     if (A->blk_desc) (void)hipFree(A->blk_desc);
+    free_dict(A);
     if (A->x_tmp) (void)hipFree(A->x_tmp);
     if (A->y_tmp) (void)hipFree(A->y_tmp);
     if (A->part) (void)hipFree(A->part);
@@ -521,6 +524,12 @@ int sprs_csr_destroy(sprs_csr *A) {
 int64_t sprs_csr_rows(const sprs_csr *A) { return A ? A->nrows : -1; }
 int64_t sprs_csr_cols(const sprs_csr *A) { return A ? A->ncols : -1; }
 int64_t sprs_csr_nnz(const sprs_csr *A) { return A ? A->nnz : -1; }
+int sprs_csr_stream_format(const sprs_csr *A, int *n_offsets, int *n_values) {
+    if (!A) return -1;
+    if (n_offsets) *n_offsets = A->dict ? A->dict->n_off : 0;
+    if (n_values) *n_values = A->dict ? A->dict->n_val : 0;
+    return dict_mode(A);
+}
 
 int sprs_diag_precond_destroy(sprs_diag *P) {
     if (!P) return SPRS_OK;

@@ -86,4 +86,37 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
                  st__ = (int64_t)gridDim.x * BLOCK;                                         \
          i < np__; i += st__)
 
+constexpr int ROWS_CAP = WAVE;    // rows per stream block: one wavefront owns a block, one lane per row in the reduce phase
+constexpr int LONG_ROW = 96;      // rows longer than this go to the wavefront-per-row path
+constexpr uint32_t VEC_FLAG = 0x80000000u;
+
+
+// nnz per stream block = per wavefront (its private LDS slice; x4 wavefronts per workgroup)
+template <class T> struct nnz_cap { static constexpr int value = 512; };        // f64: 4 KiB per wavefront
+template <> struct nnz_cap<cplx> { static constexpr int value = 320; };         // 5 KiB
+template <> struct nnz_cap<float> { static constexpr int value = 512; };        // 2 KiB
+template <> struct nnz_cap<cplxf> { static constexpr int value = 512; };        // 4 KiB
+static inline int nnz_cap_of(int dtype) { return dtype == DT_Z ? nnz_cap<cplx>::value : 512; }
+
+
+// Row-block descriptor, precomputed at handle creation so that one 16-byte load tells a workgroup
+// everything about its next block (no dependent rowblk -> row_ptr -> row_ptr chain per block).
+struct alignas(16) BlkDesc {
+    int32_t ra;      // first row
+    int32_t rb;      // one past the last row; bit 31 = vector (wavefront-per-row) block
+    int32_t pa;      // first nnz
+    int32_t nn;      // nnz in the block
+};
+
+
+// Ordering point between a wavefront's LDS writes and its own later LDS reads (and vice versa).  LDS
+// operations of one wavefront execute in issue order, so no s_barrier and no wait is needed — this only
+// stops the compiler from moving LDS accesses across it.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+
 }  // namespace sprs

@@ -38,6 +38,9 @@ struct sprs_ctx {
     // ~5.5 reads to ~1 but was 2 % SLOWER), >= 2 = strip-major walk with that many rows per strip
     // (5-10 % slower).  Both kept as experiments — see profiles/r01_tuning.md.
     int spmv_strip = 0;
+    // dictionary-compressed SpMV stream: -1 auto (offsets and, when few, values), 0 plain CSR, 1 offsets only,
+    // 2 offsets + values.  Read at handle creation (what is built) and at launch (what is used).
+    int spmv_dict = -1;
     int halo_overlap = 1;  // distributed SpMV: run the halo-free rows while the halo travels
     int gs_graph = 0;    // Gauss-Seidel: 1 = replay a sweep's level launches from a hipGraph (measured: no gain, r01_tuning.md)
     int poll = 16;       // iterations between host polls of the device status word
@@ -92,6 +95,17 @@ struct sprs_dist_info {
     hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
 };
 
+// Dictionary-compressed copy of the (col_idx, val) stream (spmv_dict.hip): one byte per nnz indexing the
+// table of distinct (col - row) offsets and, for real matrices with few distinct values, one byte per nnz
+// indexing the table of distinct values.  Built at handle creation when the matrix qualifies.
+struct sprs_dict {
+    uint8_t *idx_code = nullptr;   // device, nnz (+ pad)
+    uint8_t *val_code = nullptr;   // device, nnz (+ pad) or null
+    int32_t *off_tab = nullptr;    // device, 256 entries: col - row
+    void *val_tab = nullptr;       // device, 256 entries of T, or null
+    int n_off = 0, n_val = 0;
+};
+
 struct sprs_csr {
     sprs_ctx *ctx = nullptr;
     int dtype = 0;               // sprs::DT_D / DT_Z / DT_S / DT_C
@@ -112,6 +126,7 @@ struct sprs_csr {
     void *x_tmp = nullptr, *y_tmp = nullptr;
     double *part = nullptr;      // partials for mul_vec_dot
     sprs_dist_info *dist = nullptr;   // non-null: row block of a matrix partitioned over ranks
+    sprs_dict *dict = nullptr;        // non-null: dictionary-compressed stream available (spmv_dict.hip)
 };
 
 struct sprs_diag {
@@ -143,6 +158,13 @@ template <class T>
 int launch_spmv_subset(const sprs_csr *A, const int32_t *order, int count, const T *x, T *y, int dot_mode, const T *u,
                        T *part0, T *part1, const int *status, bool conj_x);
 int spmv_subset_grid(const sprs_csr *A, int count);
+// ---- spmv_dict.hip
+int build_dict(sprs_csr *A, bool has_vector_blocks);   // SPRS_OK also when the matrix does not qualify (A->dict stays null)
+void free_dict(sprs_csr *A);
+int dict_mode(const sprs_csr *A);                      // 0 plain, 1 offsets, 2 offsets + values: what launch_spmv will use
+template <class T>
+int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int count, int g, int xcd_chunk, const T *x, T *y,
+                     int dot_mode, const T *u, T *part0, T *part1, const int *status, bool conj_x);
 
 // ---- blas1.hip  (all on ctx->stream, asynchronous)
 template <class T, class S> int launch_axpy(sprs_ctx *c, size_t n, S a, const T *x, T *y);

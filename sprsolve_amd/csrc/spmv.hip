@@ -23,18 +23,7 @@
 
 namespace sprs {
 
-constexpr int ROWS_CAP = WAVE;    // rows per stream block: one wavefront owns a block, one lane per row in the reduce phase
-constexpr int LONG_ROW = 96;      // rows longer than this go to the wavefront-per-row path
-constexpr uint32_t VEC_FLAG = 0x80000000u;
-
 struct BlkDescHost { int32_t ra, rb, pa, nn; };   // == BlkDesc (device side)
-
-// nnz per stream block = per wavefront (its private LDS slice; x4 wavefronts per workgroup)
-template <class T> struct nnz_cap { static constexpr int value = 512; };        // f64: 4 KiB per wavefront
-template <> struct nnz_cap<cplx> { static constexpr int value = 320; };         // 5 KiB
-template <> struct nnz_cap<float> { static constexpr int value = 512; };        // 2 KiB
-template <> struct nnz_cap<cplxf> { static constexpr int value = 512; };        // 4 KiB
-static inline int nnz_cap_of(int dtype) { return dtype == DT_Z ? nnz_cap<cplx>::value : 512; }
 
 int build_schedule(sprs_csr *A, const std::vector<int32_t> &blk);
 
@@ -80,7 +69,10 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
     SPRS_HIP_TRY(c, hipMalloc((void **)&A->rowblk, blk.size() * sizeof(int32_t)));
     SPRS_HIP_TRY(c, hipMemcpyAsync(A->rowblk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return build_schedule(A, blk);
+    SPRS_TRY(build_schedule(A, blk));
+    bool has_vec = false;
+    for (int b = 0; b < A->n_rowblk; ++b) has_vec |= ((uint32_t)blk[b] & VEC_FLAG) != 0;
+    return build_dict(A, has_vec);   // dictionary-compressed stream when the matrix qualifies (spmv_dict.hip)
 }
 
 // streaming (read-once) loads: keep the matrix stream from evicting the gathered x lines
@@ -99,24 +91,6 @@ template <bool NT> __device__ __forceinline__ float ld_val(const float *p) { ret
 template <bool NT> __device__ __forceinline__ cplxf ld_val(const cplxf *p) {
     if (NT) return cplxf{__builtin_nontemporal_load(&p->re), __builtin_nontemporal_load(&p->im)};
     return *p;
-}
-
-// Row-block descriptor, precomputed at handle creation so that one 16-byte load tells a workgroup
-// everything about its next block (no dependent rowblk -> row_ptr -> row_ptr chain per block).
-struct alignas(16) BlkDesc {
-    int32_t ra;      // first row
-    int32_t rb;      // one past the last row; bit 31 = vector (wavefront-per-row) block
-    int32_t pa;      // first nnz
-    int32_t nn;      // nnz in the block
-};
-
-// Ordering point between a wavefront's LDS writes and its own later LDS reads (and vice versa).  LDS
-// operations of one wavefront execute in issue order, so no s_barrier and no wait is needed — this only
-// stops the compiler from moving LDS accesses across it.
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 template <class T, int DOT, bool CONJX, bool NT>
@@ -383,7 +357,10 @@ static inline bool is_cache_resident(const sprs_csr *A) {
 }
 static inline int base_grid(const sprs_csr *A) {
     int g = A->ctx->spmv_grid;
-    if (g <= 0) g = A->ctx->num_cu * 4;   // measured best for HBM-bound and cache-resident matrices alike (A/B on the full solve)
+    // measured (A/B on the full solve): 4 workgroups per CU for the plain and offset-code streams (HBM-bound and
+    // cache-resident matrices alike); 6 per CU for the offset + value-code stream, whose kernel is bound by the
+    // CU's vector-memory request rate and latency rather than by HBM (7 per CU is slower again)
+    if (g <= 0) g = A->ctx->num_cu * (dict_mode(A) == 2 ? 6 : 4);
     if (g < 8) g = 8;
     if (g > MAX_GRID / 2) g = MAX_GRID / 2;
     return g & ~7;
@@ -409,6 +386,8 @@ static int launch_spmv_impl(const sprs_csr *A, const int32_t *order, int count, 
     // (the XCD-period schedule encodes its placement in the order array and needs the round-robin walk)
     const bool sched = A->blk_order != nullptr;
     const int xcd_chunk = sched ? (A->sched_strip_major ? 1 : 0) : (c->xcd_chunk < 0 ? (cache_resident ? 1 : 0) : c->xcd_chunk);
+    if (const int dm = dict_mode(A))
+        return launch_spmv_dict<T>(A, dm, order, count, g, xcd_chunk, x, y, dot_mode, u, part0, part1, status, conj_x);
     const bool nt = c->spmv_nt > 0;   // measured: non-temporal stream loads never pay once the loads are batched
 #define SPRS_SPMV2(D, CJ, NTF)                                                                                        \
     hipLaunchKernelGGL((spmv_kernel<T, D, CJ, NTF>), dim3(g), dim3(BLOCK), 0, c->stream, count,                       \

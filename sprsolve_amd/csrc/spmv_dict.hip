@@ -1,0 +1,480 @@
+// Dictionary-compressed CSR SpMV — the same arithmetic as spmv.hip on fewer HBM bytes.
+//
+// The SpMV is HBM-bound and (col_idx, val) is 12 of its ~15 bytes per nnz (f64).  Matrices that come from
+// grids and bands (every BASELINE config; the reference's own tests and benches) repeat themselves:
+//   * the column OFFSET col - row takes a handful of values (7 for the 7-point stencil, 9 for the band of
+//     cfg 3, the halo blocks of a slab partition add a few more);
+//   * constant-coefficient operators also repeat their VALUES (two distinct ones in cfg 2 and cfg 5).
+// At handle creation the distinct offsets — and, for real scalars, the distinct value bit patterns — are
+// collected on the device; if there are <= 256 of them each nnz is re-encoded as ONE BYTE per table
+// (CSR-DU / CSR-VI style, Kourtis et al.), so the stream shrinks from 12 to 9 B/nnz (offsets only) or to
+// 2 B/nnz (offsets + values).  Values are matched by bit pattern, the tables hold the original values
+// and every product x[col]*val is formed and added in the original order, so y is BIT-IDENTICAL to the
+// plain kernel's (and to the reference's fold, mat.rs:100-105).  Matrices that do not qualify (too many
+// offsets, rows longer than LONG_ROW) keep the plain stream; nothing is approximated.
+//
+// Kernel shape: as in spmv.hip a wavefront owns a row block (<= 64 rows, <= CAP nnz).  The code bytes are
+// staged to LDS with aligned dword loads; then lane r walks row ra + r: col = row + off_tab[code], the x
+// gather of consecutive rows is itself coalesced, products are added left to right from zero.
+#include <algorithm>
+#include <cstring>
+
+#include "device.hpp"
+
+namespace sprs {
+
+namespace {
+
+constexpr int TAB = 256;          // dictionary entries (one byte per code)
+constexpr int HSLOTS = 1024;      // open-addressing table used while collecting (4x the dictionary)
+constexpr uint32_t EMPTY32 = 0x80000000u;            // INT32_MIN: never a valid col - row (|.| < 2^31 - 1)
+constexpr uint64_t EMPTY64 = 0xFFFFFFFFFFFFFFFFull;  // a NaN pattern; a matrix holding it is not compressed
+
+__device__ __forceinline__ uint32_t hash32(uint32_t k) { k ^= k >> 16; k *= 0x7feb352du; k ^= k >> 15; k *= 0x846ca68bu; k ^= k >> 16; return k; }
+__device__ __forceinline__ uint32_t hash64(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; return (uint32_t)k; }
+
+// value keys: the bit pattern, so -0.0 / NaN payloads survive the round trip
+__device__ __forceinline__ uint64_t key_of(double v) { return (uint64_t)__double_as_longlong(v); }
+__device__ __forceinline__ uint64_t key_of(float v) { return (uint64_t)__float_as_uint(v); }
+
+// insert-or-find; returns the slot or -1 when the table is (being) abandoned
+__device__ __forceinline__ int probe32(uint32_t *tab, int *count, uint32_t key, bool insert) {
+    uint32_t h = hash32(key) & (HSLOTS - 1);
+    for (int t = 0; t < HSLOTS; ++t, h = (h + 1) & (HSLOTS - 1)) {
+        uint32_t cur = __hip_atomic_load(tab + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return (int)h;
+        if (cur == EMPTY32) {
+            if (!insert) return -1;
+            if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > TAB) return -1;
+            cur = atomicCAS(tab + h, EMPTY32, key);
+            if (cur == EMPTY32) { atomicAdd(count, 1); return (int)h; }
+            if (cur == key) return (int)h;
+        }
+    }
+    return -1;
+}
+__device__ __forceinline__ int probe64(unsigned long long *tab, int *count, uint64_t key, bool insert) {
+    uint32_t h = hash64(key) & (HSLOTS - 1);
+    for (int t = 0; t < HSLOTS; ++t, h = (h + 1) & (HSLOTS - 1)) {
+        uint64_t cur = __hip_atomic_load(tab + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return (int)h;
+        if (cur == EMPTY64) {
+            if (!insert) return -1;
+            if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > TAB) return -1;
+            cur = atomicCAS(tab + h, (unsigned long long)EMPTY64, (unsigned long long)key);
+            if (cur == EMPTY64) { atomicAdd(count, 1); return (int)h; }
+            if (cur == key) return (int)h;
+        }
+    }
+    return -1;
+}
+
+// counts[0] = distinct offsets, counts[1] = distinct values, counts[2] = value dictionary impossible
+template <class T, bool VALS>
+__global__ __launch_bounds__(BLOCK) void dict_collect_kernel(int n, const int32_t *__restrict__ row_ptr,
+                                                             const int32_t *__restrict__ col_idx, const T *__restrict__ val,
+                                                             uint32_t *off_h, unsigned long long *val_h, int *counts) {
+    uint32_t last_off = EMPTY32;
+    uint64_t last_val = EMPTY64;
+    for (int row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK) {
+        for (int k = row_ptr[row]; k < row_ptr[row + 1]; ++k) {
+            const uint32_t d = (uint32_t)(col_idx[k] - row);
+            if (d != last_off) { (void)probe32(off_h, counts + 0, d, true); last_off = d; }
+            if constexpr (VALS) {
+                const uint64_t kv = key_of(val[k]);
+                if (kv == EMPTY64) { counts[2] = 1; continue; }
+                if (kv != last_val) { (void)probe64(val_h, counts + 1, kv, true); last_val = kv; }
+            }
+        }
+    }
+}
+
+template <class T, bool VALS>
+__global__ __launch_bounds__(BLOCK) void dict_encode_kernel(int n, const int32_t *__restrict__ row_ptr,
+                                                            const int32_t *__restrict__ col_idx, const T *__restrict__ val,
+                                                            uint32_t *off_h, const uint8_t *__restrict__ off_code_of_slot,
+                                                            unsigned long long *val_h, const uint8_t *__restrict__ val_code_of_slot,
+                                                            uint8_t *__restrict__ idx_code, uint8_t *__restrict__ val_code,
+                                                            int *__restrict__ bad) {
+    for (int row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK) {
+        for (int k = row_ptr[row]; k < row_ptr[row + 1]; ++k) {
+            const int so = probe32(off_h, nullptr, (uint32_t)(col_idx[k] - row), false);
+            if (so < 0) { *bad = 1; continue; }
+            idx_code[k] = off_code_of_slot[so];
+            if constexpr (VALS) {
+                const int sv = probe64(val_h, nullptr, key_of(val[k]), false);
+                if (sv < 0) { *bad = 1; continue; }
+                val_code[k] = val_code_of_slot[sv];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// What a wavefront loads for one row block before it can work on it.  The loads of block i+1 are issued
+// before block i is processed (and the descriptor of block i+2 before that), so a block costs one exposed
+// memory round trip — its x gather — instead of three dependent ones (descriptor -> codes/row_ptr -> x).
+template <class T, bool VALDICT, int ITEMS>
+struct BlkLoads {
+    int ra, rb, pa, nn;      // descriptor
+    int s;                   // row_ptr[row] of this lane's row
+    T uu;                    // dot operand of this lane's row
+    uint32_t wi[2], wv[2];   // code dwords
+    int di[2];               // ... and the LDS slots they go to
+    T vv[VALDICT ? 1 : ITEMS];
+};
+
+template <class T, int DOT, bool CONJX, bool VALDICT>
+__global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_chunk, const BlkDesc *__restrict__ desc,
+                                                          const int32_t *__restrict__ order,
+                                                          const int32_t *__restrict__ row_ptr,
+                                                          const uint8_t *__restrict__ idx_code,
+                                                          const uint8_t *__restrict__ val_code,
+                                                          const int32_t *__restrict__ off_tab, const T *__restrict__ val_tab,
+                                                          const T *__restrict__ val, const T *__restrict__ x,
+                                                          T *__restrict__ y, const T *__restrict__ u, T *__restrict__ part0,
+                                                          T *__restrict__ part1, const int *__restrict__ status) {
+    constexpr int CAP = nnz_cap<T>::value;          // nnz per row block (per wavefront)
+    constexpr int CW = CAP / 4 + 1;                 // dwords holding CAP code bytes at any 4-byte phase
+    constexpr int ITEMS = CAP / WAVE;
+    using Loads = BlkLoads<T, VALDICT, ITEMS>;
+    __shared__ int32_t s_off[TAB];
+    __shared__ T s_val[VALDICT ? TAB : 1];
+    __shared__ uint32_t s_ic[NWAVE][CW + 1];
+    __shared__ uint32_t s_vc[VALDICT ? NWAVE : 1][VALDICT ? CW + 1 : 1];
+    __shared__ T s_v[VALDICT ? 1 : NWAVE][VALDICT ? 1 : CAP];
+    __shared__ T red[NWAVE];
+    if (status != nullptr && *status != ST_RUNNING) return;
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    // the wavefront index as a SCALAR: the block walk (b, descriptors, loop branches) then lives in SGPRs and
+    // the descriptor loads go through the scalar cache instead of queueing behind the vector loads
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    s_off[tid] = off_tab[tid];                      // BLOCK == TAB
+    if constexpr (VALDICT) s_val[tid] = val_tab[tid];
+    __syncthreads();                                // the only workgroup barrier: tables are read-only afterwards
+
+    const uint8_t *ic = reinterpret_cast<const uint8_t *>(s_ic[wv]);
+    [[maybe_unused]] const uint8_t *vc = reinterpret_cast<const uint8_t *>(s_vc[VALDICT ? wv : 0]);
+    [[maybe_unused]] T *vs = s_v[VALDICT ? 0 : wv];
+    T d0 = szero<T>(), d1 = szero<T>();
+
+    int b, bstep, bend;                             // the persistent walk of spmv.hip
+    if (xcd_chunk) {
+        const int chunk = (n_rowblk + 7) >> 3;
+        const int xcd = blockIdx.x & 7;
+        b = xcd * chunk + (blockIdx.x >> 3) * NWAVE + wv;
+        bstep = (gridDim.x >> 3) * NWAVE;
+        bend = min(n_rowblk, (xcd + 1) * chunk);
+    } else {
+        b = blockIdx.x * NWAVE + wv; bstep = gridDim.x * NWAVE; bend = n_rowblk;
+    }
+    if (b >= bend) b = bend;                        // falls through to the partial sums below
+
+    // Descriptors (and schedule entries) are fetched with VECTOR loads on a wave-uniform address: scalar loads
+    // return out of order, so one in flight would turn every later LDS wait into a full lgkmcnt(0) stall.
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef const v4i __attribute__((address_space(1))) *gv4i_p;
+    typedef const int32_t __attribute__((address_space(1))) *gi32_p;
+    uintptr_t desc_a = reinterpret_cast<uintptr_t>(desc), order_a = reinterpret_cast<uintptr_t>(order);
+    asm volatile("" : "+v"(desc_a));                // hide the uniformity: keeps the loads on the vector path
+    asm volatile("" : "+v"(order_a));
+    const gv4i_p desc_v = reinterpret_cast<gv4i_p>(desc_a);
+    const gi32_p order_v = reinterpret_cast<gi32_p>(order_a);
+    auto load_desc = [&](int bi) -> BlkDesc { const v4i q = desc_v[bi]; return BlkDesc{q.x, q.y, q.z, q.w}; };
+    auto block_index = [&](int bi) -> int { return order ? order_v[bi] : bi; };
+    // Phase 1 of a block: issue its loads (unconditional, clamped addresses: they go out back to back).
+    // Nothing here uses a loaded value, so the wavefront does not wait.
+    auto issue = [&](const BlkDesc &d, Loads &L) {
+        L.ra = d.ra; L.rb = d.rb & 0x7fffffff; L.pa = d.pa; L.nn = d.nn;   // dictionary matrices have no vector blocks
+        const int r = L.ra + lane;
+        const int rcl = r < L.rb ? r : L.rb - 1;
+        L.s = row_ptr[rcl];                        // row_ptr[row + 1] comes from the next lane (adopt): one load, not two
+        if (DOT != 0) L.uu = u[rcl];
+        const int shift = L.pa & 3;
+        const int nd = max((shift + L.nn + 3) >> 2, 1);                    // dwords covering [pa, pa + nn), <= CW
+        const uint32_t *gi = reinterpret_cast<const uint32_t *>(idx_code + (L.pa - shift));
+        [[maybe_unused]] const uint32_t *gv = reinterpret_cast<const uint32_t *>(val_code + (L.pa - shift));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            L.di[i] = min(lane + i * WAVE, nd - 1);
+            L.wi[i] = gi[L.di[i]];
+            if constexpr (VALDICT) L.wv[i] = gv[L.di[i]];
+        }
+        if constexpr (!VALDICT) {
+            const int last = max(L.nn - 1, 0);
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) L.vv[i] = val[L.pa + min(lane + i * WAVE, last)];
+        }
+    };
+    // Phase 2: the loads have landed — put the code bytes (and values) into this wavefront's LDS slice.
+    // Called when the slice is free: before the first block and at the bottom of the loop, after the row
+    // phase of the previous block has consumed it.
+    auto stage = [&](const Loads &L) {
+        const int shift = L.pa & 3;
+        if (L.nn > 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {            // clamped duplicates store the same dword to the same slot
+                s_ic[wv][L.di[i]] = L.wi[i];
+                if constexpr (VALDICT) s_vc[wv][L.di[i]] = L.wv[i];
+            }
+            if constexpr (CW > 2 * WAVE) {
+                if (((shift + L.nn + 3) >> 2) > 2 * WAVE && lane == 0) {   // the 129th dword exists only when shift + nn > 512
+                    s_ic[wv][2 * WAVE] = reinterpret_cast<const uint32_t *>(idx_code + (L.pa - shift))[2 * WAVE];
+                    if constexpr (VALDICT) s_vc[wv][2 * WAVE] = reinterpret_cast<const uint32_t *>(val_code + (L.pa - shift))[2 * WAVE];
+                }
+            }
+            if constexpr (!VALDICT) {
+#pragma unroll
+                for (int i = 0; i < ITEMS; ++i) {
+                    const int k = lane + i * WAVE;
+                    if (k < L.nn) vs[k] = L.vv[i];
+                }
+            }
+        }
+    };
+
+    // loop-carried state of the block being processed: plain values, no load in flight behind them
+    int c_ra = 0, c_rb = 0, c_s = 0, c_len = 0, c_shift = 0;
+    T c_uu = szero<T>();
+    auto adopt = [&](const Loads &L) {
+        const int r = L.ra + lane;
+        c_ra = L.ra; c_rb = L.rb; c_shift = L.pa & 3;
+        c_s = L.s - L.pa;
+        int e = __shfl_down(L.s, 1, WAVE);          // next row's start; the block's last row ends at pa + nn
+        if (r == L.rb - 1) e = L.pa + L.nn;
+        c_len = r < L.rb ? e - L.s : 0;
+        if (DOT != 0) c_uu = L.uu;
+    };
+    // Software pipeline, everything consumed one iteration after it was requested:
+    //   top of iteration i:    issue loads of block i+1 (descriptor dn), descriptor of block i+2 (index o2),
+    //                          schedule entry of block i+3
+    //   middle:                row phase of block i — its x gather is the only exposed memory round trip
+    //   bottom:                stage block i+1 into LDS, rotate dn <- dn2, o2 <- o3
+    BlkDesc dn{0, 1, 0, 0};
+    int o2 = 0;
+    if (b < bend) {
+        Loads first;
+        issue(load_desc(block_index(b)), first);
+        if (b + bstep < bend) dn = load_desc(block_index(b + bstep));
+        if (b + 2 * bstep < bend) o2 = block_index(b + 2 * bstep);
+        stage(first);
+        adopt(first);
+    }
+    for (; b < bend; b += bstep) {
+        const bool more = b + bstep < bend;
+        Loads nxt;
+        BlkDesc dn2{0, 1, 0, 0};
+        int o3 = 0;
+        if (b + 2 * bstep < bend) dn2 = load_desc(o2);
+        if (b + 3 * bstep < bend) o3 = block_index(b + 3 * bstep);
+        if (more) issue(dn, nxt);
+        wave_lds_fence();
+        // ---- one lane per row: mat.rs:100-105, fold(T::zero(), |acc, (col, val)| acc + x[col] * val)
+        const int r = c_ra + lane;
+        const int s = c_s, len = c_len, shift = c_shift;
+        T acc = szero<T>();
+        for (int j0 = 0; __builtin_amdgcn_ballot_w64(j0 < len) != 0; j0 += 8) {
+            T xg[8], av[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool valid = j0 + t < len;
+                if (t >= 4 && __builtin_amdgcn_ballot_w64(valid) == 0) {   // no row of the block is this long
+                    xg[t] = szero<T>(); av[t] = szero<T>();
+                    continue;
+                }
+                const int k = valid ? s + j0 + t : 0;             // always inside the staged bytes
+                const int off = s_off[ic[shift + k]];
+                const int col = valid ? r + off : 0;              // lanes past their row gather x[0] and drop it
+                xg[t] = x[col];
+                if constexpr (VALDICT) av[t] = s_val[vc[shift + k]];
+                else av[t] = vs[k];
+            }
+            // all 8 gathers go out before the first product is formed (the scheduler otherwise hoists the
+            // first multiply between them and with it a wait for the first gather: two round trips per block)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (j0 + t < len) acc = sadd(acc, smul(CONJX ? sconj(xg[t]) : xg[t], av[t]));
+        }
+        if (r < c_rb) {
+            y[r] = acc;
+            if (DOT == 1) d0 = sadd(d0, smul(sconj(c_uu), acc));
+            if (DOT == 2) { d0 = sadd(d0, smul(sconj(acc), acc)); d1 = sadd(d1, smul(sconj(acc), c_uu)); }
+        }
+        wave_lds_fence();   // the row phase is done with the LDS slice: refill it for the next block
+        if (more) { stage(nxt); adopt(nxt); }
+        dn = dn2; o2 = o3;
+    }
+    if (DOT >= 1) {
+        d0 = block_sum(d0, red);
+        if (tid == 0) part0[blockIdx.x] = d0;
+    }
+    if (DOT == 2) {
+        d1 = block_sum(d1, red);
+        if (tid == 0) part1[blockIdx.x] = d1;
+    }
+}
+
+template <class T> struct has_val_dict { static constexpr bool value = false; };
+template <> struct has_val_dict<double> { static constexpr bool value = true; };
+template <> struct has_val_dict<float> { static constexpr bool value = true; };
+
+template <class T>
+int build_dict_t(sprs_csr *A) {
+    sprs_ctx *c = A->ctx;
+    constexpr bool VALS = has_val_dict<T>::value;
+    const bool want_vals = VALS && c->spmv_dict != 1;
+    const int n = (int)A->nrows;
+    uint32_t *off_h = nullptr; unsigned long long *val_h = nullptr; int *counts = nullptr;
+    uint8_t *slot_codes = nullptr;
+    auto cleanup = [&]() {
+        if (off_h) (void)hipFree(off_h);
+        if (val_h) (void)hipFree(val_h);
+        if (counts) (void)hipFree(counts);
+        if (slot_codes) (void)hipFree(slot_codes);
+    };
+#define DICT_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { snprintf(c->err, sizeof(c->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); cleanup(); return SPRS_ERR_HIP; } } while (0)
+    DICT_TRY(hipMalloc((void **)&off_h, sizeof(uint32_t) * HSLOTS));
+    DICT_TRY(hipMalloc((void **)&val_h, sizeof(unsigned long long) * HSLOTS));
+    DICT_TRY(hipMalloc((void **)&counts, sizeof(int) * 4));
+    DICT_TRY(hipMalloc((void **)&slot_codes, 2 * HSLOTS));
+    std::vector<uint32_t> h_off(HSLOTS, EMPTY32);
+    std::vector<unsigned long long> h_val(HSLOTS, EMPTY64);
+    DICT_TRY(hipMemcpyAsync(off_h, h_off.data(), sizeof(uint32_t) * HSLOTS, hipMemcpyHostToDevice, c->stream));
+    DICT_TRY(hipMemcpyAsync(val_h, h_val.data(), sizeof(unsigned long long) * HSLOTS, hipMemcpyHostToDevice, c->stream));
+    DICT_TRY(hipMemsetAsync(counts, 0, sizeof(int) * 4, c->stream));
+    const int g = std::max(1, std::min(c->num_cu * 8, (n + BLOCK - 1) / BLOCK));
+    const T *val = reinterpret_cast<const T *>(A->val);
+    if (want_vals)
+        hipLaunchKernelGGL((dict_collect_kernel<T, VALS>), dim3(g), dim3(BLOCK), 0, c->stream, n, A->row_ptr, A->col_idx, val, off_h, val_h, counts);
+    else
+        hipLaunchKernelGGL((dict_collect_kernel<T, false>), dim3(g), dim3(BLOCK), 0, c->stream, n, A->row_ptr, A->col_idx, val, off_h, val_h, counts);
+    DICT_TRY(hipGetLastError());
+    int h_counts[4] = {0, 0, 0, 0};
+    DICT_TRY(hipMemcpyAsync(h_counts, counts, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+    DICT_TRY(hipMemcpyAsync(h_off.data(), off_h, sizeof(uint32_t) * HSLOTS, hipMemcpyDeviceToHost, c->stream));
+    DICT_TRY(hipMemcpyAsync(h_val.data(), val_h, sizeof(unsigned long long) * HSLOTS, hipMemcpyDeviceToHost, c->stream));
+    DICT_TRY(hipStreamSynchronize(c->stream));
+    if (h_counts[0] > TAB || h_counts[0] == 0) { cleanup(); return SPRS_OK; }      // too many offsets: plain CSR
+    const bool use_vals = want_vals && h_counts[2] == 0 && h_counts[1] > 0 && h_counts[1] <= TAB;
+    // codes in ascending key order (deterministic tables regardless of which thread inserted first)
+    std::vector<std::pair<int32_t, int>> offs;
+    std::vector<std::pair<uint64_t, int>> vals;
+    for (int sl = 0; sl < HSLOTS; ++sl) {
+        if (h_off[sl] != EMPTY32) offs.push_back({(int32_t)h_off[sl], sl});
+        if (use_vals && h_val[sl] != EMPTY64) vals.push_back({(uint64_t)h_val[sl], sl});
+    }
+    std::sort(offs.begin(), offs.end());
+    std::sort(vals.begin(), vals.end());
+    if ((int)offs.size() != h_counts[0] || (use_vals && (int)vals.size() != h_counts[1])) { cleanup(); return SPRS_OK; }
+    std::vector<uint8_t> codes(2 * HSLOTS, 0);
+    std::vector<int32_t> off_tab(TAB, 0);
+    std::vector<T> val_tab(TAB, szero<T>());
+    for (size_t i = 0; i < offs.size(); ++i) { off_tab[i] = offs[i].first; codes[(size_t)offs[i].second] = (uint8_t)i; }
+    if constexpr (VALS) {
+        for (size_t i = 0; i < vals.size(); ++i) {
+            T v;
+            if (sizeof(T) == 8) { uint64_t k = vals[i].first; memcpy(&v, &k, 8); }
+            else { uint32_t k = (uint32_t)vals[i].first; memcpy(&v, &k, 4); }
+            val_tab[i] = v;
+            codes[HSLOTS + (size_t)vals[i].second] = (uint8_t)i;
+        }
+    }
+    DICT_TRY(hipMemcpyAsync(slot_codes, codes.data(), 2 * HSLOTS, hipMemcpyHostToDevice, c->stream));
+    auto *D = new sprs_dict();
+    A->dict = D;   // freed by free_dict on every failure path below (sprs_csr_destroy)
+    const size_t nb = ((size_t)A->nnz + 3) / 4 * 4 + 8;
+#define DICT_TRY2(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { snprintf(c->err, sizeof(c->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); cleanup(); free_dict(A); return SPRS_ERR_HIP; } } while (0)
+    DICT_TRY2(hipMalloc((void **)&D->idx_code, nb));
+    DICT_TRY2(hipMemsetAsync(D->idx_code, 0, nb, c->stream));
+    DICT_TRY2(hipMalloc((void **)&D->off_tab, sizeof(int32_t) * TAB));
+    DICT_TRY2(hipMemcpyAsync(D->off_tab, off_tab.data(), sizeof(int32_t) * TAB, hipMemcpyHostToDevice, c->stream));
+    if (use_vals) {
+        DICT_TRY2(hipMalloc((void **)&D->val_code, nb));
+        DICT_TRY2(hipMemsetAsync(D->val_code, 0, nb, c->stream));
+        DICT_TRY2(hipMalloc(&D->val_tab, sizeof(T) * TAB));
+        DICT_TRY2(hipMemcpyAsync(D->val_tab, val_tab.data(), sizeof(T) * TAB, hipMemcpyHostToDevice, c->stream));
+    }
+    D->n_off = (int)offs.size(); D->n_val = use_vals ? (int)vals.size() : 0;
+    int *bad = counts + 3;
+    if (use_vals)
+        hipLaunchKernelGGL((dict_encode_kernel<T, VALS>), dim3(g), dim3(BLOCK), 0, c->stream, n, A->row_ptr, A->col_idx, val, off_h,
+                           slot_codes, val_h, slot_codes + HSLOTS, D->idx_code, D->val_code, bad);
+    else
+        hipLaunchKernelGGL((dict_encode_kernel<T, false>), dim3(g), dim3(BLOCK), 0, c->stream, n, A->row_ptr, A->col_idx, val, off_h,
+                           slot_codes, val_h, slot_codes + HSLOTS, D->idx_code, D->val_code, bad);
+    DICT_TRY2(hipGetLastError());
+    DICT_TRY2(hipMemcpyAsync(h_counts, counts, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+    DICT_TRY2(hipStreamSynchronize(c->stream));
+    cleanup();
+    if (h_counts[3] != 0) free_dict(A);      // cannot happen (every key was inserted); keep the plain stream if it does
+    return SPRS_OK;
+#undef DICT_TRY
+#undef DICT_TRY2
+}
+
+}  // namespace
+
+void free_dict(sprs_csr *A) {
+    if (!A || !A->dict) return;
+    sprs_dict *D = A->dict;
+    if (D->idx_code) (void)hipFree(D->idx_code);
+    if (D->val_code) (void)hipFree(D->val_code);
+    if (D->off_tab) (void)hipFree(D->off_tab);
+    if (D->val_tab) (void)hipFree(D->val_tab);
+    delete D;
+    A->dict = nullptr;
+}
+
+int build_dict(sprs_csr *A, bool has_vector_blocks) {
+    if (A->ctx->spmv_dict == 0 || has_vector_blocks || A->nnz == 0 || A->nrows == 0) return SPRS_OK;
+    switch (A->dtype) {
+        case DT_D: return build_dict_t<double>(A);
+        case DT_Z: return build_dict_t<cplx>(A);
+        case DT_S: return build_dict_t<float>(A);
+        default: return build_dict_t<cplxf>(A);
+    }
+}
+
+int dict_mode(const sprs_csr *A) {
+    if (!A->dict || A->ctx->spmv_dict == 0) return 0;
+    if (A->dict->val_code && A->ctx->spmv_dict != 1) return 2;
+    return 1;
+}
+
+template <class T>
+int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int count, int g, int xcd_chunk, const T *x, T *y,
+                     int dot_mode, const T *u, T *part0, T *part1, const int *status, bool conj_x) {
+    sprs_ctx *c = A->ctx;
+    const sprs_dict *D = A->dict;
+    const T *v = reinterpret_cast<const T *>(A->val);
+    const T *vt = reinterpret_cast<const T *>(D->val_tab);
+#define SPRS_DSPMV2(DM, CJ, VD)                                                                                         \
+    hipLaunchKernelGGL((spmv_dict_kernel<T, DM, CJ, VD>), dim3(g), dim3(BLOCK), 0, c->stream, count, xcd_chunk,          \
+                       reinterpret_cast<const BlkDesc *>(A->blk_desc), order, A->row_ptr, D->idx_code, D->val_code, D->off_tab, \
+                       vt, v, x, y, u, part0, part1, status)
+#define SPRS_DSPMV(DM, CJ) do { if (has_val_dict<T>::value && mode == 2) SPRS_DSPMV2(DM, CJ, (has_val_dict<T>::value)); else SPRS_DSPMV2(DM, CJ, false); } while (0)
+    if (conj_x && is_complex<T>::value) {
+        if (dot_mode == 0) SPRS_DSPMV(0, true);
+        else if (dot_mode == 1) SPRS_DSPMV(1, true);
+        else SPRS_DSPMV(2, true);
+    } else {
+        if (dot_mode == 0) SPRS_DSPMV(0, false);
+        else if (dot_mode == 1) SPRS_DSPMV(1, false);
+        else SPRS_DSPMV(2, false);
+    }
+#undef SPRS_DSPMV2
+#undef SPRS_DSPMV
+    SPRS_HIP_TRY(c, hipGetLastError());
+    return SPRS_OK;
+}
+
+#define SPRS_INST_DSPMV(T)                                                                                              \
+    template int launch_spmv_dict<T>(const sprs_csr *, int, const int32_t *, int, int, int, const T *, T *, int, const T *, T *, T *, const int *, bool);
+SPRS_INST_DSPMV(double)
+SPRS_INST_DSPMV(cplx)
+SPRS_INST_DSPMV(float)
+SPRS_INST_DSPMV(cplxf)
+
+}  // namespace sprs

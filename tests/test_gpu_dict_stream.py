@@ -1,0 +1,178 @@
+"""The dictionary-compressed SpMV stream (csrc/spmv_dict.hip) against the plain CSR kernel and the oracle:
+bit-identical y in all three formats, correct fall-back for matrices that do not qualify."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+DTYPES = [np.float64, np.complex128, np.float32, np.complex64]
+IDS = ["f64", "c64", "f32", "c32"]
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import sprsolve_amd
+    from sprsolve_amd import _lib
+    _lib.lib()
+    sprsolve_amd.default_ctx(0)
+    return sprsolve_amd
+
+
+@pytest.fixture(autouse=True)
+def _restore_knob(sa):
+    yield
+    sa.default_ctx(0).set("spmv_dict", -1)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+def rand_vec(n, dtype, seed):
+    rng = np.random.default_rng(seed)
+    if np.dtype(dtype).kind == "c":
+        return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(dtype)
+    return rng.uniform(-1, 1, n).astype(dtype)
+
+
+def matrices(dtype):
+    from sprsolve_amd import gen
+    out = {}
+    ip, ix, d, _ = gen.poisson3d(13, 11, 9)
+    out["poisson3d"] = (ip, ix, d.astype(dtype))                       # 7 offsets, 2 values
+    ip, ix, d = gen.grid_laplacian_dirichlet(37, 37)
+    out["grid2d"] = (ip, ix, d.astype(dtype))                          # identity rows + 5-point rows
+    ip, ix, d, _ = gen.symmetric_banded(5000, 4)
+    dd = d.astype(dtype)
+    if np.dtype(dtype).kind == "c":
+        dd = dd * (1 + 0.5j)
+    out["banded_random_values"] = (ip, ix, dd)                          # 9 offsets, n distinct values
+    return out
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("name", ["poisson3d", "grid2d", "banded_random_values"])
+def test_formats_bit_identical(sa, oracle, dtype, name):
+    ctx = sa.default_ctx(0)
+    indptr, indices, data = matrices(dtype)[name]
+    n = indptr.size - 1
+    x = rand_vec(n, dtype, 7)
+    ref = oracle.spmv(indptr, indices, data, x)
+    real = np.dtype(dtype).kind != "c"
+    got = {}
+    for knob in (0, 1, 2, -1):
+        ctx.set("spmv_dict", knob)
+        A = sa.HipCsr.new((n, n), indptr, indices, data)
+        mode, n_off, n_val = A.stream_format()
+        if knob == 0:
+            assert mode == 0
+        elif knob == 1:
+            assert mode == 1 and n_val == 0
+        else:
+            few_values = real and name != "banded_random_values"
+            assert mode == (2 if few_values else 1), (mode, n_off, n_val)
+            if few_values:
+                assert n_val == 2          # {6, -1} and {-4, 1}
+        if knob != 0:
+            assert n_off == {"poisson3d": 7, "grid2d": 5, "banded_random_values": 9}[name]
+        y = np.full(n, 3.0, dtype=dtype)
+        A.mul_vec(x, y)
+        assert np.array_equal(bits(y), bits(ref)), (name, knob)       # the reference fold, bit for bit
+        y2 = np.zeros(n, dtype=dtype)
+        dot = A.mul_vec_dot(x, y2)
+        assert np.array_equal(bits(y2), bits(ref))
+        got[knob] = dot
+    # the fused dot epilogue reduces the same y the same way in every format
+    assert got[0] == got[1] == got[2] == got[-1]
+
+
+def test_fallback_too_many_offsets(sa, oracle):
+    import scipy.sparse as sp
+    n = 4000
+    rng = np.random.default_rng(2)
+    M = (sp.random(n, n, density=0.003, random_state=rng, format="csr") + sp.eye(n)).tocsr()
+    M.sort_indices()
+    A = sa.HipCsr.new((n, n), M.indptr, M.indices, M.data)
+    assert A.stream_format() == (0, 0, 0)
+    x = rand_vec(n, np.float64, 3); y = np.zeros(n)
+    A.mul_vec(x, y)
+    assert np.array_equal(bits(y), bits(oracle.spmv(M.indptr, M.indices, M.data, x)))
+
+
+def test_fallback_long_rows(sa, oracle):
+    """A row longer than LONG_ROW (96) takes the wavefront-per-row path, which reads the plain stream."""
+    import scipy.sparse as sp
+    n = 600
+    D = sp.diags([np.ones(n - abs(k)) for k in range(-60, 61)], list(range(-60, 61)), format="csr")   # 121 per row
+    A = sa.HipCsr.new((n, n), D.indptr, D.indices, D.data)
+    assert A.stream_format()[0] == 0
+    x = rand_vec(n, np.float64, 4); y = np.zeros(n)
+    A.mul_vec(x, y)
+    ref = oracle.spmv(D.indptr, D.indices, D.data, x)
+    assert np.allclose(y, ref, rtol=0, atol=1e-13 * 121)
+
+
+def test_value_bit_patterns_survive(sa, oracle):
+    """Values are matched by bit pattern: -0.0 and +0.0, denormals and a NaN payload are separate dictionary
+    entries and reproduce the plain kernel's bits."""
+    n = 300
+    indptr = np.arange(0, 3 * n + 1, 3, dtype=np.int32)
+    cols = np.stack([(np.arange(n) - 1) % n, np.arange(n), (np.arange(n) + 1) % n], axis=1)
+    cols.sort(axis=1)
+    special = np.array([0.0, -0.0, 5e-324, -2.5, np.inf, 1.0, 3.0], dtype=np.float64)
+    rng = np.random.default_rng(9)
+    data = special[rng.integers(0, special.size, 3 * n)]
+    x = rand_vec(n, np.float64, 5)
+    ctx = sa.default_ctx(0)
+    ys = []
+    for knob in (0, 2):
+        ctx.set("spmv_dict", knob)
+        A = sa.HipCsr.new((n, n), indptr, cols.ravel().astype(np.int32), data)
+        if knob == 2:
+            assert A.stream_format()[0] == 2 and A.stream_format()[2] == special.size
+        y = np.zeros(n)
+        A.mul_vec(x, y)
+        ys.append(y)
+    assert np.array_equal(bits(ys[0]), bits(ys[1]))
+    assert np.array_equal(bits(ys[0]), bits(oracle.spmv(indptr, cols.ravel(), data, x)))
+
+
+def test_ragged_and_empty_rows(sa, oracle):
+    """Empty rows, rows of every length up to LONG_ROW, block boundaries at every 4-byte phase of the code stream."""
+    rng = np.random.default_rng(12)
+    n = 2000
+    lens = rng.integers(0, 13, n)
+    lens[::97] = 0
+    lens[5::211] = 90
+    indptr = np.zeros(n + 1, dtype=np.int32); np.cumsum(lens, out=indptr[1:])
+    cols = np.concatenate([np.sort((r + rng.choice(np.arange(-48, 48), l, replace=False)) % n) for r, l in enumerate(lens)]).astype(np.int32)
+    data = rng.choice(np.array([1.0, -2.0, 0.5, 4.0]), cols.size)
+    x = rand_vec(n, np.float64, 6)
+    ctx = sa.default_ctx(0)
+    ref = oracle.spmv(indptr, cols, data, x)
+    for knob in (0, 1, 2):
+        ctx.set("spmv_dict", knob)
+        A = sa.HipCsr.new((n, n), indptr, cols, data)
+        assert A.stream_format()[0] == knob
+        y = np.full(n, 9.0)
+        A.mul_vec(x, y)
+        assert np.array_equal(bits(y), bits(ref)), knob
+
+
+@pytest.mark.parametrize("knob", [0, 1, 2])
+def test_solver_same_iterates_in_every_format(sa, oracle, knob):
+    """BiCGStab on the 3-D Poisson problem: the SpMV and its fused partials are bit-identical across formats,
+    so the whole solve (iteration count, residual, x) is."""
+    from sprsolve_amd import gen
+    indptr, indices, data, rhs = gen.poisson3d(24, 20, 16)
+    n = rhs.size
+    ctx = sa.default_ctx(0)
+    res = {}
+    for k in (0, knob):
+        ctx.set("spmv_dict", k)
+        A = sa.HipCsr.new((n, n), indptr, indices, data)
+        x = np.zeros(n)
+        its, r = sa.BiCGStab.new(A, n).solve(rhs, x, 500, 1e-10)
+        res[k] = (its, r, x)
+    assert res[0][0] == res[knob][0] and res[0][1] == res[knob][1]
+    assert np.array_equal(bits(res[0][2]), bits(res[knob][2]))
+    assert np.max(np.abs(res[knob][2] - 1.0)) < 1e-7
