@@ -67,7 +67,7 @@ const char *sprs_status_str(int status);
 int sprs_version(void);
 /* tuning knobs (defaults chosen for MI355X): key = "grid" (blocks of the streaming kernels),
  * "xcd_chunk" (1: contiguous row-block chunk per XCD), "poll" (iterations between host polls),
- * "spmv_dict" (-1 auto / 0 plain CSR / 1 offset codes / 2 offset + value codes: dictionary-compressed
+ * "spmv_dict" (-1 auto / 0 plain CSR / 1 offset codes / 2 (offset, value) pair codes: dictionary-compressed
  * SpMV stream, see sprs_csr_stream_format), "gs_graph" (1: Gauss-Seidel replays a sweep's level launches from a hipGraph; default 0) */
 int sprs_ctx_set(sprs_ctx *ctx, const char *key, int64_t value);
 int64_t sprs_ctx_get(const sprs_ctx *ctx, const char *key);
@@ -104,11 +104,11 @@ int64_t sprs_csr_rows(const sprs_csr *A);
 int64_t sprs_csr_cols(const sprs_csr *A);
 int64_t sprs_csr_nnz(const sprs_csr *A);
 /* Which stream the SpMV of this handle reads (backend detail, csrc/spmv_dict.hip): 0 = plain CSR (12 B/nnz for
- * f64), 1 = one-byte column-offset codes + values, 2 = one-byte offset codes + one-byte value codes.  The
- * compressed streams are built at creation when the matrix has <= 256 distinct (col - row) offsets (and, for
- * real scalars, <= 256 distinct values) and the ctx knob "spmv_dict" allows it; y is bit-identical in all
- * three.  n_offsets / n_values (may be NULL) receive the table sizes (0 when the table does not exist). */
-int sprs_csr_stream_format(const sprs_csr *A, int *n_offsets, int *n_values);
+ * f64), 1 = one-byte column-offset codes + the values (9 B/nnz), 2 = one-byte codes of the (offset, value) pairs
+ * (1 B/nnz).  The compressed streams are built at creation when the matrix has <= 256 distinct (col - row) offsets
+ * (and, for real scalars, <= 256 distinct values and pairs) and the ctx knob "spmv_dict" allows it; y is
+ * bit-identical in all three.  n_offsets / n_pairs (may be NULL) receive the table sizes (0 = table absent). */
+int sprs_csr_stream_format(const sprs_csr *A, int *n_offsets, int *n_pairs);
 
 /* MatVecMul::mul_vec / mul_vec_dot (mat.rs:49-64): host slices, checked — returns
  * SPRS_DIM_MISMATCH where the reference panics.  y = A x ; *dot_out = conj(x) . y

@@ -527,7 +527,7 @@ int64_t sprs_csr_nnz(const sprs_csr *A) { return A ? A->nnz : -1; }
 int sprs_csr_stream_format(const sprs_csr *A, int *n_offsets, int *n_values) {
     if (!A) return -1;
     if (n_offsets) *n_offsets = A->dict ? A->dict->n_off : 0;
-    if (n_values) *n_values = A->dict ? A->dict->n_val : 0;
+    if (n_values) *n_values = A->dict ? (A->dict->n_pair ? A->dict->n_pair : 0) : 0;
     return dict_mode(A);
 }
 

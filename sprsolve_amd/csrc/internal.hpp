@@ -38,8 +38,8 @@ struct sprs_ctx {
     // ~5.5 reads to ~1 but was 2 % SLOWER), >= 2 = strip-major walk with that many rows per strip
     // (5-10 % slower).  Both kept as experiments — see profiles/r01_tuning.md.
     int spmv_strip = 0;
-    // dictionary-compressed SpMV stream: -1 auto (offsets and, when few, values), 0 plain CSR, 1 offsets only,
-    // 2 offsets + values.  Read at handle creation (what is built) and at launch (what is used).
+    // dictionary-compressed SpMV stream: -1 auto (the most compact the matrix qualifies for), 0 plain CSR,
+    // 1 offset codes + values, 2 (offset, value) pair codes.  Read at handle creation (what is built) and at launch (what is used).
     int spmv_dict = -1;
     int halo_overlap = 1;  // distributed SpMV: run the halo-free rows while the halo travels
     int gs_graph = 0;    // Gauss-Seidel: 1 = replay a sweep's level launches from a hipGraph (measured: no gain, r01_tuning.md)
@@ -96,14 +96,15 @@ struct sprs_dist_info {
 };
 
 // Dictionary-compressed copy of the (col_idx, val) stream (spmv_dict.hip): one byte per nnz indexing the
-// table of distinct (col - row) offsets and, for real matrices with few distinct values, one byte per nnz
-// indexing the table of distinct values.  Built at handle creation when the matrix qualifies.
+// table of distinct (col - row) offsets or, for real matrices with few distinct values, the table of distinct
+// (offset, value) pairs.  Built at handle creation when the matrix qualifies.
 struct sprs_dict {
-    uint8_t *idx_code = nullptr;   // device, nnz (+ pad)
-    uint8_t *val_code = nullptr;   // device, nnz (+ pad) or null
-    int32_t *off_tab = nullptr;    // device, 256 entries: col - row
-    void *val_tab = nullptr;       // device, 256 entries of T, or null
-    int n_off = 0, n_val = 0;
+    uint8_t *idx_code = nullptr;   // device, nnz (+ pad): code of col - row
+    uint8_t *pair_code = nullptr;  // device, nnz (+ pad): code of the (col - row, value) pair, or null
+    int32_t *off_tab = nullptr;    // device, 256 entries: col - row per offset code
+    int32_t *pair_off = nullptr;   // device, 256 entries: col - row per pair code
+    void *pair_val = nullptr;      // device, 256 entries of T: value per pair code
+    int n_off = 0, n_val = 0, n_pair = 0;
 };
 
 struct sprs_csr {

@@ -357,10 +357,10 @@ static inline bool is_cache_resident(const sprs_csr *A) {
 }
 static inline int base_grid(const sprs_csr *A) {
     int g = A->ctx->spmv_grid;
-    // measured (A/B on the full solve): 4 workgroups per CU for the plain and offset-code streams (HBM-bound and
-    // cache-resident matrices alike); 6 per CU for the offset + value-code stream, whose kernel is bound by the
-    // CU's vector-memory request rate and latency rather than by HBM (7 per CU is slower again)
-    if (g <= 0) g = A->ctx->num_cu * (dict_mode(A) == 2 ? 6 : 4);
+    // measured (A/B on the full solve): 4 workgroups per CU, for HBM-bound and cache-resident matrices and for all
+    // three streams alike (the pair-code kernel runs its stand-alone best at 6 per CU but loses that inside the
+    // solve, where it alternates with the BLAS-1 kernels)
+    if (g <= 0) g = A->ctx->num_cu * 4;
     if (g < 8) g = 8;
     if (g > MAX_GRID / 2) g = MAX_GRID / 2;
     return g & ~7;

@@ -1,21 +1,28 @@
-// Dictionary-compressed CSR SpMV — the same arithmetic as spmv.hip on fewer HBM bytes.
+// Dictionary-compressed CSR SpMV — the same arithmetic as spmv.hip on fewer HBM bytes and fewer instructions.
 //
-// The SpMV is HBM-bound and (col_idx, val) is 12 of its ~15 bytes per nnz (f64).  Matrices that come from
-// grids and bands (every BASELINE config; the reference's own tests and benches) repeat themselves:
+// The SpMV streams (col_idx, val): 12 of its ~15 bytes per nnz (f64).  Matrices that come from grids and
+// bands (every BASELINE config; the reference's own tests and benches) repeat themselves:
 //   * the column OFFSET col - row takes a handful of values (7 for the 7-point stencil, 9 for the band of
 //     cfg 3, the halo blocks of a slab partition add a few more);
-//   * constant-coefficient operators also repeat their VALUES (two distinct ones in cfg 2 and cfg 5).
-// At handle creation the distinct offsets — and, for real scalars, the distinct value bit patterns — are
-// collected on the device; if there are <= 256 of them each nnz is re-encoded as ONE BYTE per table
-// (CSR-DU / CSR-VI style, Kourtis et al.), so the stream shrinks from 12 to 9 B/nnz (offsets only) or to
-// 2 B/nnz (offsets + values).  Values are matched by bit pattern, the tables hold the original values
-// and every product x[col]*val is formed and added in the original order, so y is BIT-IDENTICAL to the
-// plain kernel's (and to the reference's fold, mat.rs:100-105).  Matrices that do not qualify (too many
-// offsets, rows longer than LONG_ROW) keep the plain stream; nothing is approximated.
+//   * constant-coefficient operators also repeat their VALUES (two distinct ones in cfg 2 and cfg 5), so
+//     the (offset, value) PAIRS are few as well (7 in cfg 5).
+// At handle creation the distinct offsets — and, for real scalars, the distinct value bit patterns and the
+// distinct (offset, value) pairs — are collected on the device.  With <= 256 of them each nnz is re-encoded
+// as ONE BYTE (CSR-DU / CSR-VI style, Kourtis et al.):
+//   mode 1 "offset codes":  1 B offset code + the original value           12 -> 9 B/nnz (f64)
+//   mode 2 "pair codes":    1 B code of the (offset, value) pair           12 -> 1 B/nnz
+// Values are matched by BIT PATTERN, the tables hold the original values and every product x[col]*val is
+// formed and added in the original order, so y is BIT-IDENTICAL to the plain kernel's (and to the
+// reference's fold, mat.rs:100-105).  Matrices that do not qualify (too many offsets, rows longer than
+// LONG_ROW) keep the plain stream; nothing is approximated.
 //
 // Kernel shape: as in spmv.hip a wavefront owns a row block (<= 64 rows, <= CAP nnz).  The code bytes are
-// staged to LDS with aligned dword loads; then lane r walks row ra + r: col = row + off_tab[code], the x
-// gather of consecutive rows is itself coalesced, products are added left to right from zero.
+// staged to LDS with aligned dword loads; then lane r walks row ra + r: one LDS byte read gives the code,
+// one LDS table read gives (offset*sizeof(T), value), and x is gathered with base-in-SGPR + 32-bit lane
+// offset addressing — consecutive rows of a stencil gather consecutive x, so the gather is itself
+// coalesced.  Products are added left to right from zero.  Once the stream is this small the kernel is
+// bound by the CU's vector-ALU and vector-memory issue, not by HBM: the loop is written to keep the
+// per-nnz instruction count down (immediate-offset LDS reads, no 64-bit address arithmetic).
 #include <algorithm>
 #include <cstring>
 
@@ -110,53 +117,73 @@ __global__ __launch_bounds__(BLOCK) void dict_encode_kernel(int n, const int32_t
     }
 }
 
+// mark the (offset code, value code) pairs that occur / translate them to pair codes
+__global__ __launch_bounds__(BLOCK) void dict_pair_mark_kernel(int64_t nnz, const uint8_t *__restrict__ idx_code,
+                                                               const uint8_t *__restrict__ val_code, uint8_t *__restrict__ seen) {
+    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * BLOCK) {
+        const int pr = idx_code[k] | (val_code[k] << 8);
+        if (seen[pr] == 0) seen[pr] = 1;       // benign race: every writer stores 1
+    }
+}
+__global__ __launch_bounds__(BLOCK) void dict_pair_encode_kernel(int64_t nnz, const uint8_t *__restrict__ idx_code,
+                                                                 const uint8_t *__restrict__ val_code,
+                                                                 const uint8_t *__restrict__ pair_of, uint8_t *__restrict__ pair_code) {
+    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * BLOCK)
+        pair_code[k] = pair_of[idx_code[k] | (val_code[k] << 8)];
+}
+
 // ---------------------------------------------------------------------------------------------------------
+constexpr int CPAD = 16;    // readable bytes behind a block's codes: the row phase reads up to 7 + 3 bytes past them
+
+// LDS table entry of the pair stream: byte offset of the column relative to the row, and the value
+template <class T> struct alignas(sizeof(T) >= 8 ? 16 : 8) PairEnt { int32_t off8; T val; };
+
 // What a wavefront loads for one row block before it can work on it.  The loads of block i+1 are issued
 // before block i is processed (and the descriptor of block i+2 before that), so a block costs one exposed
 // memory round trip — its x gather — instead of three dependent ones (descriptor -> codes/row_ptr -> x).
-template <class T, bool VALDICT, int ITEMS>
+template <class T, bool PAIR, int ITEMS>
 struct BlkLoads {
     int ra, rb, pa, nn;      // descriptor
     int s;                   // row_ptr[row] of this lane's row
     T uu;                    // dot operand of this lane's row
-    uint32_t wi[2], wv[2];   // code dwords
+    uint32_t wc[2];          // code dwords
     int di[2];               // ... and the LDS slots they go to
-    T vv[VALDICT ? 1 : ITEMS];
+    T vv[PAIR ? 1 : ITEMS];  // values (offset-code stream only)
 };
 
-template <class T, int DOT, bool CONJX, bool VALDICT>
+template <class T, int DOT, bool CONJX, bool PAIR>
 __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_chunk, const BlkDesc *__restrict__ desc,
                                                           const int32_t *__restrict__ order,
                                                           const int32_t *__restrict__ row_ptr,
-                                                          const uint8_t *__restrict__ idx_code,
-                                                          const uint8_t *__restrict__ val_code,
-                                                          const int32_t *__restrict__ off_tab, const T *__restrict__ val_tab,
+                                                          const uint8_t *__restrict__ code,       // offset or pair codes
+                                                          const int32_t *__restrict__ off_tab,    // per code: col - row
+                                                          const T *__restrict__ val_tab,          // per pair code: value
                                                           const T *__restrict__ val, const T *__restrict__ x,
                                                           T *__restrict__ y, const T *__restrict__ u, T *__restrict__ part0,
                                                           T *__restrict__ part1, const int *__restrict__ status) {
     constexpr int CAP = nnz_cap<T>::value;          // nnz per row block (per wavefront)
-    constexpr int CW = CAP / 4 + 1;                 // dwords holding CAP code bytes at any 4-byte phase
+    constexpr int CW = (CAP + 3 + CPAD + 3) / 4;    // dwords: CAP code bytes at any 4-byte phase + the readable pad
     constexpr int ITEMS = CAP / WAVE;
-    using Loads = BlkLoads<T, VALDICT, ITEMS>;
-    __shared__ int32_t s_off[TAB];
-    __shared__ T s_val[VALDICT ? TAB : 1];
-    __shared__ uint32_t s_ic[NWAVE][CW + 1];
-    __shared__ uint32_t s_vc[VALDICT ? NWAVE : 1][VALDICT ? CW + 1 : 1];
-    __shared__ T s_v[VALDICT ? 1 : NWAVE][VALDICT ? 1 : CAP];
+    using Loads = BlkLoads<T, PAIR, ITEMS>;
+    __shared__ PairEnt<T> s_pair[PAIR ? TAB : 1];
+    __shared__ int32_t s_off8[PAIR ? 1 : TAB];
+    __shared__ uint32_t s_c[NWAVE][CW];
+    __shared__ T s_v[PAIR ? 1 : NWAVE][PAIR ? 1 : CAP + 8];
     __shared__ T red[NWAVE];
     if (status != nullptr && *status != ST_RUNNING) return;
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    // the wavefront index as a SCALAR: the block walk (b, descriptors, loop branches) then lives in SGPRs and
-    // the descriptor loads go through the scalar cache instead of queueing behind the vector loads
+    // the wavefront index as a SCALAR: the block walk (b, loop branches) then lives in SGPRs
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    s_off[tid] = off_tab[tid];                      // BLOCK == TAB
-    if constexpr (VALDICT) s_val[tid] = val_tab[tid];
+    if constexpr (PAIR) s_pair[tid] = PairEnt<T>{off_tab[tid] * (int32_t)sizeof(T), val_tab[tid]};    // BLOCK == TAB
+    else s_off8[tid] = off_tab[tid] * (int32_t)sizeof(T);
+    for (int i = lane; i < CW; i += WAVE) s_c[wv][i] = 0;       // the pad is read (and ignored) before it is ever written
+    if constexpr (!PAIR) for (int i = lane; i < CAP + 8; i += WAVE) s_v[wv][i] = szero<T>();
     __syncthreads();                                // the only workgroup barrier: tables are read-only afterwards
 
-    const uint8_t *ic = reinterpret_cast<const uint8_t *>(s_ic[wv]);
-    [[maybe_unused]] const uint8_t *vc = reinterpret_cast<const uint8_t *>(s_vc[VALDICT ? wv : 0]);
-    [[maybe_unused]] T *vs = s_v[VALDICT ? 0 : wv];
+    const uint8_t *cb = reinterpret_cast<const uint8_t *>(s_c[wv]);
+    [[maybe_unused]] T *vs = s_v[PAIR ? 0 : wv];
+    const char *xbytes = reinterpret_cast<const char *>(x);
     T d0 = szero<T>(), d1 = szero<T>();
 
     int b, bstep, bend;                             // the persistent walk of spmv.hip
@@ -183,25 +210,29 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
     const gi32_p order_v = reinterpret_cast<gi32_p>(order_a);
     auto load_desc = [&](int bi) -> BlkDesc { const v4i q = desc_v[bi]; return BlkDesc{q.x, q.y, q.z, q.w}; };
     auto block_index = [&](int bi) -> int { return order ? order_v[bi] : bi; };
+    // ... and turned back into scalars where they are consumed, so that everything derived from a descriptor
+    // (block bounds, code alignment, branch conditions) is scalar-ALU work instead of 64-lane vector work
+    auto uniform = [&](const BlkDesc &d) -> BlkDesc {
+        return BlkDesc{__builtin_amdgcn_readfirstlane(d.ra), __builtin_amdgcn_readfirstlane(d.rb),
+                       __builtin_amdgcn_readfirstlane(d.pa), __builtin_amdgcn_readfirstlane(d.nn)};
+    };
     // Phase 1 of a block: issue its loads (unconditional, clamped addresses: they go out back to back).
     // Nothing here uses a loaded value, so the wavefront does not wait.
     auto issue = [&](const BlkDesc &d, Loads &L) {
         L.ra = d.ra; L.rb = d.rb & 0x7fffffff; L.pa = d.pa; L.nn = d.nn;   // dictionary matrices have no vector blocks
         const int r = L.ra + lane;
         const int rcl = r < L.rb ? r : L.rb - 1;
-        L.s = row_ptr[rcl];                        // row_ptr[row + 1] comes from the next lane (adopt): one load, not two
-        if (DOT != 0) L.uu = u[rcl];
+        // uniform base + 32-bit lane offset everywhere (launch checks the sizes): no 64-bit address arithmetic
+        L.s = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(row_ptr) + (uint32_t)rcl * 4u);   // row_ptr[row + 1] comes from the next lane (adopt)
+        if (DOT != 0) L.uu = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(u) + (uint32_t)rcl * (uint32_t)sizeof(T));
         const int shift = L.pa & 3;
-        const int nd = max((shift + L.nn + 3) >> 2, 1);                    // dwords covering [pa, pa + nn), <= CW
-        const uint32_t *gi = reinterpret_cast<const uint32_t *>(idx_code + (L.pa - shift));
-        [[maybe_unused]] const uint32_t *gv = reinterpret_cast<const uint32_t *>(val_code + (L.pa - shift));
+        const int nd = max((shift + L.nn + 3) >> 2, 1);                    // dwords covering [pa, pa + nn), <= CAP/4 + 1
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             L.di[i] = min(lane + i * WAVE, nd - 1);
-            L.wi[i] = gi[L.di[i]];
-            if constexpr (VALDICT) L.wv[i] = gv[L.di[i]];
+            L.wc[i] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(code) + (uint32_t)(L.pa - shift + 4 * L.di[i]));
         }
-        if constexpr (!VALDICT) {
+        if constexpr (!PAIR) {
             const int last = max(L.nn - 1, 0);
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) L.vv[i] = val[L.pa + min(lane + i * WAVE, last)];
@@ -214,17 +245,12 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
         const int shift = L.pa & 3;
         if (L.nn > 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {            // clamped duplicates store the same dword to the same slot
-                s_ic[wv][L.di[i]] = L.wi[i];
-                if constexpr (VALDICT) s_vc[wv][L.di[i]] = L.wv[i];
+            for (int i = 0; i < 2; ++i) s_c[wv][L.di[i]] = L.wc[i];   // clamped duplicates store the same dword to the same slot
+            if constexpr (CAP / 4 + 1 > 2 * WAVE) {
+                if (((shift + L.nn + 3) >> 2) > 2 * WAVE && lane == 0)     // the 129th dword exists only when shift + nn > 512
+                    s_c[wv][2 * WAVE] = reinterpret_cast<const uint32_t *>(code + (L.pa - shift))[2 * WAVE];
             }
-            if constexpr (CW > 2 * WAVE) {
-                if (((shift + L.nn + 3) >> 2) > 2 * WAVE && lane == 0) {   // the 129th dword exists only when shift + nn > 512
-                    s_ic[wv][2 * WAVE] = reinterpret_cast<const uint32_t *>(idx_code + (L.pa - shift))[2 * WAVE];
-                    if constexpr (VALDICT) s_vc[wv][2 * WAVE] = reinterpret_cast<const uint32_t *>(val_code + (L.pa - shift))[2 * WAVE];
-                }
-            }
-            if constexpr (!VALDICT) {
+            if constexpr (!PAIR) {
 #pragma unroll
                 for (int i = 0; i < ITEMS; ++i) {
                     const int k = lane + i * WAVE;
@@ -255,9 +281,9 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
     int o2 = 0;
     if (b < bend) {
         Loads first;
-        issue(load_desc(block_index(b)), first);
-        if (b + bstep < bend) dn = load_desc(block_index(b + bstep));
-        if (b + 2 * bstep < bend) o2 = block_index(b + 2 * bstep);
+        issue(uniform(load_desc(__builtin_amdgcn_readfirstlane(block_index(b)))), first);
+        if (b + bstep < bend) dn = uniform(load_desc(__builtin_amdgcn_readfirstlane(block_index(b + bstep))));
+        if (b + 2 * bstep < bend) o2 = __builtin_amdgcn_readfirstlane(block_index(b + 2 * bstep));
         stage(first);
         adopt(first);
     }
@@ -272,23 +298,24 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
         wave_lds_fence();
         // ---- one lane per row: mat.rs:100-105, fold(T::zero(), |acc, (col, val)| acc + x[col] * val)
         const int r = c_ra + lane;
-        const int s = c_s, len = c_len, shift = c_shift;
+        const uint32_t r8 = (uint32_t)r * (uint32_t)sizeof(T);     // byte offset of x[row]; launch checks ncols*sizeof(T) < 4 GiB
+        const int s = c_s, len = c_len;
         T acc = szero<T>();
         for (int j0 = 0; __builtin_amdgcn_ballot_w64(j0 < len) != 0; j0 += 8) {
+            // slots past a row's end read the (in-bounds, stale or zero) bytes behind it and are dropped below;
+            // one clamp per chunk keeps the whole chunk inside the wavefront's slice
+            const int kb = min(s + j0, CAP);
+            const uint8_t *cp = cb + c_shift + kb;
             T xg[8], av[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const bool valid = j0 + t < len;
-                if (t >= 4 && __builtin_amdgcn_ballot_w64(valid) == 0) {   // no row of the block is this long
-                    xg[t] = szero<T>(); av[t] = szero<T>();
-                    continue;
-                }
-                const int k = valid ? s + j0 + t : 0;             // always inside the staged bytes
-                const int off = s_off[ic[shift + k]];
-                const int col = valid ? r + off : 0;              // lanes past their row gather x[0] and drop it
-                xg[t] = x[col];
-                if constexpr (VALDICT) av[t] = s_val[vc[shift + k]];
-                else av[t] = vs[k];
+                const int cd = cp[t];
+                int off8;
+                if constexpr (PAIR) { const PairEnt<T> e = s_pair[cd]; off8 = e.off8; av[t] = e.val; }
+                else { off8 = s_off8[cd]; av[t] = vs[kb + t]; }
+                const uint32_t vo = valid ? r8 + (uint32_t)off8 : 0u;     // lanes past their row gather x[0] and drop it
+                xg[t] = *reinterpret_cast<const T *>(xbytes + vo);
             }
             // all 8 gathers go out before the first product is formed (the scheduler otherwise hoists the
             // first multiply between them and with it a wait for the first gather: two round trips per block)
@@ -298,13 +325,13 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
                 if (j0 + t < len) acc = sadd(acc, smul(CONJX ? sconj(xg[t]) : xg[t], av[t]));
         }
         if (r < c_rb) {
-            y[r] = acc;
+            *reinterpret_cast<T *>(reinterpret_cast<char *>(y) + r8) = acc;
             if (DOT == 1) d0 = sadd(d0, smul(sconj(c_uu), acc));
             if (DOT == 2) { d0 = sadd(d0, smul(sconj(acc), acc)); d1 = sadd(d1, smul(sconj(acc), c_uu)); }
         }
         wave_lds_fence();   // the row phase is done with the LDS slice: refill it for the next block
         if (more) { stage(nxt); adopt(nxt); }
-        dn = dn2; o2 = o3;
+        dn = uniform(dn2); o2 = __builtin_amdgcn_readfirstlane(o3);
     }
     if (DOT >= 1) {
         d0 = block_sum(d0, red);
@@ -385,30 +412,63 @@ int build_dict_t(sprs_csr *A) {
     auto *D = new sprs_dict();
     A->dict = D;   // freed by free_dict on every failure path below (sprs_csr_destroy)
     const size_t nb = ((size_t)A->nnz + 3) / 4 * 4 + 8;
-#define DICT_TRY2(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { snprintf(c->err, sizeof(c->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); cleanup(); free_dict(A); return SPRS_ERR_HIP; } } while (0)
+    uint8_t *val_code = nullptr, *seen = nullptr;   // temporaries of the pair stage
+    auto cleanup2 = [&]() { cleanup(); if (val_code) (void)hipFree(val_code); if (seen) (void)hipFree(seen); };
+#define DICT_TRY2(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { snprintf(c->err, sizeof(c->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); cleanup2(); free_dict(A); return SPRS_ERR_HIP; } } while (0)
     DICT_TRY2(hipMalloc((void **)&D->idx_code, nb));
     DICT_TRY2(hipMemsetAsync(D->idx_code, 0, nb, c->stream));
     DICT_TRY2(hipMalloc((void **)&D->off_tab, sizeof(int32_t) * TAB));
     DICT_TRY2(hipMemcpyAsync(D->off_tab, off_tab.data(), sizeof(int32_t) * TAB, hipMemcpyHostToDevice, c->stream));
     if (use_vals) {
-        DICT_TRY2(hipMalloc((void **)&D->val_code, nb));
-        DICT_TRY2(hipMemsetAsync(D->val_code, 0, nb, c->stream));
-        DICT_TRY2(hipMalloc(&D->val_tab, sizeof(T) * TAB));
-        DICT_TRY2(hipMemcpyAsync(D->val_tab, val_tab.data(), sizeof(T) * TAB, hipMemcpyHostToDevice, c->stream));
+        DICT_TRY2(hipMalloc((void **)&val_code, nb));
+        DICT_TRY2(hipMemsetAsync(val_code, 0, nb, c->stream));
     }
     D->n_off = (int)offs.size(); D->n_val = use_vals ? (int)vals.size() : 0;
     int *bad = counts + 3;
     if (use_vals)
         hipLaunchKernelGGL((dict_encode_kernel<T, VALS>), dim3(g), dim3(BLOCK), 0, c->stream, n, A->row_ptr, A->col_idx, val, off_h,
-                           slot_codes, val_h, slot_codes + HSLOTS, D->idx_code, D->val_code, bad);
+                           slot_codes, val_h, slot_codes + HSLOTS, D->idx_code, val_code, bad);
     else
         hipLaunchKernelGGL((dict_encode_kernel<T, false>), dim3(g), dim3(BLOCK), 0, c->stream, n, A->row_ptr, A->col_idx, val, off_h,
-                           slot_codes, val_h, slot_codes + HSLOTS, D->idx_code, D->val_code, bad);
+                           slot_codes, val_h, slot_codes + HSLOTS, D->idx_code, val_code, bad);
     DICT_TRY2(hipGetLastError());
     DICT_TRY2(hipMemcpyAsync(h_counts, counts, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
     DICT_TRY2(hipStreamSynchronize(c->stream));
-    cleanup();
-    if (h_counts[3] != 0) free_dict(A);      // cannot happen (every key was inserted); keep the plain stream if it does
+    if (h_counts[3] != 0) { cleanup2(); free_dict(A); return SPRS_OK; }   // cannot happen (every key was inserted)
+    if (use_vals) {
+        // ---- pair stage: which (offset code, value code) pairs occur?  <= 256 of them -> one byte per nnz
+        const int gk = (int)std::max<int64_t>(1, std::min<int64_t>(c->num_cu * 8, (A->nnz + BLOCK - 1) / BLOCK));
+        DICT_TRY2(hipMalloc((void **)&seen, 65536 + 65536));
+        DICT_TRY2(hipMemsetAsync(seen, 0, 65536, c->stream));
+        hipLaunchKernelGGL(dict_pair_mark_kernel, dim3(gk), dim3(BLOCK), 0, c->stream, A->nnz, D->idx_code, val_code, seen);
+        DICT_TRY2(hipGetLastError());
+        std::vector<uint8_t> h_seen(65536), pair_of(65536, 0);
+        DICT_TRY2(hipMemcpyAsync(h_seen.data(), seen, 65536, hipMemcpyDeviceToHost, c->stream));
+        DICT_TRY2(hipStreamSynchronize(c->stream));
+        std::vector<int32_t> pair_off(TAB, 0);
+        std::vector<T> pair_val(TAB, szero<T>());
+        int np = 0;
+        for (int pr = 0; pr < 65536; ++pr) {
+            if (!h_seen[pr]) continue;
+            if (np < TAB) { pair_of[pr] = (uint8_t)np; pair_off[np] = off_tab[pr & 255]; pair_val[np] = val_tab[pr >> 8]; }
+            ++np;
+        }
+        if (np >= 1 && np <= TAB) {
+            DICT_TRY2(hipMalloc((void **)&D->pair_code, nb));
+            DICT_TRY2(hipMemsetAsync(D->pair_code, 0, nb, c->stream));
+            DICT_TRY2(hipMalloc((void **)&D->pair_off, sizeof(int32_t) * TAB));
+            DICT_TRY2(hipMalloc(&D->pair_val, sizeof(T) * TAB));
+            DICT_TRY2(hipMemcpyAsync(D->pair_off, pair_off.data(), sizeof(int32_t) * TAB, hipMemcpyHostToDevice, c->stream));
+            DICT_TRY2(hipMemcpyAsync(D->pair_val, pair_val.data(), sizeof(T) * TAB, hipMemcpyHostToDevice, c->stream));
+            DICT_TRY2(hipMemcpyAsync(seen + 65536, pair_of.data(), 65536, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(dict_pair_encode_kernel, dim3(gk), dim3(BLOCK), 0, c->stream, A->nnz, D->idx_code, val_code,
+                               seen + 65536, D->pair_code);
+            DICT_TRY2(hipGetLastError());
+            DICT_TRY2(hipStreamSynchronize(c->stream));
+            D->n_pair = np;
+        }
+    }
+    cleanup2();
     return SPRS_OK;
 #undef DICT_TRY
 #undef DICT_TRY2
@@ -419,10 +479,8 @@ int build_dict_t(sprs_csr *A) {
 void free_dict(sprs_csr *A) {
     if (!A || !A->dict) return;
     sprs_dict *D = A->dict;
-    if (D->idx_code) (void)hipFree(D->idx_code);
-    if (D->val_code) (void)hipFree(D->val_code);
-    if (D->off_tab) (void)hipFree(D->off_tab);
-    if (D->val_tab) (void)hipFree(D->val_tab);
+    for (void *q : {(void *)D->idx_code, (void *)D->pair_code, (void *)D->off_tab, (void *)D->pair_off, D->pair_val})
+        if (q) (void)hipFree(q);
     delete D;
     A->dict = nullptr;
 }
@@ -439,7 +497,9 @@ int build_dict(sprs_csr *A, bool has_vector_blocks) {
 
 int dict_mode(const sprs_csr *A) {
     if (!A->dict || A->ctx->spmv_dict == 0) return 0;
-    if (A->dict->val_code && A->ctx->spmv_dict != 1) return 2;
+    // the kernel addresses x, y, row_ptr and the codes with 32-bit byte offsets from their bases
+    if ((uint64_t)std::max(A->ncols, A->nrows + 1) * std::max<size_t>(dtype_size(A->dtype), 4) >= (1ull << 32)) return 0;
+    if (A->dict->pair_code && A->ctx->spmv_dict != 1) return 2;
     return 1;
 }
 
@@ -449,12 +509,15 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
     sprs_ctx *c = A->ctx;
     const sprs_dict *D = A->dict;
     const T *v = reinterpret_cast<const T *>(A->val);
-    const T *vt = reinterpret_cast<const T *>(D->val_tab);
-#define SPRS_DSPMV2(DM, CJ, VD)                                                                                         \
-    hipLaunchKernelGGL((spmv_dict_kernel<T, DM, CJ, VD>), dim3(g), dim3(BLOCK), 0, c->stream, count, xcd_chunk,          \
-                       reinterpret_cast<const BlkDesc *>(A->blk_desc), order, A->row_ptr, D->idx_code, D->val_code, D->off_tab, \
-                       vt, v, x, y, u, part0, part1, status)
-#define SPRS_DSPMV(DM, CJ) do { if (has_val_dict<T>::value && mode == 2) SPRS_DSPMV2(DM, CJ, (has_val_dict<T>::value)); else SPRS_DSPMV2(DM, CJ, false); } while (0)
+    const T *pv = reinterpret_cast<const T *>(D->pair_val);
+    const bool pair = has_val_dict<T>::value && mode == 2;
+    const uint8_t *code = pair ? D->pair_code : D->idx_code;
+    const int32_t *otab = pair ? D->pair_off : D->off_tab;
+#define SPRS_DSPMV2(DM, CJ, PR)                                                                                         \
+    hipLaunchKernelGGL((spmv_dict_kernel<T, DM, CJ, PR>), dim3(g), dim3(BLOCK), 0, c->stream, count, xcd_chunk,          \
+                       reinterpret_cast<const BlkDesc *>(A->blk_desc), order, A->row_ptr, code, otab, pv, v, x, y, u,   \
+                       part0, part1, status)
+#define SPRS_DSPMV(DM, CJ) do { if (pair) SPRS_DSPMV2(DM, CJ, (has_val_dict<T>::value)); else SPRS_DSPMV2(DM, CJ, false); } while (0)
     if (conj_x && is_complex<T>::value) {
         if (dot_mode == 0) SPRS_DSPMV(0, true);
         else if (dot_mode == 1) SPRS_DSPMV(1, true);

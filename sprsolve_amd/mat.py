@@ -93,7 +93,7 @@ class HipCsr(MatVecMul):
         return int(_lib.lib().sprs_csr_nnz(self.h))
 
     def stream_format(self):
-        """(mode, n_offsets, n_values): 0 plain CSR, 1 offset codes, 2 offset + value codes (csrc/spmv_dict.hip)."""
+        """(mode, n_offsets, n_pairs): 0 plain CSR, 1 offset codes + values, 2 (offset, value) pair codes (csrc/spmv_dict.hip)."""
         no, nv = C.c_int(0), C.c_int(0)
         m = _lib.lib().sprs_csr_stream_format(self.h, C.byref(no), C.byref(nv))
         return int(m), no.value, nv.value
