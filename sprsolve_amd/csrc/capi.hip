@@ -65,7 +65,9 @@ int sprs_ctx_create(int device, void *stream, sprs_ctx **out) {
     }
     // 4 workgroups of 256 lanes per CU: enough loads in flight to saturate HBM while the
     // number of reduction partials (== grid) stays small enough for the fused prologues
-    c->grid = ((c->num_cu * 4 + 7) / 8) * 8;
+    // streaming / reduction kernels: 2 workgroups per CU (measured on the cfg-5 solve: 256 -> 1.99, 384 -> 1.90,
+    // 512 -> 1.86, 768 -> 1.86, 1024 -> 2.00, 2048 -> 2.06 ms per BiCGStab iteration; profiles/r01_tuning.md)
+    c->grid = ((c->num_cu * 2 + 7) / 8) * 8;
     if (c->grid > MAX_GRID) c->grid = MAX_GRID;
     if (hipMalloc((void **)&c->d_part, sizeof(double) * 2 * MAX_GRID) != hipSuccess) return fail(SPRS_ERR_HIP);
     if (hipMalloc((void **)&c->d_scal, 256) != hipSuccess) return fail(SPRS_ERR_HIP);

@@ -24,7 +24,7 @@ struct sprs_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 256;
-    int grid = 1024;     // blocks launched by streaming / reduction kernels (multiple of 8)
+    int grid = 512;      // blocks launched by streaming / reduction kernels (multiple of 8; 2 per CU, set in sprs_ctx_create)
     int spmv_grid = -1;    // workgroups of the persistent SpMV grid; -1 = auto (4 per CU)
     // SpMV placement knobs; -1 = auto (measured on MI355X, profiles/r01_tuning.md): matrices whose stream
     // fits the 256 MiB Infinity Cache run best with one contiguous chunk of row blocks per XCD and
