@@ -129,4 +129,9 @@ def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, t
     tot = reduce_scalar(nnz_loc, tdist.ReduceOp.SUM)
     check_ = dict(tol=1e-8, iters=its, rel_res=res, max_abs_err_vs_exact=err,
                   exchange=exchange, halo_entries_per_rank=int(plan["n_ext"] - n_loc), peers=[int(p) for p in plan["peers"]])
-    return dt, prof, t_spmv, bs, check_, nx * ny * nz, int(tot)
+    mode, n_off, n_pair = A.stream_format()      # what this rank's SpMV streams (csrc/spmv_dict.hip)
+    per_nnz = {0: 12, 1: 9, 2: 1}[mode]
+    sinfo = dict(stream={0: "csr", 1: "offset-codes", 2: "pair-codes"}[mode], mode=mode, distinct_offsets=n_off,
+                 distinct_pairs=n_pair, bytes_per_nnz=per_nnz,
+                 format_bytes_per_launch=nnz_loc * per_nnz + (n_loc + 1) * 4 + 2 * n_loc * 8)
+    return dt, prof, t_spmv, bs, check_, nx * ny * nz, int(tot), sinfo
