@@ -500,6 +500,15 @@ int dict_mode(const sprs_csr *A) {
     // the kernel addresses x, y, row_ptr and the codes with 32-bit byte offsets from their bases
     if ((uint64_t)std::max(A->ncols, A->nrows + 1) * std::max<size_t>(dtype_size(A->dtype), 4) >= (1ull << 32)) return 0;
     if (A->dict->pair_code && A->ctx->spmv_dict != 1) return 2;
+    if (A->ctx->spmv_dict == -1) {
+        // offset codes + values pay only where the saved 3 B/nnz matter (measured, profiles/r01_tuning.md): f64 / f32
+        // matrices that stream from HBM (cfg-5 size: 940 vs 1110 us).  Cache-resident ones run the same (cfg 3:
+        // 25 vs 25 us) and complex ones slower (cfg 4: 27 vs 16 us; 17 instead of 20 B/nnz is not worth the
+        // lane-per-row layout), so auto keeps the plain stream for those.
+        const double sz = (double)dtype_size(A->dtype);
+        const bool cache_resident = (double)A->nnz * (sz + 4) + 3.0 * A->nrows * sz < 192.0 * 1024 * 1024;
+        if (dtype_is_complex(A->dtype) || cache_resident) return 0;
+    }
     return 1;
 }
 
