@@ -94,7 +94,9 @@ int sprs_csr_create_i64_d(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t n
 int sprs_csr_create_i64_z(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t *row_ptr,
                           const int64_t *col_idx, const sprs_c64 *val, int storage_csc, sprs_csr **out);
 /* Create from arrays already resident in HBM (CSR, i32).  adopt == 0: copied; adopt != 0: the
- * handle references the caller's arrays, which must outlive it (no copy of multi-GB matrices). */
+ * handle references the caller's arrays, which must outlive it (no copy of multi-GB matrices) and must not
+ * be modified while the handle lives: like mkl_sparse_optimize (mkl_mat.rs:81-148), creation analyses the
+ * matrix once and keeps what it derived (row blocks, the compressed code stream of sprs_csr_stream_format). */
 int sprs_csr_create_dev_d(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *dev_row_ptr,
                           const int32_t *dev_col_idx, const double *dev_val, int adopt, sprs_csr **out);
 int sprs_csr_create_dev_z(sprs_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *dev_row_ptr,
