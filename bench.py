@@ -74,6 +74,31 @@ def stream_info(A, n, nnz, s):
                 bytes_per_nnz=per_nnz, format_bytes_per_launch=nnz * per_nnz + (n + 1) * 4 + 2 * n * s)
 
 
+def stream_ceiling(torch, ctx, n, reps=20):
+    """SURVEY §8d's secondary denominator: what this library's own streaming kernels reach on this box.
+    axpy (y += a*x: 2 reads + 1 write of n doubles, `ew_kernel<AxpyF>`) and a device-to-device copy
+    (1 read + 1 write), back to back on the library's stream, wall clock around `reps` launches."""
+    import ctypes as C
+
+    from sprsolve_amd import _lib
+    x = torch.rand(n, dtype=torch.float64, device="cuda"); y = torch.rand(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    L = _lib.lib()
+    px, py = C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())
+    out = {}
+    for name, fn, nbytes in (("axpy", lambda: L.sprs_axpy_d(ctx.h, n, 1e-3, px, py), 3 * n * 8),
+                             ("copy", lambda: L.sprs_memcpy_d2d(ctx.h, py, px, n * 8), 2 * n * 8)):
+        for _ in range(3):
+            fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.sync()
+        out[name + "_GBs"] = nbytes * reps / (time.perf_counter() - t0) / 1e9
+    return out
+
+
 def run_fixed_iterations(solver, precond, rhs, x, steps):
     """solve(max_iter=steps, tol=0): exactly `steps` iterations, ends in InsufficientIterNum."""
     import sprsolve_amd as sa
@@ -321,6 +346,16 @@ def main():
                                bytes_per_iteration_reference_oplist=it_bytes),
                    effective_GBs_reference_oplist=it_bytes * args.steps / dt / 1e9,
                    roofline=roof, converge_check=check)
+        if world == 1 and rank == 0:
+            del x
+            sc = stream_ceiling(torch, ctx, n_glob if not args.force_dist else min(n_glob, 50_000_000))
+            roof["measured_stream_ceiling"] = dict(sc, note="this library's axpy (2R+1W) and a d2d copy (1R+1W) on n doubles, "
+                                                            "back to back — SURVEY §8d's secondary denominator")
+            best = max(sc.values())
+            roof["frac_of_measured_stream"] = roof["achieved"] / best
+            roof["format_frac_of_measured_stream"] = roof["format_GBs"] / best
+            if "cfg5_plain_csr_stream" in also:
+                also["cfg5_plain_csr_stream"]["spmv_frac_of_measured_stream"] = also["cfg5_plain_csr_stream"]["spmv_GBs"] / best
         if world == 1 and not args.no_also and not args.force_dist:
             r2, _, _ = bench_poisson2d(500, 50)
             also["cfg2_poisson2d_1M_bicgstab_jacobi"] = r2
