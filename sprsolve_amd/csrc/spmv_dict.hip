@@ -308,7 +308,17 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
             const uint8_t *cp = cb + c_shift + kb;
             T xg[8], av[8];
 #pragma unroll
+            for (int t = 0; t < 8; ++t) { xg[t] = szero<T>(); av[t] = szero<T>(); }
+            // slots 4..7 are skipped (scalar branch) when no row of the block is that long: a 5-point row wastes
+            // none of the LDS look-ups and gathers of slots 5..7, a 7-point row none of slot 7
+            const uint64_t m4 = __builtin_amdgcn_ballot_w64(j0 + 4 < len), m5 = __builtin_amdgcn_ballot_w64(j0 + 5 < len),
+                           m6 = __builtin_amdgcn_ballot_w64(j0 + 6 < len), m7 = __builtin_amdgcn_ballot_w64(j0 + 7 < len);
+#pragma unroll
             for (int t = 0; t < 8; ++t) {
+                if (t == 4 && m4 == 0) break;
+                if (t == 5 && m5 == 0) break;
+                if (t == 6 && m6 == 0) break;
+                if (t == 7 && m7 == 0) break;
                 const bool valid = j0 + t < len;
                 const int cd = cp[t];
                 int off8;
