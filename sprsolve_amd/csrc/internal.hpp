@@ -41,6 +41,7 @@ struct sprs_ctx {
     // dictionary-compressed SpMV stream: -1 auto (the most compact the matrix qualifies for), 0 plain CSR,
     // 1 offset codes + values, 2 (offset, value) pair codes.  Read at handle creation (what is built) and at launch (what is used).
     int spmv_dict = -1;
+    int spmv_wide = -1;   // f64 pair codes: two rows per lane (16-byte gathers); -1 / 1 on, 0 off
     int halo_overlap = 1;  // distributed SpMV: run the halo-free rows while the halo travels
     int gs_graph = 0;    // Gauss-Seidel: 1 = replay a sweep's level launches from a hipGraph (measured: no gain, r01_tuning.md)
     int poll = 16;       // iterations between host polls of the device status word
@@ -105,6 +106,8 @@ struct sprs_dict {
     int32_t *pair_off = nullptr;   // device, 256 entries: col - row per pair code
     void *pair_val = nullptr;      // device, 256 entries of T: value per pair code
     int n_off = 0, n_val = 0, n_pair = 0;
+    void *wide_desc = nullptr;     // device: descriptors of the 128-row blocks of the two-rows-per-lane kernel (f64 pair codes)
+    int n_wide = 0;
 };
 
 struct sprs_csr {
@@ -160,7 +163,8 @@ int launch_spmv_subset(const sprs_csr *A, const int32_t *order, int count, const
                        T *part0, T *part1, const int *status, bool conj_x);
 int spmv_subset_grid(const sprs_csr *A, int count);
 // ---- spmv_dict.hip
-int build_dict(sprs_csr *A, bool has_vector_blocks);   // SPRS_OK also when the matrix does not qualify (A->dict stays null)
+// SPRS_OK also when the matrix does not qualify (A->dict stays null); blk / host_row_ptr: the row blocks just built
+int build_dict(sprs_csr *A, bool has_vector_blocks, const std::vector<int32_t> &blk, const int32_t *host_row_ptr);
 void free_dict(sprs_csr *A);
 int dict_mode(const sprs_csr *A);                      // 0 plain, 1 offsets, 2 offsets + values: what launch_spmv will use
 template <class T>

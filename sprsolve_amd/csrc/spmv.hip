@@ -72,7 +72,7 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
     SPRS_TRY(build_schedule(A, blk));
     bool has_vec = false;
     for (int b = 0; b < A->n_rowblk; ++b) has_vec |= ((uint32_t)blk[b] & VEC_FLAG) != 0;
-    return build_dict(A, has_vec);   // dictionary-compressed stream when the matrix qualifies (spmv_dict.hip)
+    return build_dict(A, has_vec, blk, rp);   // dictionary-compressed stream when the matrix qualifies (spmv_dict.hip)
 }
 
 // streaming (read-once) loads: keep the matrix stream from evicting the gathered x lines

@@ -353,12 +353,197 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Two rows per lane (f64, pair codes).  A 64-lane 8-byte gather costs the CU's vector-memory pipe ~14.4 cycles
+// whatever it touches — the same as a 16-byte one (scripts/micro/ta_rate.hip) — and the x gathers are most of the
+// pipe's work in the kernel above.  Here lane l owns rows ra + 2l and ra + 2l + 1 of a 128-row block; where both
+// rows have the same column offset in a slot (every interior row of a stencil) ONE 16-byte load returns x for
+// both, as does one 16-byte load for u and one 16-byte store for y.  Rows whose slots disagree (grid boundaries,
+// irregular rows) take an extra 8-byte gather for the second row, issued only if some lane of the wavefront needs
+// it.  Same fold per row (left to right from zero): y stays bit-identical; the fused dot partials group the rows
+// differently, so those reductions differ from the 64-row kernel's in summation order only.
+struct alignas(16) D2 { double lo, hi; };
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+constexpr int CAP2 = 2 * nnz_cap<double>::value;          // 1024 code bytes per wide block
+constexpr int CW2 = (CAP2 + 3 + CPAD + 15) / 16 * 4;      // dwords of a wavefront's slice (multiple of 4: b128 stores)
+
+struct Blk2Loads {
+    int ra, rb, pa, nn;      // descriptor of the 128-row block
+    int a, b;                // row_ptr[i0], row_ptr[i0 + 1], i0 = min(ra + 2 lane, rb - 1)
+    double u0, u1;           // dot operands of the lane's two rows
+    u4v wc;                  // 16 code bytes
+    int di;                  // ... and the b128 slot they go to
+};
+
+template <int DOT>
+__global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_chunk, const BlkDesc *__restrict__ desc,
+                                                           const int32_t *__restrict__ row_ptr,
+                                                           const uint8_t *__restrict__ code,
+                                                           const int32_t *__restrict__ off_tab,
+                                                           const double *__restrict__ val_tab, const double *__restrict__ x,
+                                                           double *__restrict__ y, const double *__restrict__ u,
+                                                           double *__restrict__ part0, double *__restrict__ part1,
+                                                           const int *__restrict__ status, int nrows, int ncols) {
+    using T = double;
+    __shared__ PairEnt<T> s_pair[TAB];
+    __shared__ __attribute__((aligned(16))) uint32_t s_c[NWAVE][CW2];
+    __shared__ T red[NWAVE];
+    if (status != nullptr && *status != ST_RUNNING) return;
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    s_pair[tid] = PairEnt<T>{off_tab[tid] * 8, val_tab[tid]};                  // BLOCK == TAB
+    for (int i = lane; i < CW2; i += WAVE) s_c[wv][i] = 0;                     // the pad is read (and ignored) before it is written
+    __syncthreads();
+
+    const uint8_t *cb = reinterpret_cast<const uint8_t *>(s_c[wv]);
+    const char *xbytes = reinterpret_cast<const char *>(x);
+    const uint32_t xlast_pair = (uint32_t)(ncols - 2) * 8u;                    // last byte offset a 16-byte x load may start at
+    T d0 = 0.0, d1 = 0.0;
+
+    int b, bstep, bend;
+    if (xcd_chunk) {
+        const int chunk = (n_wide + 7) >> 3;
+        const int xcd = blockIdx.x & 7;
+        b = xcd * chunk + (blockIdx.x >> 3) * NWAVE + wv;
+        bstep = (gridDim.x >> 3) * NWAVE;
+        bend = min(n_wide, (xcd + 1) * chunk);
+    } else {
+        b = blockIdx.x * NWAVE + wv; bstep = gridDim.x * NWAVE; bend = n_wide;
+    }
+    if (b >= bend) b = bend;
+
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef const v4i __attribute__((address_space(1))) *gv4i_p;
+    uintptr_t desc_a = reinterpret_cast<uintptr_t>(desc);
+    asm volatile("" : "+v"(desc_a));                // vector (in-order) descriptor loads, as in spmv_dict_kernel
+    const gv4i_p desc_v = reinterpret_cast<gv4i_p>(desc_a);
+    auto load_desc = [&](int bi) -> BlkDesc { const v4i q = desc_v[bi]; return BlkDesc{q.x, q.y, q.z, q.w}; };
+    auto uniform = [&](const BlkDesc &d) -> BlkDesc {
+        return BlkDesc{__builtin_amdgcn_readfirstlane(d.ra), __builtin_amdgcn_readfirstlane(d.rb),
+                       __builtin_amdgcn_readfirstlane(d.pa), __builtin_amdgcn_readfirstlane(d.nn)};
+    };
+    auto issue = [&](const BlkDesc &d, Blk2Loads &L) {
+        L.ra = d.ra; L.rb = d.rb; L.pa = d.pa; L.nn = d.nn;
+        const int r0 = L.ra + 2 * lane;
+        const int i0 = min(r0, L.rb - 1);                                       // row_ptr[i0 + 1] exists: i0 + 1 <= rb <= nrows
+        const int2 ab = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(row_ptr) + (uint32_t)i0 * 4u);
+        L.a = ab.x; L.b = ab.y;
+        if (DOT != 0) {
+            const int p0 = min(r0, nrows - 2);                                  // the pair (u[p0], u[p0 + 1]) is inside u
+            const D2 uu = *reinterpret_cast<const D2 *>(reinterpret_cast<const char *>(u) + (uint32_t)p0 * 8u);
+            L.u0 = r0 == p0 ? uu.lo : uu.hi;                                    // r0 == nrows - 1: its operand is the pair's second half
+            L.u1 = uu.hi;
+        }
+        const int shift = L.pa & 3;
+        const int nq = max((shift + L.nn + 15) >> 4, 1);                        // 16-byte pieces covering the codes, <= 65
+        L.di = min(lane, nq - 1);
+        L.wc = *reinterpret_cast<const u4v *>(reinterpret_cast<const char *>(code) + (uint32_t)(L.pa - shift + 16 * L.di));
+    };
+    int c_ra = 0, c_rb = 0, c_shift = 0, c_s0 = 0, c_s1 = 0, c_len0 = 0, c_len1 = 0;
+    T c_u0 = 0.0, c_u1 = 0.0;
+    auto stage = [&](const Blk2Loads &L) {
+        const int shift = L.pa & 3;
+        if (L.nn > 0) {
+            *reinterpret_cast<u4v *>(&s_c[wv][4 * L.di]) = L.wc;               // clamped duplicates store the same 16 bytes
+            if (shift + L.nn > CAP2 && lane == 0)                               // the 65th piece exists only then: one dword is enough
+                s_c[wv][CAP2 / 4] = *reinterpret_cast<const uint32_t *>(code + (L.pa - shift) + CAP2);
+        }
+        const int r0 = L.ra + 2 * lane;
+        int c = __shfl_down(L.a, 1, WAVE);                                      // row_ptr[r0 + 2] sits in the next lane
+        if (r0 + 2 >= L.rb) c = L.pa + L.nn;                                    // ... unless the block ends there
+        c_ra = L.ra; c_rb = L.rb; c_shift = shift;
+        c_s0 = L.a - L.pa; c_s1 = L.b - L.pa;
+        c_len0 = r0 < L.rb ? L.b - L.a : 0;
+        c_len1 = r0 + 1 < L.rb ? c - L.b : 0;
+        if (DOT != 0) { c_u0 = L.u0; c_u1 = L.u1; }
+    };
+
+    BlkDesc dn{0, 1, 0, 0};
+    if (b < bend) {
+        Blk2Loads first;
+        issue(uniform(load_desc(b)), first);
+        if (b + bstep < bend) dn = uniform(load_desc(b + bstep));
+        stage(first);
+    }
+    for (; b < bend; b += bstep) {
+        const bool more = b + bstep < bend;
+        Blk2Loads nxt;
+        BlkDesc dn2{0, 1, 0, 0};
+        if (b + 2 * bstep < bend) dn2 = load_desc(b + 2 * bstep);
+        if (more) issue(dn, nxt);
+        wave_lds_fence();
+        const int r0 = c_ra + 2 * lane;
+        const uint32_t r8 = (uint32_t)r0 * 8u;
+        const int len0 = c_len0, len1 = c_len1, lenm = max(len0, len1);
+        T acc0 = 0.0, acc1 = 0.0;
+        for (int j0 = 0; __builtin_amdgcn_ballot_w64(j0 < lenm) != 0; j0 += 8) {
+            const uint8_t *cp0 = cb + c_shift + min(c_s0 + j0, CAP2);
+            const uint8_t *cp1 = cb + c_shift + min(c_s1 + j0, CAP2);
+            T pl[8], ph[8];           // the 16-byte gather of the slot: x[col0], x[col0 + 1]
+            T xs[8];                  // row 1's own gather where its column is not row 0's + 1
+            uint32_t same_bits = 0, hi_bits = 0;      // per slot: row 1 shares the gather / row 0's x is the pair's second half
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; xs[t] = 0.0; }
+            const uint64_t m4 = __builtin_amdgcn_ballot_w64(j0 + 4 < lenm), m5 = __builtin_amdgcn_ballot_w64(j0 + 5 < lenm),
+                           m6 = __builtin_amdgcn_ballot_w64(j0 + 6 < lenm), m7 = __builtin_amdgcn_ballot_w64(j0 + 7 < lenm);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t == 4 && m4 == 0) break;
+                if (t == 5 && m5 == 0) break;
+                if (t == 6 && m6 == 0) break;
+                if (t == 7 && m7 == 0) break;
+                const bool v0 = j0 + t < len0, v1 = j0 + t < len1;
+                const int off0 = s_pair[cp0[t]].off8, off1 = s_pair[cp1[t]].off8;
+                const bool same = v0 && v1 && off0 == off1;                     // column of row 1 == column of row 0 + 1
+                const uint32_t vo0 = v0 ? r8 + (uint32_t)off0 : 0u;             // byte offset of x[col0]; unused rows read x[0]
+                const uint32_t vp = min(vo0, xlast_pair);                       // a 16-byte load must start at or before x[ncols - 2]
+                same_bits |= (same ? 1u : 0u) << t;
+                hi_bits |= (vo0 != vp ? 1u : 0u) << t;                          // col0 == ncols - 1: it is the pair's second half
+                const D2 px = *reinterpret_cast<const D2 *>(xbytes + vp);
+                pl[t] = px.lo; ph[t] = px.hi;
+                const bool need1 = v1 && !same;
+                if (__builtin_amdgcn_ballot_w64(need1) != 0)                    // scalar branch: interior stencil blocks skip it
+                    xs[t] = *reinterpret_cast<const T *>(xbytes + (need1 ? r8 + 8u + (uint32_t)off1 : 0u));
+            }
+            __builtin_amdgcn_sched_barrier(0);                                  // every gather out before the first product
+            asm volatile("" ::: "memory");      // the values are looked up again below rather than held in 32 registers across the wait
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (j0 + t < len0) acc0 = acc0 + (((hi_bits >> t) & 1u) ? ph[t] : pl[t]) * s_pair[cp0[t]].val;
+                if (j0 + t < len1) acc1 = acc1 + (((same_bits >> t) & 1u) ? ph[t] : xs[t]) * s_pair[cp1[t]].val;
+            }
+        }
+        if (r0 + 1 < c_rb) {
+            *reinterpret_cast<D2 *>(reinterpret_cast<char *>(y) + r8) = D2{acc0, acc1};
+            if (DOT == 1) { d0 = d0 + c_u0 * acc0; d0 = d0 + c_u1 * acc1; }
+            if (DOT == 2) { d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * c_u0; d0 = d0 + acc1 * acc1; d1 = d1 + acc1 * c_u1; }
+        } else if (r0 < c_rb) {
+            *reinterpret_cast<T *>(reinterpret_cast<char *>(y) + r8) = acc0;
+            if (DOT == 1) d0 = d0 + c_u0 * acc0;
+            if (DOT == 2) { d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * c_u0; }
+        }
+        wave_lds_fence();
+        if (more) stage(nxt);
+        dn = uniform(dn2);
+    }
+    if (DOT >= 1) {
+        d0 = block_sum(d0, red);
+        if (tid == 0) part0[blockIdx.x] = d0;
+    }
+    if (DOT == 2) {
+        d1 = block_sum(d1, red);
+        if (tid == 0) part1[blockIdx.x] = d1;
+    }
+}
+
+struct BlkDescHost2 { int32_t ra, rb, pa, nn; };
 template <class T> struct has_val_dict { static constexpr bool value = false; };
 template <> struct has_val_dict<double> { static constexpr bool value = true; };
 template <> struct has_val_dict<float> { static constexpr bool value = true; };
 
 template <class T>
-int build_dict_t(sprs_csr *A) {
+int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp) {
     sprs_ctx *c = A->ctx;
     constexpr bool VALS = has_val_dict<T>::value;
     const bool want_vals = VALS && c->spmv_dict != 1;
@@ -421,7 +606,7 @@ int build_dict_t(sprs_csr *A) {
     DICT_TRY(hipMemcpyAsync(slot_codes, codes.data(), 2 * HSLOTS, hipMemcpyHostToDevice, c->stream));
     auto *D = new sprs_dict();
     A->dict = D;   // freed by free_dict on every failure path below (sprs_csr_destroy)
-    const size_t nb = ((size_t)A->nnz + 3) / 4 * 4 + 8;
+    const size_t nb = ((size_t)A->nnz + 3) / 4 * 4 + 64;     // the kernels read whole dwords / 16-byte pieces past the last code
     uint8_t *val_code = nullptr, *seen = nullptr;   // temporaries of the pair stage
     auto cleanup2 = [&]() { cleanup(); if (val_code) (void)hipFree(val_code); if (seen) (void)hipFree(seen); };
 #define DICT_TRY2(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { snprintf(c->err, sizeof(c->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); cleanup2(); free_dict(A); return SPRS_ERR_HIP; } } while (0)
@@ -476,6 +661,19 @@ int build_dict_t(sprs_csr *A) {
             DICT_TRY2(hipGetLastError());
             DICT_TRY2(hipStreamSynchronize(c->stream));
             D->n_pair = np;
+            if constexpr (sizeof(T) == 8 && !is_complex<T>::value) {
+                // 128-row blocks of the two-rows-per-lane kernel: consecutive pairs of the 64-row blocks
+                const int nb64 = A->n_rowblk, nw = (nb64 + 1) / 2;
+                std::vector<BlkDescHost2> wd((size_t)nw);
+                for (int j = 0; j < nw; ++j) {
+                    const int32_t ra = blk[(size_t)2 * j], rb = blk[(size_t)std::min(2 * j + 2, nb64)];
+                    wd[(size_t)j] = BlkDescHost2{ra, rb, rp[ra], rp[rb] - rp[ra]};
+                }
+                DICT_TRY2(hipMalloc(&D->wide_desc, sizeof(BlkDescHost2) * (size_t)std::max(nw, 1)));
+                DICT_TRY2(hipMemcpyAsync(D->wide_desc, wd.data(), sizeof(BlkDescHost2) * (size_t)nw, hipMemcpyHostToDevice, c->stream));
+                DICT_TRY2(hipStreamSynchronize(c->stream));
+                D->n_wide = nw;
+            }
         }
     }
     cleanup2();
@@ -489,19 +687,19 @@ int build_dict_t(sprs_csr *A) {
 void free_dict(sprs_csr *A) {
     if (!A || !A->dict) return;
     sprs_dict *D = A->dict;
-    for (void *q : {(void *)D->idx_code, (void *)D->pair_code, (void *)D->off_tab, (void *)D->pair_off, D->pair_val})
+    for (void *q : {(void *)D->idx_code, (void *)D->pair_code, (void *)D->off_tab, (void *)D->pair_off, D->pair_val, D->wide_desc})
         if (q) (void)hipFree(q);
     delete D;
     A->dict = nullptr;
 }
 
-int build_dict(sprs_csr *A, bool has_vector_blocks) {
+int build_dict(sprs_csr *A, bool has_vector_blocks, const std::vector<int32_t> &blk, const int32_t *rp) {
     if (A->ctx->spmv_dict == 0 || has_vector_blocks || A->nnz == 0 || A->nrows == 0) return SPRS_OK;
     switch (A->dtype) {
-        case DT_D: return build_dict_t<double>(A);
-        case DT_Z: return build_dict_t<cplx>(A);
-        case DT_S: return build_dict_t<float>(A);
-        default: return build_dict_t<cplxf>(A);
+        case DT_D: return build_dict_t<double>(A, blk, rp);
+        case DT_Z: return build_dict_t<cplx>(A, blk, rp);
+        case DT_S: return build_dict_t<float>(A, blk, rp);
+        default: return build_dict_t<cplxf>(A, blk, rp);
     }
 }
 
@@ -530,6 +728,21 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
     const T *v = reinterpret_cast<const T *>(A->val);
     const T *pv = reinterpret_cast<const T *>(D->pair_val);
     const bool pair = has_val_dict<T>::value && mode == 2;
+    if constexpr (sizeof(T) == 8 && !is_complex<T>::value) {
+        // the whole matrix in natural order, f64 pair codes: two rows per lane (the subset launches of the
+        // distributed operator keep the 64-row kernel: their schedules are lists of 64-row blocks)
+        if (pair && D->wide_desc && c->spmv_wide != 0 && order == nullptr && count == A->n_rowblk && A->nrows >= 2 && A->ncols >= 2) {
+            const int gw = g;     // same grid as the 64-row kernel: the consumers reduce exactly spmv_num_partials(A) partials
+            const BlkDesc *wd = reinterpret_cast<const BlkDesc *>(D->wide_desc);
+            const double *pvd = reinterpret_cast<const double *>(D->pair_val);
+#define SPRS_WSPMV(DM) hipLaunchKernelGGL((spmv_pair2_kernel<DM>), dim3(gw), dim3(BLOCK), 0, c->stream, D->n_wide, xcd_chunk, wd, \
+                                          A->row_ptr, D->pair_code, D->pair_off, pvd, x, y, u, part0, part1, status, (int)A->nrows, (int)A->ncols)
+            if (dot_mode == 0) SPRS_WSPMV(0); else if (dot_mode == 1) SPRS_WSPMV(1); else SPRS_WSPMV(2);
+#undef SPRS_WSPMV
+            SPRS_HIP_TRY(c, hipGetLastError());
+            return SPRS_OK;
+        }
+    }
     const uint8_t *code = pair ? D->pair_code : D->idx_code;
     const int32_t *otab = pair ? D->pair_off : D->off_tab;
 #define SPRS_DSPMV2(DM, CJ, PR)                                                                                         \

@@ -21,6 +21,7 @@ def sa():
 def _restore_knob(sa):
     yield
     sa.default_ctx(0).set("spmv_dict", -1)
+    sa.default_ctx(0).set("spmv_wide", -1)
 
 
 def bits(a):
@@ -59,6 +60,7 @@ def test_formats_bit_identical(sa, oracle, dtype, name):
     ref = oracle.spmv(indptr, indices, data, x)
     real = np.dtype(dtype).kind != "c"
     got = {}
+    ctx.set("spmv_wide", 0)           # the 64-row kernels: even the fused dot partials are grouped identically
     for knob in (0, 1, 2, -1):
         ctx.set("spmv_dict", knob)
         A = sa.HipCsr.new((n, n), indptr, indices, data)
@@ -167,12 +169,14 @@ def test_ragged_and_empty_rows(sa, oracle, span):
 
 @pytest.mark.parametrize("knob", [0, 1, 2])
 def test_solver_same_iterates_in_every_format(sa, oracle, knob):
-    """BiCGStab on the 3-D Poisson problem: the SpMV and its fused partials are bit-identical across formats,
-    so the whole solve (iteration count, residual, x) is."""
+    """BiCGStab on the 3-D Poisson problem: with the 64-row kernels the SpMV and its fused partials are
+    bit-identical across formats, so the whole solve (iteration count, residual, x) is.  (The two-rows-per-lane
+    kernel groups the dot partials differently: see test_wide_kernel.)"""
     from sprsolve_amd import gen
     indptr, indices, data, rhs = gen.poisson3d(24, 20, 16)
     n = rhs.size
     ctx = sa.default_ctx(0)
+    ctx.set("spmv_wide", 0)
     res = {}
     for k in (0, knob):
         ctx.set("spmv_dict", k)
@@ -212,6 +216,7 @@ def test_minres_and_csminres_on_compressed_streams(sa, oracle):
     plain stream's iterates bit for bit."""
     from sprsolve_amd import gen
     ctx = sa.default_ctx(0)
+    ctx.set("spmv_wide", 0)           # 64-row kernels: identical dot partials, hence identical iterates
     ip, ix, d, rhs = gen.minres_grid_laplacian(24, 24)
     n = rhs.size
     out = {}
@@ -232,3 +237,70 @@ def test_minres_and_csminres_on_compressed_streams(sa, oracle):
         x = np.zeros(n, dtype=np.complex128)
         out[knob] = (sa.CSMinRes.new(A, n).solve(rhs, x, 2000, 1e-10), x)
     assert out[0][0] == out[1][0] and np.array_equal(bits(out[0][1]), bits(out[1][1]))
+
+
+@pytest.mark.parametrize("shape", [(13, 11, 9), (64, 3, 5), (7, 1, 1), (500, 2, 3)], ids=lambda s: "x".join(map(str, s)))
+def test_wide_kernel_bit_identical_y(sa, oracle, shape):
+    """The two-rows-per-lane kernel (f64 pair codes): y bit-identical to the reference fold, for block tails with an odd
+    row count, rows at the matrix end (16-byte loads clamped to x[ncols-2]), and slots where the two rows of a lane
+    disagree (grid boundaries); the fused dot agrees with the 64-row kernel's to reduction-order tolerance."""
+    from sprsolve_amd import gen
+    ctx = sa.default_ctx(0)
+    indptr, indices, data, _ = gen.poisson3d(*shape)
+    n = indptr.size - 1
+    x = rand_vec(n, np.float64, 21)
+    ref = oracle.spmv(indptr, indices, data, x)
+    dots = {}
+    for wide in (0, 1):
+        ctx.set("spmv_wide", wide)
+        A = sa.HipCsr.new((n, n), indptr, indices, data)
+        assert A.stream_format()[0] == 2
+        y = np.full(n, 5.0)
+        A.mul_vec(x, y)
+        assert np.array_equal(bits(y), bits(ref)), wide
+        y2 = np.zeros(n)
+        dots[wide] = A.mul_vec_dot(x, y2)
+        assert np.array_equal(bits(y2), bits(ref))
+    assert abs(dots[0] - dots[1]) <= 1e-13 * np.sum(np.abs(x * ref))
+
+
+def test_wide_kernel_irregular_rows(sa, oracle):
+    """Ragged rows (lengths 0..12, a few of 34), pair codes: the lanes' two rows rarely agree on a slot's offset."""
+    rng = np.random.default_rng(31)
+    n = 3001                                   # odd: the last lane owns a single row
+    lens = rng.integers(0, 13, n)
+    lens[::97] = 0
+    lens[5::211] = 34
+    rows = []
+    for r, l in enumerate(lens):
+        c = r + rng.choice(np.arange(-20, 21), l, replace=False)
+        rows.append(np.sort(c[(c >= 0) & (c < n)]))
+    indptr = np.zeros(n + 1, dtype=np.int32); np.cumsum([len(c) for c in rows], out=indptr[1:])
+    cols = np.concatenate(rows).astype(np.int32)
+    data = rng.choice(np.array([1.0, -2.0, 0.5, 4.0]), cols.size)
+    x = rand_vec(n, np.float64, 6)
+    ref = oracle.spmv(indptr, cols, data, x)
+    ctx = sa.default_ctx(0)
+    for wide in (0, 1):
+        ctx.set("spmv_wide", wide)
+        A = sa.HipCsr.new((n, n), indptr, cols, data)
+        assert A.stream_format()[0] == 2
+        y = np.full(n, 9.0)
+        A.mul_vec(x, y)
+        assert np.array_equal(bits(y), bits(ref)), wide
+
+
+def test_wide_kernel_solve(sa, oracle):
+    """The full solve on the wide kernel: same iteration count as the 64-row kernel up to reduction noise, exact solution."""
+    from sprsolve_amd import gen
+    indptr, indices, data, rhs = gen.poisson3d(24, 20, 16)
+    n = rhs.size
+    ctx = sa.default_ctx(0)
+    out = {}
+    for wide in (0, 1):
+        ctx.set("spmv_wide", wide)
+        A = sa.HipCsr.new((n, n), indptr, indices, data)
+        x = np.zeros(n)
+        out[wide] = (sa.BiCGStab.new(A, n).solve(rhs, x, 500, 1e-10), x)
+    assert abs(out[0][0][0] - out[1][0][0]) <= 2
+    assert np.max(np.abs(out[1][1] - 1.0)) < 1e-7

@@ -17,6 +17,7 @@ def env():
     ctx = sa.default_ctx(0)
     comm = sdist.Comm(ctx, 0, 1)
     yield dict(torch=torch, sa=sa, sdist=sdist, ctx=ctx, comm=comm, dev=torch.device("cuda", 0))
+    ctx.set("spmv_wide", -1)
     comm.close()
 
 
@@ -50,6 +51,9 @@ def test_dist_operator_equals_plain(env, oracle, with_halo):
             }.get(with_halo, lambda c: c > n - 3 * R)                   # only the last rows do: interior/boundary overlap
     plan = _self_halo_plan(torch, dev, n, indices, mask, segments=2 if with_halo == "tail-2-segments" else 1)
     env["ctx"].set("halo_overlap", 0 if with_halo == "tail-no-overlap" else 1)
+    # bit-for-bit equality of the SCALARS needs the same grouping of the fused dot partials: the plain handle must
+    # use the 64-row kernels like the distributed operator's subset launches (y itself is bit-identical either way)
+    env["ctx"].set("spmv_wide", 0)
     if with_halo != "none":
         assert plan["n_ext"] > n
     ip_d = torch.from_numpy(indptr).to(dev); dv_d = torch.from_numpy(data).to(dev)
