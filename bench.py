@@ -347,7 +347,7 @@ def main():
                    effective_GBs_reference_oplist=it_bytes * args.steps / dt / 1e9,
                    roofline=roof, converge_check=check)
         if world == 1 and rank == 0:
-            del x
+            x = None                      # release the solution vector before the microbench allocates its own
             sc = stream_ceiling(torch, ctx, n_glob if not args.force_dist else min(n_glob, 50_000_000))
             roof["measured_stream_ceiling"] = dict(sc, note="this library's axpy (2R+1W) and a d2d copy (1R+1W) on n doubles, "
                                                             "back to back — SURVEY §8d's secondary denominator")

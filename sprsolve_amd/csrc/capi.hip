@@ -517,6 +517,8 @@ int sprs_csr_destroy(sprs_csr *A) {
         if (A->dist->ag_buf) (void)hipFree(A->dist->ag_buf);
         if (A->dist->order_int) (void)hipFree(A->dist->order_int);
         if (A->dist->order_bnd) (void)hipFree(A->dist->order_bnd);
+        if (A->dist->order_int_w) (void)hipFree(A->dist->order_int_w);
+        if (A->dist->order_bnd_w) (void)hipFree(A->dist->order_bnd_w);
         if (A->dist->ev_pack) (void)hipEventDestroy(A->dist->ev_pack);
         if (A->dist->ev_halo) (void)hipEventDestroy(A->dist->ev_halo);
         if (A->dist->comm_stream) (void)hipStreamDestroy(A->dist->comm_stream);

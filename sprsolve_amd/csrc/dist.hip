@@ -236,12 +236,32 @@ int dist_csr_create(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz
         std::vector<int32_t> lo, hi;
         st = rowblk_spans(A, lo, hi);
         if (st != SPRS_OK) { sprs_csr_destroy(A); return st; }
-        std::vector<int32_t> oi, ob;
-        for (int b = 0; b < A->n_rowblk; ++b) (hi[b] >= n_local ? ob : oi).push_back(b);
+        std::vector<int32_t> oi, ob, oiw, obw;
+        const bool wide = A->dict && A->dict->wide_desc && !A->blk_order;
+        if (wide) {
+            // classify PAIRS of consecutive 64-row blocks (= the 128-row blocks of the two-rows-per-lane kernel) so
+            // that both kernels can run the same split: a pair is boundary if either half reads the halo
+            for (int j = 0; 2 * j < A->n_rowblk; ++j) {
+                const int b0 = 2 * j, b1 = std::min(2 * j + 1, A->n_rowblk - 1);
+                const bool bnd = hi[b0] >= n_local || hi[b1] >= n_local;
+                (bnd ? obw : oiw).push_back(j);
+                for (int b = b0; b <= b1; ++b) (bnd ? ob : oi).push_back(b);
+            }
+        } else {
+            for (int b = 0; b < A->n_rowblk; ++b) (hi[b] >= n_local ? ob : oi).push_back(b);
+        }
         if (!oi.empty() && !ob.empty() && ob.size() * 2 <= (size_t)A->n_rowblk) {
             // keep the XCD-period placement of the local operator for the (large) interior launch
             if (A->blk_order && !A->sched_strip_major && A->sched_period > 0 && !A->blk_row_start.empty())
                 oi = place_on_xcds(oi, A->blk_row_start, A->sched_period);
+            if (wide) {
+                bool okw = hipMalloc((void **)&D->order_int_w, sizeof(int32_t) * oiw.size()) == hipSuccess &&
+                           hipMalloc((void **)&D->order_bnd_w, sizeof(int32_t) * obw.size()) == hipSuccess &&
+                           hipMemcpy(D->order_int_w, oiw.data(), sizeof(int32_t) * oiw.size(), hipMemcpyHostToDevice) == hipSuccess &&
+                           hipMemcpy(D->order_bnd_w, obw.data(), sizeof(int32_t) * obw.size(), hipMemcpyHostToDevice) == hipSuccess;
+                if (!okw) { sprs_csr_destroy(A); return SPRS_ERR_HIP; }
+                D->n_int_w = (int32_t)oiw.size(); D->n_bnd_w = (int32_t)obw.size();
+            }
             bool ok = hipMalloc((void **)&D->order_int, sizeof(int32_t) * oi.size()) == hipSuccess &&
                       hipMalloc((void **)&D->order_bnd, sizeof(int32_t) * ob.size()) == hipSuccess &&
                       hipMemcpy(D->order_int, oi.data(), sizeof(int32_t) * oi.size(), hipMemcpyHostToDevice) == hipSuccess &&

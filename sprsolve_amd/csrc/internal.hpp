@@ -92,6 +92,9 @@ struct sprs_dist_info {
     // overlap of the halo exchange with the SpMV of the rows that need no halo entry
     int32_t *order_int = nullptr, *order_bnd = nullptr;   // device: interior / boundary row blocks
     int32_t n_int = 0, n_bnd = 0;
+    // the same split in units of the 128-row blocks of the two-rows-per-lane kernel (null when it does not apply)
+    int32_t *order_int_w = nullptr, *order_bnd_w = nullptr;
+    int32_t n_int_w = 0, n_bnd_w = 0;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
 };

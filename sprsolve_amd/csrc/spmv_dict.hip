@@ -377,6 +377,7 @@ struct Blk2Loads {
 
 template <int DOT>
 __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_chunk, const BlkDesc *__restrict__ desc,
+                                                           const int32_t *__restrict__ order,
                                                            const int32_t *__restrict__ row_ptr,
                                                            const uint8_t *__restrict__ code,
                                                            const int32_t *__restrict__ off_tab,
@@ -415,10 +416,14 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
 
     typedef int v4i __attribute__((ext_vector_type(4)));
     typedef const v4i __attribute__((address_space(1))) *gv4i_p;
-    uintptr_t desc_a = reinterpret_cast<uintptr_t>(desc);
+    typedef const int32_t __attribute__((address_space(1))) *gi32_p;
+    uintptr_t desc_a = reinterpret_cast<uintptr_t>(desc), order_a = reinterpret_cast<uintptr_t>(order);
     asm volatile("" : "+v"(desc_a));                // vector (in-order) descriptor loads, as in spmv_dict_kernel
+    asm volatile("" : "+v"(order_a));
     const gv4i_p desc_v = reinterpret_cast<gv4i_p>(desc_a);
+    const gi32_p order_v = reinterpret_cast<gi32_p>(order_a);
     auto load_desc = [&](int bi) -> BlkDesc { const v4i q = desc_v[bi]; return BlkDesc{q.x, q.y, q.z, q.w}; };
+    auto block_index = [&](int bi) -> int { return order ? order_v[bi] : bi; };
     auto uniform = [&](const BlkDesc &d) -> BlkDesc {
         return BlkDesc{__builtin_amdgcn_readfirstlane(d.ra), __builtin_amdgcn_readfirstlane(d.rb),
                        __builtin_amdgcn_readfirstlane(d.pa), __builtin_amdgcn_readfirstlane(d.nn)};
@@ -460,17 +465,21 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
     };
 
     BlkDesc dn{0, 1, 0, 0};
+    int o2 = 0;
     if (b < bend) {
         Blk2Loads first;
-        issue(uniform(load_desc(b)), first);
-        if (b + bstep < bend) dn = uniform(load_desc(b + bstep));
+        issue(uniform(load_desc(__builtin_amdgcn_readfirstlane(block_index(b)))), first);
+        if (b + bstep < bend) dn = uniform(load_desc(__builtin_amdgcn_readfirstlane(block_index(b + bstep))));
+        if (b + 2 * bstep < bend) o2 = __builtin_amdgcn_readfirstlane(block_index(b + 2 * bstep));
         stage(first);
     }
     for (; b < bend; b += bstep) {
         const bool more = b + bstep < bend;
         Blk2Loads nxt;
         BlkDesc dn2{0, 1, 0, 0};
-        if (b + 2 * bstep < bend) dn2 = load_desc(b + 2 * bstep);
+        int o3 = 0;
+        if (b + 2 * bstep < bend) dn2 = load_desc(o2);
+        if (b + 3 * bstep < bend) o3 = block_index(b + 3 * bstep);
         if (more) issue(dn, nxt);
         wave_lds_fence();
         const int r0 = c_ra + 2 * lane;
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
         }
         wave_lds_fence();
         if (more) stage(nxt);
-        dn = uniform(dn2);
+        dn = uniform(dn2); o2 = __builtin_amdgcn_readfirstlane(o3);
     }
     if (DOT >= 1) {
         d0 = block_sum(d0, red);
@@ -729,13 +738,19 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
     const T *pv = reinterpret_cast<const T *>(D->pair_val);
     const bool pair = has_val_dict<T>::value && mode == 2;
     if constexpr (sizeof(T) == 8 && !is_complex<T>::value) {
-        // the whole matrix in natural order, f64 pair codes: two rows per lane (the subset launches of the
-        // distributed operator keep the 64-row kernel: their schedules are lists of 64-row blocks)
-        if (pair && D->wide_desc && c->spmv_wide != 0 && order == nullptr && count == A->n_rowblk && A->nrows >= 2 && A->ncols >= 2) {
+        // f64 pair codes: two rows per lane
+        // ... on the whole matrix in natural order, or on the interior / boundary subsets of a distributed operator,
+        // whose split is made on pairs of 64-row blocks for this purpose (dist.hip)
+        const int32_t *order_w = nullptr;
+        int count_w = -1;
+        if (order == nullptr && count == A->n_rowblk) count_w = D->n_wide;
+        else if (A->dist && A->dist->order_int_w && order == A->dist->order_int && count == A->dist->n_int) { order_w = A->dist->order_int_w; count_w = A->dist->n_int_w; }
+        else if (A->dist && A->dist->order_bnd_w && order == A->dist->order_bnd && count == A->dist->n_bnd) { order_w = A->dist->order_bnd_w; count_w = A->dist->n_bnd_w; }
+        if (pair && D->wide_desc && c->spmv_wide != 0 && count_w >= 0 && A->nrows >= 2 && A->ncols >= 2) {
             const int gw = g;     // same grid as the 64-row kernel: the consumers reduce exactly spmv_num_partials(A) partials
             const BlkDesc *wd = reinterpret_cast<const BlkDesc *>(D->wide_desc);
             const double *pvd = reinterpret_cast<const double *>(D->pair_val);
-#define SPRS_WSPMV(DM) hipLaunchKernelGGL((spmv_pair2_kernel<DM>), dim3(gw), dim3(BLOCK), 0, c->stream, D->n_wide, xcd_chunk, wd, \
+#define SPRS_WSPMV(DM) hipLaunchKernelGGL((spmv_pair2_kernel<DM>), dim3(gw), dim3(BLOCK), 0, c->stream, count_w, xcd_chunk, wd, order_w, \
                                           A->row_ptr, D->pair_code, D->pair_off, pvd, x, y, u, part0, part1, status, (int)A->nrows, (int)A->ncols)
             if (dot_mode == 0) SPRS_WSPMV(0); else if (dot_mode == 1) SPRS_WSPMV(1); else SPRS_WSPMV(2);
 #undef SPRS_WSPMV

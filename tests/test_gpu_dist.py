@@ -38,6 +38,40 @@ def _self_halo_plan(torch, dev, n, indices, remote_mask_fn, segments=1):
                 send_off=off, send_idx=cols.astype(np.int32), recv_off=off)
 
 
+@pytest.mark.parametrize("with_halo", ["scattered", "tail-overlapped", "tail-no-overlap"])
+def test_dist_operator_wide_kernel(env, oracle, with_halo):
+    """The same distributed SpMV with the two-rows-per-lane kernel on the interior / boundary subsets (split made on
+    pairs of 64-row blocks): y bit-identical to the reference fold; the solve agrees with the oracle."""
+    torch, sa, sdist, dev = env["torch"], env["sa"], env["sdist"], env["dev"]
+    from sprsolve_amd import gen
+    R = 96
+    indptr, indices, data = gen.grid_laplacian_dirichlet(R, R)
+    rhs = gen.dirichlet_rhs(R, R)
+    n = R * R
+    mask = {"scattered": lambda c: (c % 7 == 3) | (c > n - 2 * R)}.get(with_halo, lambda c: c > n - 3 * R)
+    plan = _self_halo_plan(torch, dev, n, indices, mask)
+    env["ctx"].set("halo_overlap", 0 if with_halo == "tail-no-overlap" else 1)
+    env["ctx"].set("spmv_wide", 1)
+    ip_d = torch.from_numpy(indptr).to(dev); dv_d = torch.from_numpy(data).to(dev)
+    A = sdist.DistCsr.from_plan(env["comm"], plan, int(indptr[-1]), ip_d, dv_d, adopt=True,
+                                to_device=lambda a: torch.from_numpy(a).to(dev))
+    if with_halo != "scattered":
+        assert A.stream_format()[0] == 2          # few (offset, value) pairs survive the halo renumbering
+    x = np.linspace(-1, 1, n) ** 3
+    x_ext = torch.zeros(plan["n_ext"], dtype=torch.float64, device=dev)
+    x_ext[:n] = torch.from_numpy(x).to(dev)
+    x_ext[n:] = float("nan")
+    y = torch.empty(n, dtype=torch.float64, device=dev)
+    A.mul_vec_ext(x_ext, y)
+    ref = oracle.spmv(indptr, indices, data, x)
+    assert np.array_equal(y.cpu().numpy().view(np.uint64), ref.view(np.uint64))
+    xs = torch.zeros(n, dtype=torch.float64, device=dev)
+    its, res = sa.BiCGStab.new(A, n).solve(torch.from_numpy(rhs).to(dev), xs, 5000, 1e-10)
+    i, j = np.meshgrid(np.arange(R), np.arange(R), indexing="ij")
+    assert np.max(np.abs(xs.cpu().numpy() - (i + j).ravel())) < 1e-6
+    env["ctx"].set("spmv_wide", -1)
+
+
 @pytest.mark.parametrize("with_halo", ["none", "scattered", "tail-overlapped", "tail-2-segments", "tail-no-overlap"])
 def test_dist_operator_equals_plain(env, oracle, with_halo):
     torch, sa, sdist, dev = env["torch"], env["sa"], env["sdist"], env["dev"]
