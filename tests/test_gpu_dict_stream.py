@@ -304,3 +304,39 @@ def test_wide_kernel_solve(sa, oracle):
         out[wide] = (sa.BiCGStab.new(A, n).solve(rhs, x, 500, 1e-10), x)
     assert abs(out[0][0][0] - out[1][0][0]) <= 2
     assert np.max(np.abs(out[1][1] - 1.0)) < 1e-7
+
+
+def test_fuzz_small_matrices(sa, oracle):
+    """200 small random matrices (1..300 rows, banded patterns with a handful of offsets and values so that the
+    pair-code stream and the two-rows-per-lane kernel are taken, empty rows, single rows, odd sizes): y bit-identical
+    to the reference fold on every stream / kernel."""
+    rng = np.random.default_rng(2026)
+    ctx = sa.default_ctx(0)
+    vals = np.array([1.0, -1.0, 0.5, 2.0, -3.25])
+    for trial in range(200):
+        n = int(rng.integers(1, 301))
+        offs = np.unique(rng.integers(-min(n - 1, 9), min(n - 1, 9) + 1, size=int(rng.integers(1, 8))))
+        keep_p = rng.uniform(0.3, 1.0)
+        rows = []
+        for r in range(n):
+            c = r + offs
+            c = c[(c >= 0) & (c < n)]
+            c = c[rng.uniform(size=c.size) < keep_p] if rng.uniform() < 0.7 else c
+            rows.append(c)
+        indptr = np.zeros(n + 1, dtype=np.int32); np.cumsum([len(c) for c in rows], out=indptr[1:])
+        if indptr[-1] == 0:
+            continue
+        cols = np.concatenate(rows).astype(np.int32)
+        data = vals[rng.integers(0, vals.size, cols.size)]
+        x = rng.uniform(-1, 1, n)
+        ref = oracle.spmv(indptr, cols, data, x)
+        for knob, wide in ((0, 0), (1, 0), (2, 0), (2, 1)):
+            ctx.set("spmv_dict", knob); ctx.set("spmv_wide", wide)
+            A = sa.HipCsr.new((n, n), indptr, cols, data)
+            y = np.full(n, 7.0)
+            A.mul_vec(x, y)
+            assert np.array_equal(bits(y), bits(ref)), (trial, n, knob, wide, A.stream_format())
+            y2 = np.zeros(n)
+            d = A.mul_vec_dot(x, y2)
+            assert np.array_equal(bits(y2), bits(ref))
+            assert abs(d - float(np.dot(x, ref))) <= 1e-12 * max(1.0, float(np.sum(np.abs(x * ref))))
