@@ -340,3 +340,42 @@ def test_fuzz_small_matrices(sa, oracle):
             d = A.mul_vec_dot(x, y2)
             assert np.array_equal(bits(y2), bits(ref))
             assert abs(d - float(np.dot(x, ref))) <= 1e-12 * max(1.0, float(np.sum(np.abs(x * ref))))
+
+
+def test_dictionary_limits(sa, oracle):
+    """Exactly 256 distinct offsets still compress, 257 fall back to the plain stream; a value whose bit pattern is the
+    collector's EMPTY marker (all ones, a NaN) disables the value dictionary instead of being mis-keyed."""
+    ctx = sa.default_ctx(0)
+    ctx.set("spmv_dict", 2)
+    n = 4000
+    for n_off, want in ((256, True), (257, False)):
+        rows = np.arange(n)
+        offs = np.arange(n_off) - n_off // 2
+        # row r holds the 3 offsets (r, r+1, r+2) mod n_off: every offset occurs, each row is short
+        cols = rows[:, None] + offs[(rows[:, None] + np.arange(3)[None, :]) % n_off]
+        cols = np.sort(np.clip(cols, 0, n - 1), axis=1)
+        keep = np.concatenate([np.ones((n, 1), bool), cols[:, 1:] != cols[:, :-1]], axis=1)      # drop clipped duplicates
+        indptr = np.zeros(n + 1, dtype=np.int32); np.cumsum(keep.sum(axis=1), out=indptr[1:])
+        ci = cols[keep].astype(np.int32)
+        data = np.ones(ci.size)
+        got_offs = np.unique(ci - np.repeat(rows, keep.sum(axis=1))).size
+        A = sa.HipCsr.new((n, n), indptr, ci, data)
+        mode, no, npair = A.stream_format()
+        assert (mode != 0) == (got_offs <= 256), (n_off, got_offs, mode)
+        x = rand_vec(n, np.float64, 1); y = np.zeros(n)
+        A.mul_vec(x, y)
+        assert np.array_equal(bits(y), bits(oracle.spmv(indptr, ci, data, x)))
+    # the all-ones NaN
+    n = 64
+    indptr = np.arange(0, 2 * n + 1, 2, dtype=np.int32)
+    ci = np.stack([np.arange(n), (np.arange(n) + 1) % n], axis=1); ci.sort(axis=1)
+    data = np.tile(np.array([1.5, -2.0]), n)
+    data[7] = np.frombuffer(np.uint64(0xFFFFFFFFFFFFFFFF).tobytes(), dtype=np.float64)[0]
+    A = sa.HipCsr.new((n, n), indptr, ci.ravel().astype(np.int32), data)
+    assert A.stream_format()[0] == 1            # offsets compress, values do not
+    x = rand_vec(n, np.float64, 2); y = np.zeros(n)
+    A.mul_vec(x, y)
+    ctx.set("spmv_dict", 0)
+    B = sa.HipCsr.new((n, n), indptr, ci.ravel().astype(np.int32), data)
+    y0 = np.zeros(n); B.mul_vec(x, y0)
+    assert np.array_equal(bits(y), bits(y0))
