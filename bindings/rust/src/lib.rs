@@ -51,6 +51,7 @@ pub mod sys {
         pub fn sprs_csr_create_i64_z(ctx: *mut sprs_ctx, nrows: i64, ncols: i64, nnz: i64, row_ptr: *const i64,
             col_idx: *const i64, val: *const Complex64, storage_csc: c_int, out: *mut *mut sprs_csr) -> c_int;
         pub fn sprs_csr_destroy(a: *mut sprs_csr) -> c_int;
+        pub fn sprs_csr_stream_format(a: *const sprs_csr, n_offsets: *mut c_int, n_pairs: *mut c_int) -> c_int;
 
         pub fn sprs_mul_vec_d(a: *const sprs_csr, x: *const f64, x_len: usize, y: *mut f64, y_len: usize) -> c_int;
         pub fn sprs_mul_vec_z(a: *const sprs_csr, x: *const Complex64, x_len: usize, y: *mut Complex64, y_len: usize) -> c_int;
@@ -166,6 +167,13 @@ impl<T: HipScalar> HipCsr<T> {
     }
     pub fn rows(&self) -> usize { self.size.0 }
     pub fn cols(&self) -> usize { self.size.1 }
+    /// Which stream the SpMV reads: (0 plain CSR | 1 offset codes | 2 pair codes, distinct offsets, distinct pairs).
+    /// Backend detail (csrc/spmv_dict.hip); y is bit-identical in all three.
+    pub fn stream_format(&self) -> (i32, i32, i32) {
+        let (mut no, mut np) = (0 as c_int, 0 as c_int);
+        let m = unsafe { sys::sprs_csr_stream_format(self.handle, &mut no, &mut np) };
+        (m, no, np)
+    }
     pub(crate) fn raw(&self) -> *const sys::sprs_csr { self.handle }
     pub(crate) fn ctx(&self) -> *mut sys::sprs_ctx { self.ctx }
 }
