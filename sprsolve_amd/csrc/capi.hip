@@ -107,6 +107,7 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     else if (k == "spmv_strip") c->spmv_strip = (int)value;
     else if (k == "spmv_dict") { if (value < -1 || value > 2) return SPRS_INVALID_ARGUMENT; c->spmv_dict = (int)value; }
     else if (k == "spmv_wide") c->spmv_wide = value < 0 ? -1 : (value ? 1 : 0);
+    else if (k == "spmv_uniform") c->spmv_uniform = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "halo_overlap") c->halo_overlap = value ? 1 : 0;
     else if (k == "gs_graph") c->gs_graph = value ? 1 : 0;
     else if (k == "poll") { if (value < 1) return SPRS_INVALID_ARGUMENT; c->poll = (int)value; }
@@ -123,6 +124,7 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     if (k == "spmv_strip") return c->spmv_strip;
     if (k == "spmv_dict") return c->spmv_dict;
     if (k == "spmv_wide") return c->spmv_wide;
+    if (k == "spmv_uniform") return c->spmv_uniform;
     if (k == "halo_overlap") return c->halo_overlap;
     if (k == "gs_graph") return c->gs_graph;
     if (k == "poll") return c->poll;

@@ -42,6 +42,7 @@ struct sprs_ctx {
     // 1 offset codes + values, 2 (offset, value) pair codes.  Read at handle creation (what is built) and at launch (what is used).
     int spmv_dict = -1;
     int spmv_wide = -1;   // f64 pair codes: two rows per lane (16-byte gathers); -1 / 1 on, 0 off
+    int spmv_uniform = -1; // ... and blocks whose rows all repeat one code sequence read neither codes nor row_ptr; read at creation
     int halo_overlap = 1;  // distributed SpMV: run the halo-free rows while the halo travels
     int gs_graph = 0;    // Gauss-Seidel: 1 = replay a sweep's level launches from a hipGraph (measured: no gain, r01_tuning.md)
     int poll = 16;       // iterations between host polls of the device status word

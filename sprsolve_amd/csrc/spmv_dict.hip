@@ -367,8 +367,36 @@ typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 constexpr int CAP2 = 2 * nnz_cap<double>::value;          // 1024 code bytes per wide block
 constexpr int CW2 = (CAP2 + 3 + CPAD + 15) / 16 * 4;      // dwords of a wavefront's slice (multiple of 4: b128 stores)
 
+constexpr uint32_t UNI2 = 0x40000000u;     // wide descriptor, rb bit 30: every row of the block has the SAME code sequence
+constexpr int UNI2_MAXLEN = 8;              // ... of at most this many codes; the descriptor's nn then holds that length
+
+// One wavefront per 128-row block: are all its rows copies of the first one (same length, same codes)?  Interior
+// rows of a constant-coefficient stencil are; such a block needs neither its 1 KiB of codes nor row_ptr — the
+// pattern is read once per block from the first row (spmv_pair2_kernel, uniform path).
+__global__ __launch_bounds__(BLOCK) void mark_uniform_kernel(int n_wide, BlkDesc *__restrict__ desc,
+                                                             const int32_t *__restrict__ row_ptr,
+                                                             const uint8_t *__restrict__ code) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (int b = blockIdx.x * NWAVE + (threadIdx.x >> 6); b < n_wide; b += gridDim.x * NWAVE) {
+        const BlkDesc d = desc[b];
+        const int nr = d.rb - d.ra;
+        const int L0 = row_ptr[d.ra + 1] - row_ptr[d.ra];
+        bool ok = nr >= 1 && L0 >= 1 && L0 <= UNI2_MAXLEN && d.nn == nr * L0;
+        if (ok) {
+            for (int r = d.ra + lane; r < d.rb; r += WAVE) {
+                const int s = row_ptr[r];
+                ok = ok && s == d.pa + (r - d.ra) * L0;             // with nn == nr * L0: every row has L0 entries
+                for (int j = 0; ok && j < L0; ++j) ok = code[s + j] == code[d.pa + j];
+            }
+        }
+        const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+        if (all_ok && lane == 0) desc[b] = BlkDesc{d.ra, (int32_t)((uint32_t)d.rb | UNI2), d.pa, L0};
+    }
+}
+
 struct Blk2Loads {
     int ra, rb, pa, nn;      // descriptor of the 128-row block
+    bool uni; int ulen;      // uniform block (every row = the first row's ulen codes)
     int a, b;                // row_ptr[i0], row_ptr[i0 + 1], i0 = min(ra + 2 lane, rb - 1)
     double u0, u1;           // dot operands of the lane's two rows
     u4v wc;                  // 16 code bytes
@@ -429,11 +457,17 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
                        __builtin_amdgcn_readfirstlane(d.pa), __builtin_amdgcn_readfirstlane(d.nn)};
     };
     auto issue = [&](const BlkDesc &d, Blk2Loads &L) {
-        L.ra = d.ra; L.rb = d.rb; L.pa = d.pa; L.nn = d.nn;
+        L.uni = ((uint32_t)d.rb & UNI2) != 0;                                   // scalar: all rows share one code sequence of d.nn codes
+        L.ra = d.ra; L.rb = (int)((uint32_t)d.rb & ~UNI2); L.pa = d.pa;
+        L.nn = L.uni ? d.nn * (L.rb - L.ra) : d.nn;
+        L.ulen = L.uni ? d.nn : 0;
         const int r0 = L.ra + 2 * lane;
-        const int i0 = min(r0, L.rb - 1);                                       // row_ptr[i0 + 1] exists: i0 + 1 <= rb <= nrows
-        const int2 ab = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(row_ptr) + (uint32_t)i0 * 4u);
-        L.a = ab.x; L.b = ab.y;
+        L.a = 0; L.b = 0;
+        if (!L.uni) {                                                           // a uniform block needs no row_ptr
+            const int i0 = min(r0, L.rb - 1);                                   // row_ptr[i0 + 1] exists: i0 + 1 <= rb <= nrows
+            const int2 ab = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(row_ptr) + (uint32_t)i0 * 4u);
+            L.a = ab.x; L.b = ab.y;
+        }
         if (DOT != 0) {
             const int p0 = min(r0, nrows - 2);                                  // the pair (u[p0], u[p0 + 1]) is inside u
             const D2 uu = *reinterpret_cast<const D2 *>(reinterpret_cast<const char *>(u) + (uint32_t)p0 * 8u);
@@ -441,14 +475,30 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
             L.u1 = uu.hi;
         }
         const int shift = L.pa & 3;
-        const int nq = max((shift + L.nn + 15) >> 4, 1);                        // 16-byte pieces covering the codes, <= 65
+        const int nq = L.uni ? 1 : max((shift + L.nn + 15) >> 4, 1);            // 16-byte pieces covering the codes, <= 65 (uniform: the first row's only)
         L.di = min(lane, nq - 1);
         L.wc = *reinterpret_cast<const u4v *>(reinterpret_cast<const char *>(code) + (uint32_t)(L.pa - shift + 16 * L.di));
     };
     int c_ra = 0, c_rb = 0, c_shift = 0, c_s0 = 0, c_s1 = 0, c_len0 = 0, c_len1 = 0;
+    bool c_uni = false;
+    uint64_t c_pat = 0;      // uniform block: its (at most 8) codes, first code in the low byte
     T c_u0 = 0.0, c_u1 = 0.0;
     auto stage = [&](const Blk2Loads &L) {
         const int shift = L.pa & 3;
+        c_uni = L.uni;
+        if (L.uni) {
+            // every lane holds the same 16 bytes [pa - shift, pa - shift + 16): the pattern starts `shift` bytes in
+            const uint64_t lo = (uint64_t)__builtin_amdgcn_readfirstlane(L.wc.x) | ((uint64_t)__builtin_amdgcn_readfirstlane(L.wc.y) << 32);
+            const uint64_t hi = (uint64_t)__builtin_amdgcn_readfirstlane(L.wc.z);
+            c_pat = shift ? (lo >> (8 * shift)) | (hi << (64 - 8 * shift)) : lo;
+            const int r0 = L.ra + 2 * lane;
+            c_ra = L.ra; c_rb = L.rb; c_shift = shift;
+            c_s0 = 0; c_s1 = 0;
+            c_len0 = r0 < L.rb ? L.ulen : 0;
+            c_len1 = r0 + 1 < L.rb ? L.ulen : 0;
+            if (DOT != 0) { c_u0 = L.u0; c_u1 = L.u1; }
+            return;
+        }
         if (L.nn > 0) {
             *reinterpret_cast<u4v *>(&s_c[wv][4 * L.di]) = L.wc;               // clamped duplicates store the same 16 bytes
             if (shift + L.nn > CAP2 && lane == 0)                               // the 65th piece exists only then: one dword is enough
@@ -486,6 +536,33 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
         const uint32_t r8 = (uint32_t)r0 * 8u;
         const int len0 = c_len0, len1 = c_len1, lenm = max(len0, len1);
         T acc0 = 0.0, acc1 = 0.0;
+        if (c_uni) {
+            // ---- uniform block: the pattern is scalar.  Per slot one LDS read of {offset, value} at a wave-uniform
+            // address, one 16-byte gather for the lane's two rows, two multiply-adds; no codes, no row_ptr.
+            const int ulen = __builtin_amdgcn_readfirstlane(lenm);             // == the block's row length (lane 0 always has a row)
+            T pl[8], ph[8], av[8];
+            uint32_t hi_bits = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; av[t] = 0.0; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t >= ulen) break;
+                const PairEnt<T> e = s_pair[(int)((c_pat >> (8 * t)) & 255u)];
+                av[t] = e.val;
+                const uint32_t vo0 = len0 > 0 ? r8 + (uint32_t)e.off8 : 0u;
+                const uint32_t vp = min(vo0, xlast_pair);                       // only a single-row lane at the matrix end is ever clamped
+                hi_bits |= (vo0 != vp ? 1u : 0u) << t;
+                const D2 px = *reinterpret_cast<const D2 *>(xbytes + vp);
+                pl[t] = px.lo; ph[t] = px.hi;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t >= ulen) break;
+                if (len0 > 0) acc0 = acc0 + (((hi_bits >> t) & 1u) ? ph[t] : pl[t]) * av[t];
+                if (len1 > 0) acc1 = acc1 + ph[t] * av[t];
+            }
+        } else
         for (int j0 = 0; __builtin_amdgcn_ballot_w64(j0 < lenm) != 0; j0 += 8) {
             const uint8_t *cp0 = cb + c_shift + min(c_s0 + j0, CAP2);
             const uint8_t *cp1 = cb + c_shift + min(c_s1 + j0, CAP2);
@@ -680,6 +757,12 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
                 }
                 DICT_TRY2(hipMalloc(&D->wide_desc, sizeof(BlkDescHost2) * (size_t)std::max(nw, 1)));
                 DICT_TRY2(hipMemcpyAsync(D->wide_desc, wd.data(), sizeof(BlkDescHost2) * (size_t)nw, hipMemcpyHostToDevice, c->stream));
+                if (c->spmv_uniform != 0 && nw > 0) {
+                    const int gu = std::max(1, std::min(c->num_cu * 8, (nw + NWAVE - 1) / NWAVE));
+                    hipLaunchKernelGGL(mark_uniform_kernel, dim3(gu), dim3(BLOCK), 0, c->stream, nw,
+                                       reinterpret_cast<BlkDesc *>(D->wide_desc), A->row_ptr, D->pair_code);
+                    DICT_TRY2(hipGetLastError());
+                }
                 DICT_TRY2(hipStreamSynchronize(c->stream));
                 D->n_wide = nw;
             }
