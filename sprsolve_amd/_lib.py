@@ -119,6 +119,7 @@ def _protos():
         P["sprs_dist_mul_vec_dev_" + s] = [_vp, _vp, _vp]
         P["sprs_dist_csr_create_allgather_dev_" + s] = [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _pp]
     P["sprs_csr_stream_format"] = [_vp, C.POINTER(_int), C.POINTER(_int)]
+    P["sprs_csr_wide_blocks"] = [_vp, C.POINTER(_i64), C.POINTER(_i64)]
     P["sprs_gauss_seidel_create"] = [_vp, _pp]
     P["sprs_gauss_seidel_destroy"] = [_vp]
     for s in ("d", "s"):

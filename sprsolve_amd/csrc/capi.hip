@@ -532,6 +532,19 @@ int sprs_csr_destroy(sprs_csr *A) {
 int64_t sprs_csr_rows(const sprs_csr *A) { return A ? A->nrows : -1; }
 int64_t sprs_csr_cols(const sprs_csr *A) { return A ? A->ncols : -1; }
 int64_t sprs_csr_nnz(const sprs_csr *A) { return A ? A->nnz : -1; }
+int sprs_csr_wide_blocks(const sprs_csr *A, int64_t *n_blocks, int64_t *n_uniform) {
+    if (!A || !n_blocks || !n_uniform) return SPRS_INVALID_ARGUMENT;
+    *n_blocks = 0; *n_uniform = 0;
+    if (!A->dict || !A->dict->wide_desc || A->dict->n_wide == 0) return SPRS_OK;
+    sprs_ctx *c = A->ctx;
+    std::vector<int32_t> d((size_t)A->dict->n_wide * 4);
+    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    SPRS_HIP_TRY(c, hipMemcpyAsync(d.data(), A->dict->wide_desc, d.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_blocks = A->dict->n_wide;
+    for (int64_t j = 0; j < A->dict->n_wide; ++j) *n_uniform += ((uint32_t)d[(size_t)j * 4 + 1] & 0x40000000u) != 0;
+    return SPRS_OK;
+}
 int sprs_csr_stream_format(const sprs_csr *A, int *n_offsets, int *n_values) {
     if (!A) return -1;
     if (n_offsets) *n_offsets = A->dict ? A->dict->n_off : 0;

@@ -98,6 +98,12 @@ class HipCsr(MatVecMul):
         m = _lib.lib().sprs_csr_stream_format(self.h, C.byref(no), C.byref(nv))
         return int(m), no.value, nv.value
 
+    def wide_blocks(self):
+        """(n_blocks, n_uniform) of the two-rows-per-lane kernel's 128-row blocks (f64 pair codes), else (0, 0)."""
+        nb, nu = C.c_int64(0), C.c_int64(0)
+        check(_lib.lib().sprs_csr_wide_blocks(self.h, C.byref(nb), C.byref(nu)), self.ctx.h)
+        return nb.value, nu.value
+
     # -------------------------------------------------------------- MatVecMul
     def _s(self):
         return sfx(self.dtype)

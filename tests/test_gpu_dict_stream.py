@@ -379,3 +379,48 @@ def test_dictionary_limits(sa, oracle):
     B = sa.HipCsr.new((n, n), indptr, ci.ravel().astype(np.int32), data)
     y0 = np.zeros(n); B.mul_vec(x, y0)
     assert np.array_equal(bits(y), bits(y0))
+
+
+@pytest.mark.parametrize("kind", ["tridiagonal", "poisson3d_long_lines", "poisson2d"])
+def test_uniform_blocks(sa, oracle, kind):
+    """Blocks whose rows all repeat one code sequence are multiplied from a scalar pattern (no codes, no row_ptr):
+    the flag is found where it should be, and y is bit-identical with and without that path."""
+    from sprsolve_amd import gen
+    ctx = sa.default_ctx(0)
+    if kind == "tridiagonal":
+        n = 5001
+        indptr = np.zeros(n + 1, dtype=np.int32)
+        lens = np.full(n, 3); lens[0] = lens[-1] = 2
+        np.cumsum(lens, out=indptr[1:])
+        cols = np.concatenate([[0, 1]] + [[i - 1, i, i + 1] for i in range(1, n - 1)] + [[n - 2, n - 1]]).astype(np.int32)
+        data = np.tile(np.array([-1.0, 2.0, -1.0]), n)[1:-1].copy()
+        expect_uniform = (n - 2) // 128 - 1            # at least: every block strictly inside the interior run
+    elif kind == "poisson3d_long_lines":
+        indptr, cols, data, _ = gen.poisson3d(300, 4, 3)
+        n = indptr.size - 1
+        expect_uniform = 4 * 3                          # >= one fully interior 128-row block per 300-row line
+    else:
+        indptr, cols, data = gen.grid_laplacian_dirichlet(200, 200)
+        n = 200 * 200
+        expect_uniform = 90                             # interior rows come in runs of 198 between the Dirichlet rows: ~1 block in 3
+    x = rand_vec(n, np.float64, 17)
+    ref = oracle.spmv(indptr, cols, data, x)
+    ys = {}
+    for uni in (1, 0):
+        ctx.set("spmv_uniform", uni)
+        A = sa.HipCsr.new((n, n), indptr, cols, data)
+        assert A.stream_format()[0] == 2
+        nb, nu = A.wide_blocks()
+        assert nb == (n + 127) // 128
+        if uni:
+            assert expect_uniform <= nu < nb, (nb, nu)
+        else:
+            assert nu == 0
+        y = np.full(n, 4.0)
+        A.mul_vec(x, y)
+        assert np.array_equal(bits(y), bits(ref)), (kind, uni)
+        y2 = np.zeros(n)
+        ys[uni] = A.mul_vec_dot(x, y2)
+        assert np.array_equal(bits(y2), bits(ref))
+    assert ys[0] == ys[1]           # same kernel, same lane/row grouping: even the fused dot is identical
+    ctx.set("spmv_uniform", -1)
