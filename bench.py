@@ -319,7 +319,8 @@ def main():
                 traffic, traffic_note = pm["traffic_bytes"], "profiles/r01_pmc_summary.json[%s]: %s" % (pmc_key, pm["note"])
         kernel = {0: "spmv_kernel<double> (plain CSR stream, LDS product path, fused dot epilogue)",
                   1: "spmv_dict_kernel<double, PAIR=false> (one-byte column-offset codes + values)",
-                  2: "spmv_dict_kernel<double, PAIR=true> (one-byte (offset, value) pair codes)"}[sinfo["mode"]]
+                  2: "spmv_pair2_kernel<DOT> (one-byte (offset, value) pair codes, two rows per lane, uniform blocks from a "
+                     "scalar pattern; csrc/spmv_dict.hip)"}[sinfo["mode"]]
         fb = sinfo["format_bytes_per_launch"]          # per rank, like bs
         roof = dict(bound="hbm", kernel=kernel,
                     achieved=bs / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=bs / t_spmv / 1e9 / HBM_PEAK_GBS,
