@@ -542,7 +542,7 @@ int sprs_csr_wide_blocks(const sprs_csr *A, int64_t *n_blocks, int64_t *n_unifor
     SPRS_HIP_TRY(c, hipMemcpyAsync(d.data(), A->dict->wide_desc, d.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     *n_blocks = A->dict->n_wide;
-    for (int64_t j = 0; j < A->dict->n_wide; ++j) *n_uniform += ((uint32_t)d[(size_t)j * 4 + 1] & 0x40000000u) != 0;
+    for (int64_t j = 0; j < A->dict->n_wide; ++j) *n_uniform += ((uint32_t)d[(size_t)j * 4 + 1] & sprs::UNI2) != 0;
     return SPRS_OK;
 }
 int sprs_csr_stream_format(const sprs_csr *A, int *n_offsets, int *n_values) {

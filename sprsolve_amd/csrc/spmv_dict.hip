@@ -367,7 +367,6 @@ typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 constexpr int CAP2 = 2 * nnz_cap<double>::value;          // 1024 code bytes per wide block
 constexpr int CW2 = (CAP2 + 3 + CPAD + 15) / 16 * 4;      // dwords of a wavefront's slice (multiple of 4: b128 stores)
 
-constexpr uint32_t UNI2 = 0x40000000u;     // wide descriptor, rb bit 30: every row of the block has the SAME code sequence
 constexpr int UNI2_MAXLEN = 8;              // ... of at most this many codes; the descriptor's nn then holds that length
 
 // One wavefront per 128-row block: are all its rows copies of the first one (same length, same codes)?  Interior
