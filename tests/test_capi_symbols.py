@@ -74,3 +74,27 @@ def test_null_handles_are_rejected(L):
     out = C.c_void_p()
     assert L.sprs_bicgstab_create_d(None, 4, C.byref(out)) == 7
     assert L.sprs_mul_vec_dev_d(None, None, None) == 7
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/sprsolve_hip.h must compile as strict C99 (and as C++), and a C program must
+    link against the library with nothing but the header."""
+    import subprocess
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "sprsolve_hip.h"\n'
+                   'int main(void) {\n'
+                   '    sprs_ctx *ctx = 0; sprs_csr *a = 0; int no = 0, np = 0; size_t its = 0; double res = 0;\n'
+                   '    if (sprs_version() <= 0) return 2;\n'
+                   '    if (sprs_csr_stream_format(a, &no, &np) != -1) return 3;      /* null handle */\n'
+                   '    if (sprs_csr_destroy(a) != SPRS_OK || sprs_ctx_destroy(ctx) != SPRS_OK) return 4;\n'
+                   '    (void)its; (void)res;\n'
+                   '    return sprs_status_str(SPRS_BREAKDOWN) ? 0 : 5;\n'
+                   '}\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-c", str(src), "-o", str(tmp_path / "a.o")])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "b.o")])
+    libdir = os.path.join(ROOT, "sprsolve_amd")
+    exe = tmp_path / "use_header"
+    subprocess.check_call(["gcc", str(tmp_path / "a.o"), "-o", str(exe), "-L", libdir, "-l:libsprsolve_hip.so",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    assert subprocess.call([str(exe)]) == 0
