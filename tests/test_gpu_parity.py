@@ -687,3 +687,19 @@ def test_spmv_row_length_boundaries(sa, oracle, dtype):
     tol = RED_RTOL_F32 if is_single(dtype) else RED_RTOL
     absA = oracle.spmv(indptr, indices, np.abs(data).astype(dtype), np.abs(x).astype(dtype))
     assert np.all(np.abs(y[:m][~short] - ref[~short]) <= tol * np.abs(absA[~short]))
+
+
+def test_c_program_through_the_abi(tmp_path):
+    """examples/c_abi_demo.c: a plain C host builds the reference's bench matrix, solves it through the C ABI alone
+    (no Python, no torch in the process) and checks the known solution i + j."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_demo")
+    libdir = os.path.join(root, "sprsolve_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_abi_demo.c"), "-o", exe, "-L", libdir, "-l:libsprsolve_hip.so",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"])
+    out = subprocess.run([exe, "96"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "stream=2" in out.stdout and "max_err=" in out.stdout, out.stdout
