@@ -9,7 +9,8 @@
 // diagonal, so a row of an earlier level never sees a value the serial sweep would not have seen.
 // x after k sweeps is therefore BIT-IDENTICAL to the reference's; only the residual norm
 // (a reduction) differs in summation order.  A 3-D stencil of 50 M rows has ~1200 levels of up
-// to ~10^5 rows; a 2-D one has ~2n levels of <= n rows (little parallelism, still exact).
+// to ~10^5 rows; a 2-D one has ~2n levels of <= n rows (little parallelism, still exact); a chain (tridiagonal
+// matrix) has n levels of one row each — one launch per row: exact, and pointless on a GPU.
 #include <algorithm>
 
 #include "device.hpp"
