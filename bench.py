@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the sprsolve Krylov hot path on MI355X — BASELINE.json's metric.
 
-    python bench.py --gpus N --steps K --warmup W [--workload poisson3d|poisson2d|banded|complex]
+    python bench.py --gpus N --steps K --warmup W [--workload poisson3d|poisson2d|banded|complex|bench100]
 
 A "step" is one BiCGStab iteration (2 SpMV + the fused vector updates and dot products) on
 synthetic data already resident in HBM.  The timed region is one `solve` call with
@@ -14,15 +14,29 @@ Workload (config.workload):
   * default, every N: BASELINE cfg 5 — 7-point 3-D Poisson, 500x500x200 = 50 M rows,
     349.1 M nnz, f64, BiCGStab.  It is the configuration the metric's "1/2/4/8 MI355X"
     scaling is quoted on, it fits one GPU (5.2 GB), and — unlike the 1 M-row cfg 2, whose
-    whole working set sits in the 256 MiB Infinity Cache — it is genuinely HBM-bound, so the
-    roofline fraction is an honest HBM number.  N > 1: the same system row-partitioned in
-    z-slabs over the ranks (strong scaling), halo exchange + dot all-reduce over RCCL.
-  * N = 1 additionally measures BASELINE cfg 2 (1 M-row 2-D Poisson, BiCGStab + Jacobi) and
-    reports it in the "also" object; `--workload poisson2d` makes it the headline instead.
+    whole working set sits in the 256 MiB Infinity Cache — it is genuinely HBM-bound.
+    N > 1: the same system row-partitioned in z-slabs over the ranks (strong scaling), halo
+    exchange + dot all-reduce over RCCL.  `--gpus N` started WITHOUT torchrun launches itself:
+    the parent (which never touches the GPU) runs `python -m torch.distributed.run` with N ranks,
+    relays rank 0's JSON line and exits with the child's code.
+  * N = 1 additionally measures (object "also"): the plain-CSR kernel on the same matrix, the same
+    pattern with RANDOM values (what "identical random CSR inputs" exercises: no value dictionary,
+    9 B/nnz offset-code stream), and BASELINE cfg 2 (1 M-row 2-D Poisson, BiCGStab + Jacobi).
+  * `--workload bench100`: BASELINE cfg 1, the reference's own bench (benches/bicgstab.rs:14-37):
+    CPU restatement at 4 threads and all cores, fixed iteration count; the GPU number beside it if a GPU is there.
+
+roofline (every fraction is <= 1 by construction): `achieved` = the bytes the TIMED kernel's stream has to move
+(`format_bytes_per_launch`: x and y once, row_ptr, and what the stream stores per nnz) / its mean launch time,
+HIP events on the solver's stream inside the timed solve.  SURVEY §8d's CSR formula nnz*12 + (n+1)*4 + 2*n*8 applies
+to the plain-CSR kernel only and is reported for that kernel (`roofline_plain_csr`, measured in the same run on the
+same matrix); for a compressed stream the same time against the CSR bytes is `csr_equivalent_GBs` — a speed-up
+figure, not a roofline fraction.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +44,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+STREAM_KNOB = {"auto": -1, "csr": 0, "offsets": 1, "dict": 2}
+STREAM_NAMES = {0: "csr", 1: "offset-codes", 2: "pair-codes"}
+KERNEL_NAMES = {0: "spmv_kernel<double> (plain CSR stream, wavefront-private LDS products, fused dot epilogue; csrc/spmv.hip)",
+                1: "spmv_dict_kernel<double, PAIR=false> (one-byte column-offset codes + 8-byte values; csrc/spmv_dict.hip)",
+                2: "spmv_pair2_kernel<DOT> (one-byte (offset, value) pair codes, two rows per lane, uniform blocks from a scalar "
+                   "pattern; csrc/spmv_dict.hip)"}
 
 
 def parse():
@@ -37,17 +57,20 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="poisson3d", choices=["poisson3d", "poisson2d", "banded", "complex"])
+    ap.add_argument("--workload", default="poisson3d", choices=["poisson3d", "poisson2d", "banded", "complex", "bench100"])
     ap.add_argument("--grid", default="500x500x200", help="poisson3d grid nx x ny x nz")
+    ap.add_argument("--values", default="poisson", choices=["poisson", "random"],
+                    help="poisson3d values: the constant-coefficient operator, or U(-1,1) off-diagonals with a dominant diagonal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=40.0,
+                    help="budget of the CPU baseline (both thread legs together); samples keep all rows and cut iterations")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the bootstrap (gloo + SPRS_BENCH_DEVICE + SPRS_RCCL_LIB rehearse "
                          "the N>1 leg with several ranks on one GPU)")
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
                     help="N>1 SpMV input exchange: sparse halo (default) or north_star's literal full all-gather of x")
-    ap.add_argument("--stream", default="auto", choices=["auto", "csr", "offsets", "dict"],
+    ap.add_argument("--stream", default="auto", choices=list(STREAM_KNOB),
                     help="SpMV stream: plain CSR (12 B/nnz), one-byte column-offset codes, offset + value codes; "
                          "auto = the most compact one the matrix qualifies for (csrc/spmv_dict.hip)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
@@ -57,12 +80,38 @@ def parse():
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------ self-launch
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This process has not touched the
+    GPU (no torch import, no HIP call), the ranks are ordinary children (never an exec)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    if p.returncode != 0:
+        sys.exit(p.returncode)
+    if line is None:
+        print("bench.py: the ranks exited 0 but rank 0 printed no JSON line", file=sys.stderr)
+        sys.exit(1)
+    sys.exit(0)
+
+
+# ------------------------------------------------------------------------------------------ helpers
 def spmv_bytes(n, nnz, s):
     """nnz*(s+4) + (n+1)*4 + n*s (x) + n*s (y)."""
     return nnz * (s + 4) + (n + 1) * 4 + 2 * n * s
-
-
-STREAM_NAMES = {0: "csr", 1: "offset-codes", 2: "pair-codes"}
 
 
 def stream_info(A, n, nnz, s):
@@ -72,6 +121,34 @@ def stream_info(A, n, nnz, s):
     per_nnz = {0: s + 4, 1: s + 1, 2: 1}[mode]
     return dict(stream=STREAM_NAMES[mode], mode=mode, distinct_offsets=n_off, distinct_pairs=n_pair,
                 bytes_per_nnz=per_nnz, format_bytes_per_launch=nnz * per_nnz + (n + 1) * 4 + 2 * n * s)
+
+
+def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8):
+    """The roofline object of one measured SpMV kernel: fraction of the HBM peak on the bytes ITS stream must move."""
+    fb = sinfo["format_bytes_per_launch"]
+    r = dict(bound="hbm", kernel=KERNEL_NAMES[sinfo["mode"]], achieved=fb / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+             frac=fb / t_spmv / 1e9 / HBM_PEAK_GBS, traffic=None, stream=sinfo["stream"], bytes_per_nnz=sinfo["bytes_per_nnz"],
+             format_bytes_per_launch=fb, algorithmic_bytes_per_launch=fb, avg_launch_us=t_spmv * 1e6, launches=launches)
+    if sinfo["mode"] != 0:
+        r["csr_equivalent_GBs"] = spmv_bytes(n, nnz, s) / t_spmv / 1e9
+        r["csr_equivalent_note"] = ("the same launch time against SURVEY §8d's CSR bytes nnz*12 + (n+1)*4 + 2*n*8: what a plain-CSR "
+                                    "kernel would have to sustain to be as fast; a speed-up figure, NOT a roofline fraction "
+                                    "(the stream is lossless, y bit-identical; the plain-CSR kernel's own fraction is roofline_plain_csr)")
+    return r
+
+
+def pmc_traffic(key):
+    """HBM-side bytes per SpMV launch from the committed rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE passes
+    of this bench command, gfx950 x2 FETCH correction) — measured off-line, so it goes stale when the kernel changes:
+    the file records the commit it was taken at."""
+    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                pm = json.load(f).get(key, {}).get("spmv_in_solve")
+            if pm:
+                return pm["traffic_bytes"], "profiles/%s[%s]: %s" % (name, key, pm["note"])
+    return None, "no PMC summary found"
 
 
 def stream_ceiling(torch, ctx, n, reps=20):
@@ -146,59 +223,151 @@ def time_solve(torch, dist, solver, precond, rhs, x, steps, warmup, world, profi
     return dt, prof
 
 
-def cpu_baseline_poisson3d(nx, ny, nz_full, target_s):
-    """The reference's CPU path (row-parallel SpMV + serial BLAS-1) restated in C (oracle/),
-    timed on this box's host cores on a z-slab sample of the same system."""
+# ------------------------------------------------------------------------------------------ CPU baseline
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_threads():
+    """Hardware threads this process may really use: the affinity mask, capped by the cgroup CPU quota (a container
+    that sees 256 CPUs but is throttled to 16 runs SLOWER with 256 OpenMP threads than with 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = max(1, min(n, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = max(1, min(n, int(q / float(f.read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_baseline(fn, ip, ix, dv, rhs, diag, budget_s, what, legs=None):
+    """the reference's CPU path restated in C (oracle/: rayon-style row-parallel SpMV + SERIAL BLAS-1,
+    usize indices), timed ON THE CONFIG ITSELF (all rows), at 4 threads (the reference's own bench setting,
+    benches/bicgstab.rs:7-10) and at all host cores this process may use; x reset before every sample; median of >= 5
+    samples per leg.  A sample is one solve with max_iter = k and tol = 0 (exactly k iterations + the solve's set-up);
+    `value` is the MARGINAL iteration rate (k_hi - k_lo) / (median T(k_hi) - median T(k_lo)), so the set-up cancels.
+    The budget cuts iterations per sample, never rows and never the number of samples."""
+    import numpy as np
+
+    from oracle import oracle as orc
+    ip64 = np.ascontiguousarray(ip, dtype=np.int64); ix64 = np.ascontiguousarray(ix, dtype=np.int64)
+    ncores = host_threads()
+    legs = legs or [4, ncores]
+    out = dict(unit="iterations/s", kind="port", cpu_model=cpu_model(), host_threads_available=ncores, samples=5)
+    x0 = np.zeros_like(rhs)
+
+    def solve(k):
+        t0 = time.perf_counter()
+        r = fn(ip64, ix64, dv, rhs, x0, k, 0.0, precond_diag=diag, parallel=True)   # x0 is copied inside: x reset per sample
+        dt = time.perf_counter() - t0
+        assert r.status == orc.INSUFFICIENT_ITER and r.its == k
+        return dt
+    for li, th in enumerate(legs):
+        orc.set_threads(th)
+        t1 = solve(1)                               # calibration sample (also warms the page cache of the arrays)
+        per_leg = budget_s / len(legs)
+        # 5 samples at k_lo and 5 at k_hi must fit the leg's budget: T(k) ~ t1 * (0.6 + 0.4 k) is only used to choose k
+        k_lo = 1
+        k_hi = int(max(2, min(50, (per_leg / 5.0 / max(t1, 1e-9) - 1.2) / 0.8)))
+        lo = sorted(solve(k_lo) for _ in range(5))
+        hi = sorted(solve(k_hi) for _ in range(5))
+        marginal = (k_hi - k_lo) / max(hi[2] - lo[2], 1e-12)
+        out["threads%d" % th if li == 0 else "all_cores"] = dict(
+            threads=th, value=marginal, k_lo=k_lo, k_hi=k_hi, median_s_k_lo=lo[2], median_s_k_hi=hi[2],
+            min_s_k_hi=hi[0], max_s_k_hi=hi[4], with_setup_it_s=k_hi / hi[2])
+    best = max(out[k]["value"] for k in out if isinstance(out[k], dict))
+    out["value"] = best
+    out["cores"] = [out[k]["threads"] for k in out if isinstance(out[k], dict) and out[k]["value"] == best][0]
+    out["sample"] = ("CPU restatement of the reference path (oracle/: row-parallel SpMV + serial BLAS-1, usize indices) on %s, ALL rows; "
+                     "per thread leg 5 solves of %d and 5 of k_hi iterations (tol = 0, x reset), medians, marginal iterations/s; "
+                     "CPU: %s, %d hardware threads usable; baseline, not target" % (what, 1, out["cpu_model"], ncores))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ cfg 1
+def bench100(args):
+    """BASELINE cfg 1 = the reference's own bench (benches/bicgstab.rs:14-37): grid_laplacian(100,100) with Dirichlet
+    rows, rhs = i+j on the border, x0 = 0, BiCGStab.  The reference times solve-to-1e-16 with x never reset
+    (SURVEY §6 lists why that is not a measurement); here: fixed iteration count, x reset, 4 threads and all cores."""
     import numpy as np
 
     from oracle import oracle as orc
     from sprsolve_amd import gen
-    cores = os.cpu_count() or 1
-    orc.set_threads(cores)
-    nz_s = 16
-    indptr, indices, data, rhs = gen.poisson3d(nx, ny, nz_s)
-    n = rhs.size
-    ip64 = indptr.astype(np.int64); ix64 = indices.astype(np.int64)
-    # calibrate with 3 iterations, then run enough for ~target_s
-    t0 = time.perf_counter()
-    orc.bicgstab(ip64, ix64, data, rhs, np.zeros(n), 3, 0.0, parallel=True)
-    per_it = (time.perf_counter() - t0) / 3
-    its = int(max(5, min(200, target_s / max(per_it, 1e-6))))
-    t0 = time.perf_counter()
-    r = orc.bicgstab(ip64, ix64, data, rhs, np.zeros(n), its, 0.0, parallel=True)
-    dt = time.perf_counter() - t0
-    assert r.status == orc.INSUFFICIENT_ITER
-    it_s_sample = its / dt
-    scale = (nx * ny * nz_full) / float(n)
-    return dict(value=it_s_sample / scale, unit="iterations/s", cores=cores, kind="port",
-                sample="%d BiCGStab iterations of the CPU restatement (oracle/, rayon-style row-parallel SpMV on %d "
-                       "threads + serial BLAS-1, usize indices) on a %dx%dx%d slab (%d rows) of the same 7-point system; "
-                       "%.2f it/s on the slab, scaled by rows to the %dx%dx%d system" %
-                       (its, cores, nx, ny, nz_s, n, it_s_sample, nx, ny, nz_full))
+    R = 100
+    ip, ix, dv = gen.grid_laplacian_dirichlet(R, R)
+    rhs = gen.dirichlet_rhs(R, R)
+    n, nnz = R * R, int(ip[-1])
+    ip64 = ip.astype(np.int64); ix64 = ix.astype(np.int64)
+    K = args.steps
+    res = {}
+    for name, th in (("threads4", 4), ("all_cores", host_threads())):
+        orc.set_threads(th)
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            r = orc.bicgstab(ip64, ix64, dv, rhs, np.zeros(n), K, 0.0, parallel=True)
+            ts.append(time.perf_counter() - t0)
+            assert r.status == orc.INSUFFICIENT_ITER
+        ts.sort()
+        res[name] = dict(threads=th, value=K / ts[3], median_s=ts[3], min_s=ts[0], max_s=ts[6], samples=7)
+    # correctness of the restated path on the reference's own settings (tol 1e-16, max 1500): exact solution i+j
+    r = orc.bicgstab(ip64, ix64, dv, rhs, np.zeros(n), 1500, 1e-16, parallel=True)
+    g = np.arange(n)
+    err = float(np.abs(r.x - (g // R + g % R)).max())
+    out = dict(metric="BiCGStab iterations/s (f64, cfg 1: 100x100 Dirichlet grid Laplacian, benches/bicgstab.rs) — CPU restatement",
+               value=res["threads4"]["value"], unit="iterations/s", n_gpus=0, steps=K, warmup=0,
+               ms_per_step=1e3 / res["threads4"]["value"], higher_is_better=True, scaling="strong", vs_baseline=None,
+               dtype="f64", data="synthetic",
+               config=dict(workload="cfg1: grid_laplacian(100,100) + Dirichlet rhs, n=%d, nnz=%d, BiCGStab tol=0 fixed %d iterations, "
+                                    "x reset per sample, median of 7" % (n, nnz, K), rows=n, nnz=nnz, index_type="usize"),
+               cpu_baseline=dict(res, unit="iterations/s", kind="port", cpu_model=cpu_model(), value=res["threads4"]["value"], cores=4,
+                                 sample="the whole of cfg 1; `value` is the 4-thread leg (the reference's rayon pool size, benches/bicgstab.rs:7-10)"),
+               converge_check=dict(tol=1e-16, max_iter=1500, status=int(r.status), iters=int(r.its), rel_res=float(r.res),
+                                   max_abs_err_vs_exact=err),
+               roofline=None)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            import sprsolve_amd as sa
+            ctx = sa.default_ctx(0)
+            A = sa.HipCsr.new((n, n), ip, ix, dv, ctx=ctx)
+            s = sa.BiCGStab.new(A, n)
+            drhs = torch.from_numpy(rhs).cuda(); x = torch.zeros(n, dtype=torch.float64, device="cuda")
+            dt, _ = time_solve(torch, None, s, None, drhs, x, K, min(args.warmup, K), 1, profile=False)
+            out["gpu_same_config"] = dict(value=K / dt, unit="iterations/s", note="libsprsolve_hip on one MI355X, same matrix, same K; "
+                                          "78 KB of matrix: pure launch latency (5 launches per iteration)")
+    except Exception as e:     # the CPU line stands on its own
+        out["gpu_same_config"] = dict(error=str(e))
+    print(json.dumps(out))
 
 
-def cpu_baseline_rows(build, full_rows, target_s, what):
-    import numpy as np
-
-    from oracle import oracle as orc
-    cores = os.cpu_count() or 1
-    orc.set_threads(cores)
-    indptr, indices, data, rhs, diag, fn, n = build()
-    ip64 = indptr.astype(np.int64); ix64 = indices.astype(np.int64)
-    t0 = time.perf_counter()
-    fn(ip64, ix64, data, rhs, np.zeros_like(rhs), 3, 0.0, precond_diag=diag, parallel=True)
-    per_it = (time.perf_counter() - t0) / 3
-    its = int(max(5, min(500, target_s / max(per_it, 1e-6))))
-    t0 = time.perf_counter()
-    fn(ip64, ix64, data, rhs, np.zeros_like(rhs), its, 0.0, precond_diag=diag, parallel=True)
-    dt = time.perf_counter() - t0
-    return dict(value=(its / dt) / (full_rows / float(n)), unit="iterations/s", cores=cores, kind="port",
-                sample="%d iterations of the CPU restatement (oracle/, row-parallel SpMV on %d threads + serial BLAS-1) "
-                       "on %s (%d rows), scaled by rows" % (its, cores, what, n))
-
-
+# ------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    if args.workload == "bench100":
+        return bench100(args)
     import torch   # first: libsprsolve_hip.so then shares torch's HIP runtime (same soname)
     import torch.distributed as dist
 
@@ -206,8 +375,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     local_rank = int(os.environ.get("SPRS_BENCH_DEVICE", local_rank))   # rehearsal: several ranks on one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -224,7 +392,7 @@ def main():
     import sprsolve_amd as sa
     from sprsolve_amd import gen_torch
     ctx = sa.default_ctx(local_rank)
-    ctx.set("spmv_dict", {"auto": -1, "csr": 0, "offsets": 1, "dict": 2}[args.stream])
+    ctx.set("spmv_dict", STREAM_KNOB[args.stream])
     for kv in args.set:
         k, v = kv.split("=")
         ctx.set(k, int(v))
@@ -256,26 +424,31 @@ def main():
             pass
         pcie_dt = time.perf_counter() - t0
         bs = spmv_bytes(n, nnz, 8)
+        sinfo = stream_info(A, n, nnz, 8)
         # stand-alone SpMV timing (back-to-back launches, HIP events on the library's stream)
         y = torch.empty_like(x)
         ms_alone = A.time_mul_vec(rhs, y, reps=200)
         t_spmv = prof["spmv_ms_total"] / max(prof["spmv_launches"], 1) * 1e-3
         return dict(workload="cfg2: 1000x1000 2-D 5-point Poisson (Dirichlet rows), n=1e6, nnz=4984016, BiCGStab + Jacobi",
-                    value=steps / dt, ms_per_step=dt / steps * 1e3, n=n, nnz=nnz,
+                    value=steps / dt, ms_per_step=dt / steps * 1e3, n=n, nnz=nnz, spmv_stream=sinfo["stream"],
                     pcie_inclusive_it_s=steps / pcie_dt,
                     spmv_us_in_solve=t_spmv * 1e6, spmv_us_back_to_back=ms_alone * 1e3,
-                    spmv_GBs_in_solve=bs / t_spmv / 1e9, spmv_GBs_back_to_back=bs / (ms_alone * 1e-3) / 1e9,
+                    spmv_csr_equivalent_GBs_in_solve=bs / t_spmv / 1e9, spmv_csr_equivalent_GBs_back_to_back=bs / (ms_alone * 1e-3) / 1e9,
                     spmv_bytes=bs, iter_bytes_reference_oplist=2 * bs + 26 * n * 8 + 2 * n * 24,
                     effective_GBs=(2 * bs + 26 * n * 8 + 2 * n * 24) * steps / dt / 1e9,
                     converge_check=dict(tol=1e-8, iters=its, rel_res=res, max_abs_err_vs_exact=err),
-                    note="working set (~140 MB) fits the 256 MiB Infinity Cache: GB/s here is not an HBM figure"), t_spmv, bs
+                    note="working set (~140 MB) fits the 256 MiB Infinity Cache: GB/s here is not an HBM figure"), t_spmv, bs, sinfo, prof
 
     if args.workload == "poisson3d":
         nx, ny, nz = (int(v) for v in args.grid.lower().split("x"))
+        cpu_arrays = None
         if world == 1 and not args.force_dist:
-            ip, ix, dv, rhs = gen_torch.poisson3d(nx, ny, nz, device=dev)
+            ip, ix, dv, rhs = gen_torch.poisson3d(nx, ny, nz, device=dev, values=args.values)
             n = nx * ny * nz
             nnz = int(ip[-1].item())
+            if rank == 0 and not args.no_cpu_baseline:
+                # host copy for the CPU leg, taken before the arrays are adopted (the baseline runs last)
+                cpu_arrays = (ip.cpu().numpy(), ix.cpu().numpy(), dv.cpu().numpy(), rhs.cpu().numpy())
             A = sa.HipCsr.from_device((n, n), nnz, ip, ix, dv, adopt=True, ctx=ctx)
             s = sa.BiCGStab.new(A, n)
             x = torch.zeros(n, dtype=torch.float64, device=dev)
@@ -289,111 +462,130 @@ def main():
             check = dict(tol=1e-8, iters=its, rel_res=res, max_abs_err_vs_exact=err)
             n_glob, nnz_glob = n, nnz
             sinfo = stream_info(A, n, nnz, 8)
-            if sinfo["mode"] != 0 and not args.no_also:
-                # the same solve on the plain CSR stream (12 B/nnz): the apples-to-apples figure against SURVEY's
-                # CSR roofline; identical iterates (the streams are bit-identical), so only the time differs
-                ctx.set("spmv_dict", 0)
-                t_csr, p_csr = time_solve(torch, dist, s, None, rhs, x, max(args.steps // 2, 10), min(args.warmup, 5), 1)
-                ctx.set("spmv_dict", {"auto": -1, "csr": 0, "offsets": 1, "dict": 2}[args.stream])
+            roof_csr = None
+            if not args.no_also:
+                # the same solve on the plain CSR stream (12 B/nnz): the kernel SURVEY §8d's formula describes;
+                # identical iterates (the streams are bit-identical), so only the time differs
                 k_csr = max(args.steps // 2, 10)
+                if sinfo["mode"] != 0:
+                    ctx.set("spmv_dict", 0)
+                    t_csr, p_csr = time_solve(torch, dist, s, None, rhs, x, k_csr, min(args.warmup, 5), 1)
+                    ctx.set("spmv_dict", STREAM_KNOB[args.stream])
+                else:
+                    t_csr, p_csr, k_csr = dt, prof, args.steps
                 tl = p_csr["spmv_ms_total"] / max(p_csr["spmv_launches"], 1) * 1e-3
+                csr_info = dict(stream="csr", mode=0, bytes_per_nnz=12, format_bytes_per_launch=bs)
+                roof_csr = roofline_of(csr_info, tl, p_csr["spmv_launches"], n, nnz)
+                roof_csr["traffic"], roof_csr["traffic_note"] = pmc_traffic("bench_csr")
+                if roof_csr["traffic"]:
+                    roof_csr["traffic_over_algorithmic"] = roof_csr["traffic"] / bs
                 also["cfg5_plain_csr_stream"] = dict(
                     value=k_csr / t_csr, unit="iterations/s", ms_per_step=t_csr / k_csr * 1e3, steps=k_csr,
                     spmv_us_in_solve=tl * 1e6, spmv_GBs=bs / tl / 1e9, spmv_frac_of_hbm_peak=bs / tl / 1e9 / HBM_PEAK_GBS,
                     note="spmv_kernel<double> on (col_idx, val); same matrix, same vectors, same iterates")
+            if not args.no_also and args.values == "poisson":
+                # variable coefficients on the same pattern: no value dictionary => one-byte offset codes + values, 9 B/nnz
+                del s, A
+                x = None
+                torch.cuda.empty_cache()
+                ipr, ixr, dvr, rhsr = gen_torch.poisson3d(nx, ny, nz, device=dev, values="random")
+                Ar = sa.HipCsr.from_device((n, n), nnz, ipr, ixr, dvr, adopt=True, ctx=ctx)
+                sr = sa.BiCGStab.new(Ar, n)
+                xr = torch.zeros(n, dtype=torch.float64, device=dev)
+                k_r = max(args.steps // 2, 10)
+                t_r, p_r = time_solve(torch, dist, sr, None, rhsr, xr, k_r, min(args.warmup, 5), 1)
+                tlr = p_r["spmv_ms_total"] / max(p_r["spmv_launches"], 1) * 1e-3
+                sinfo_r = stream_info(Ar, n, nnz, 8)
+                xr.zero_()
+                its_r, res_r = sr.solve(rhsr, xr, 5000, 1e-8)
+                err_r = float((xr - 1.0).abs().max().item())
+                rr = roofline_of(sinfo_r, tlr, p_r["spmv_launches"], n, nnz)
+                also["cfg5_random_values"] = dict(
+                    workload="the cfg-5 pattern (500x500x200 7-point) with off-diagonals U(-1,1) and diagonal 1 + sum|row off-diagonals| "
+                             "(splitmix64 by nnz position), rhs = A*1, BiCGStab tol=0 fixed %d iterations" % k_r,
+                    value=k_r / t_r, unit="iterations/s", ms_per_step=t_r / k_r * 1e3, steps=k_r, spmv_stream=sinfo_r,
+                    roofline=rr, converge_check=dict(tol=1e-8, iters=its_r, rel_res=res_r, max_abs_err_vs_exact=err_r))
+                del sr, Ar, xr, ipr, ixr, dvr, rhsr
+                torch.cuda.empty_cache()
         else:
             from sprsolve_amd import dist as sdist
             res_ = sdist.bench_poisson3d(torch, dist, ctx, rank, world, nx, ny, nz, args.steps, args.warmup, time_solve,
                                          exchange=args.exchange)
-            dt, prof, t_spmv, bs, check, n_glob, nnz_glob, sinfo = res_
+            dt, prof, t_spmv, bs, check, n_glob, nnz_glob, sinfo = res_[:8]
+            dist_info = res_[8] if len(res_) > 8 else {}
+            roof_csr = None
         it_bytes = 2 * spmv_bytes(n_glob, nnz_glob, 8) + 26 * n_glob * 8
-        traffic, traffic_note = None, "no PMC summary found"
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        pmc_key = {0: "bench_csr", 1: "bench_offsets", 2: "bench_pair"}[sinfo["mode"]]
-        if world == 1 and (nx, ny, nz) == (500, 500, 200) and os.path.exists(pmc_path):
-            # HBM-side bytes per launch from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes of this same
-            # command, gfx950 x2 FETCH correction calibrated in the SpMV's access pattern) — profiles/
-            with open(pmc_path) as f:
-                pm = json.load(f).get(pmc_key, {}).get("spmv_in_solve")
-            if pm:
-                traffic, traffic_note = pm["traffic_bytes"], "profiles/r01_pmc_summary.json[%s]: %s" % (pmc_key, pm["note"])
-        kernel = {0: "spmv_kernel<double> (plain CSR stream, LDS product path, fused dot epilogue)",
-                  1: "spmv_dict_kernel<double, PAIR=false> (one-byte column-offset codes + values)",
-                  2: "spmv_pair2_kernel<DOT> (one-byte (offset, value) pair codes, two rows per lane, uniform blocks from a "
-                     "scalar pattern; csrc/spmv_dict.hip)"}[sinfo["mode"]]
-        fb = sinfo["format_bytes_per_launch"]          # per rank, like bs
-        roof = dict(bound="hbm", kernel=kernel,
-                    achieved=bs / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=bs / t_spmv / 1e9 / HBM_PEAK_GBS,
-                    traffic=traffic, traffic_note=traffic_note, algorithmic_bytes_per_launch=bs,
-                    avg_launch_us=t_spmv * 1e6, launches=prof["spmv_launches"],
-                    stream=sinfo["stream"], format_bytes_per_launch=fb,
-                    format_GBs=fb / t_spmv / 1e9, format_frac_of_hbm_peak=fb / t_spmv / 1e9 / HBM_PEAK_GBS,
-                    note="per rank; `achieved` / `frac` use SURVEY §8d's CSR bytes nnz*12 + (n+1)*4 + 2*n*8 (x counted once), as the "
-                         "contract says"
-                         + ("" if sinfo["mode"] == 0 else "; the %s stream moves %d B/nnz instead of 12 (lossless, y bit-identical), so `frac` "
-                            "exceeds what a 12 B/nnz CSR kernel could reach at the HBM peak — `format_*` is the same time against the bytes "
-                            "this stream really needs, and also.cfg5_plain_csr_stream is the plain CSR kernel on the same matrix; the "
-                            "compressed kernel is bound by the CUs' vector-memory issue and latency, not by HBM (DESIGN.md §5)"
-                            % (sinfo["stream"], sinfo["bytes_per_nnz"]))
-                         + ("; N>1: the bracketed time includes the wait for the halo exchange of the boundary rows" if world > 1 else ""))
+        n_rank = sinfo.get("rows", n_glob)
+        nnz_rank = sinfo.get("nnz", nnz_glob)
+        roof = roofline_of(sinfo, t_spmv, prof["spmv_launches"], n_rank, nnz_rank)
+        if world == 1 and (nx, ny, nz) == (500, 500, 200) and args.values == "poisson":
+            roof["traffic"], roof["traffic_note"] = pmc_traffic({0: "bench_csr", 1: "bench_offsets", 2: "bench_pair"}[sinfo["mode"]])
+        roof["note"] = ("per rank; `achieved` / `frac` = the bytes this kernel's stream must move (x, y once; row_ptr; %d B per nnz) / mean "
+                        "launch time (HIP events on the solver's stream, inside the timed solve)" % sinfo["bytes_per_nnz"]
+                        + ("; the kernel is bound by the CUs' vector-memory issue and gather latency, not by HBM (DESIGN.md §3)" if sinfo["mode"] == 2 else "")
+                        + ("; N>1: the bracketed time includes the wait for the halo exchange of the boundary rows" if world > 1 else ""))
         out = dict(metric="BiCGStab iterations/s (f64, 50M-row 7-point 3-D Poisson) + CSR SpMV GB/s vs HBM roofline",
                    value=args.steps / dt, unit="iterations/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None,
                    dtype="f64", data="synthetic",
-                   config=dict(workload="cfg5: %dx%dx%d 7-point 3-D Poisson, n=%d, nnz=%d, BiCGStab (no preconditioner), "
-                                        "tol=0 fixed %d iterations" % (nx, ny, nz, n_glob, nnz_glob, args.steps),
+                   config=dict(workload="cfg5: %dx%dx%d 7-point 3-D Poisson%s, n=%d, nnz=%d, BiCGStab (no preconditioner), "
+                                        "tol=0 fixed %d iterations" % (nx, ny, nz, " (random values)" if args.values == "random" else "",
+                                                                       n_glob, nnz_glob, args.steps),
                                rows=n_glob, nnz=nnz_glob, index_type="i32", partition="z-slabs x%d" % world,
                                spmv_stream=sinfo,
                                bytes_per_iteration_reference_oplist=it_bytes),
                    effective_GBs_reference_oplist=it_bytes * args.steps / dt / 1e9,
                    roofline=roof, converge_check=check)
+        if roof_csr is not None:
+            out["roofline_plain_csr"] = roof_csr
+        if world > 1 or args.force_dist:
+            out.update(dist_info)
         if world == 1 and rank == 0:
             x = None                      # release the solution vector before the microbench allocates its own
             sc = stream_ceiling(torch, ctx, n_glob if not args.force_dist else min(n_glob, 50_000_000))
             roof["measured_stream_ceiling"] = dict(sc, note="this library's axpy (2R+1W) and a d2d copy (1R+1W) on n doubles, "
                                                             "back to back — SURVEY §8d's secondary denominator")
-            best = max(sc.values())
+            best = max(sc["axpy_GBs"], sc["copy_GBs"])
             roof["frac_of_measured_stream"] = roof["achieved"] / best
-            roof["format_frac_of_measured_stream"] = roof["format_GBs"] / best
-            if "cfg5_plain_csr_stream" in also:
-                also["cfg5_plain_csr_stream"]["spmv_frac_of_measured_stream"] = also["cfg5_plain_csr_stream"]["spmv_GBs"] / best
+            if roof_csr is not None:
+                roof_csr["frac_of_measured_stream"] = roof_csr["achieved"] / best
         if world == 1 and not args.no_also and not args.force_dist:
-            r2, _, _ = bench_poisson2d(500, 50)
+            r2, _, _, _, _ = bench_poisson2d(500, 50)
             also["cfg2_poisson2d_1M_bicgstab_jacobi"] = r2
-        if world == 1 and rank == 0 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_poisson3d(nx, ny, nz, args.cpu_seconds)
+        if cpu_arrays is not None:
+            from oracle import oracle as orc
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(orc.bicgstab, *cpu_arrays, None, args.cpu_seconds,
+                                               "the full cfg-5 system (%d rows, %d nnz)" % (n_glob, nnz_glob))
     elif args.workload == "poisson2d":
         if world != 1:
             raise SystemExit("poisson2d is a single-GPU workload (cfg 2)")
-        r2, t_spmv, bs = bench_poisson2d(args.steps, args.warmup)
+        r2, t_spmv, bs, sinfo, prof = bench_poisson2d(args.steps, args.warmup)
+        roof = roofline_of(sinfo, t_spmv, prof["spmv_launches"], 10**6, r2["nnz"])
+        roof["note"] = "cache-resident working set (fits the 256 MiB Infinity Cache): not an HBM figure; see detail.note"
         out = dict(metric="BiCGStab iterations/s (f64, 1M-row 2-D Poisson + Jacobi) + CSR SpMV GB/s",
                    value=r2["value"], unit="iterations/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
                    ms_per_step=r2["ms_per_step"], higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64",
-                   data="synthetic", config=dict(workload=r2["workload"]),
-                   roofline=dict(bound="hbm", achieved=bs / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                                 frac=bs / t_spmv / 1e9 / HBM_PEAK_GBS, traffic=None,
-                                 note="cache-resident working set; see detail.note"),
-                   detail=r2)
+                   data="synthetic", config=dict(workload=r2["workload"]), roofline=roof, detail=r2)
         if not args.no_cpu_baseline:
             from oracle import oracle as orc
             from sprsolve_amd import gen
-
-            def build():
-                ip, ix, dv = gen.grid_laplacian_dirichlet(1000, 1000)
-                return ip, ix, dv, gen.dirichlet_rhs(1000, 1000), np.where(np.diff(ip) == 1, 1.0, -4.0), orc.bicgstab, 10**6
-            out["cpu_baseline"] = cpu_baseline_rows(build, 10**6, args.cpu_seconds, "the full cfg-2 system")
+            ip, ix, dv = gen.grid_laplacian_dirichlet(1000, 1000)
+            out["cpu_baseline"] = cpu_baseline(orc.bicgstab, ip, ix, dv, gen.dirichlet_rhs(1000, 1000),
+                                               np.where(np.diff(ip) == 1, 1.0, -4.0), args.cpu_seconds, "the full cfg-2 system (Jacobi)")
     else:
         if world != 1:
             raise SystemExit("%s is a single-GPU workload" % args.workload)
+        from oracle import oracle as orc
         from sprsolve_amd import gen
         if args.workload == "banded":
             n = 10**6
             ip, ix, dv, rhs = gen.symmetric_banded(n)
-            solver_cls, label, sbytes = sa.MinRes, "cfg3: symmetric banded (hbw 4), n=1e6, nnz=8999980, MINRES", 8
+            solver_cls, label, sbytes, ofn = sa.MinRes, "cfg3: symmetric banded (hbw 4), n=1e6, nnz=8999980, MINRES", 8, orc.minres
         else:
             ip, ix, dv, rhs, _ = gen.complex_symmetric_grid(500, 1000)
             n = 500000
-            solver_cls, label, sbytes = sa.CSMinRes, "cfg4: complex-symmetric 500x1000 grid, n=5e5, nnz=2497000, CSMINRES", 16
+            solver_cls, label, sbytes, ofn = sa.CSMinRes, "cfg4: complex-symmetric 500x1000 grid, n=5e5, nnz=2497000, CSMINRES", 16, orc.csminres
         A = sa.HipCsr.new((n, n), ip, ix, dv, ctx=ctx)
         s = solver_cls.new(A, n)
         tdt = torch.float64 if sbytes == 8 else torch.complex128
@@ -401,13 +593,20 @@ def main():
         x = torch.zeros(n, dtype=tdt, device=dev)
         dt, prof = time_solve(torch, dist, s, None, drhs, x, args.steps, args.warmup, 1)
         t_spmv = prof["spmv_ms_total"] / max(prof["spmv_launches"], 1) * 1e-3
-        bs = spmv_bytes(n, int(ip[-1]), sbytes)
+        sinfo = stream_info(A, n, int(ip[-1]), sbytes)
+        roof = roofline_of(sinfo, t_spmv, prof["spmv_launches"], n, int(ip[-1]), sbytes)
+        roof["kernel"] = roof["kernel"].replace("double", "double" if sbytes == 8 else "cplx")
+        roof["note"] = "cache-resident working set (fits the 256 MiB Infinity Cache): the fraction is against the HBM peak all the same"
         out = dict(metric="%s iterations/s + CSR SpMV GB/s" % solver_cls.__name__, value=args.steps / dt, unit="iterations/s",
                    n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                    scaling="strong", vs_baseline=None, dtype="f64" if sbytes == 8 else "c64", data="synthetic",
-                   config=dict(workload=label),
-                   roofline=dict(bound="hbm", achieved=bs / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                                 frac=bs / t_spmv / 1e9 / HBM_PEAK_GBS, traffic=None, avg_launch_us=t_spmv * 1e6))
+                   config=dict(workload=label, spmv_stream=sinfo), roofline=roof)
+        if not args.no_cpu_baseline:
+            if args.workload == "banded":
+                out["cpu_baseline"] = cpu_baseline(ofn, ip, ix, dv, rhs, None, args.cpu_seconds, "the full cfg-3 system")
+            else:
+                out["cpu_baseline"] = cpu_baseline(lambda a, b, c, d, e, k, tol, precond_diag=None, parallel=True: ofn(a, b, c, d, e, k, tol, parallel=parallel),
+                                                   ip, ix, dv, rhs, None, args.cpu_seconds, "the full cfg-4 system")
     if also:
         out["also"] = also
     if rank == 0:

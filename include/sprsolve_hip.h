@@ -118,9 +118,12 @@ int sprs_csr_wide_blocks(const sprs_csr *A, int64_t *n_blocks, int64_t *n_unifor
 
 /* MatVecMul::mul_vec / mul_vec_dot (mat.rs:49-64): host slices, checked — returns
  * SPRS_DIM_MISMATCH where the reference panics.  y = A x ; *dot_out = conj(x) . y
- * Thread-safety: the handle is immutable after creation, but the host-slice entry points stage x / y
- * through per-handle device buffers — concurrent callers need one handle (or one external lock) each;
- * sprs_mul_vec_dev_* without a dot result touches no shared scratch. */
+ * Thread-safety (bicg_stab.rs:17-18 `T: Send + Sync`, `A: &M` shared): the handle is immutable after creation and
+ * every entry point that uses per-context or per-handle scratch — the host-slice mul_vec / mul_vec_dot (staging
+ * buffers), everything that returns a scalar, handle creation, all solves — takes the context's mutex, so concurrent
+ * `&self` calls on one handle from several host threads are safe: they queue (one context = one stream; use one
+ * context per thread for concurrency).  tests/test_gpu_threads.py.  The asynchronous device-pointer entry points
+ * (sprs_mul_vec_dev_*, element-wise vecalg) touch no shared scratch; sprs_last_error is last-writer-wins. */
 int sprs_mul_vec_d(const sprs_csr *A, const double *x_host, size_t x_len, double *y_host, size_t y_len);
 int sprs_mul_vec_z(const sprs_csr *A, const sprs_c64 *x_host, size_t x_len, sprs_c64 *y_host, size_t y_len);
 int sprs_mul_vec_dot_d(const sprs_csr *A, const double *x_host, size_t x_len, double *y_host, size_t y_len, double *dot_out);
@@ -320,6 +323,7 @@ int sprs_dist_mul_vec_dev_c(const sprs_csr *A, sprs_c32 *x_ext_dev, sprs_c32 *y_
 int sprs_comm_unique_id(void *id128_out);  /* rank 0: 128-byte RCCL id to broadcast to the other ranks */
 int sprs_comm_create(sprs_ctx *ctx, int world, int rank, const void *id128, sprs_comm **out); /* collective */
 int sprs_comm_destroy(sprs_comm *comm);
+int sprs_comm_count(const sprs_comm *comm, int *count_out); /* ncclCommCount: the number of ranks RCCL itself reports */
 int sprs_comm_allreduce_sum_f64(sprs_comm *comm, double *dev, size_t count); /* in place; blocking */
 /* peer_rank[n_peers]; send_off/recv_off[n_peers+1] are element offsets; send_idx_dev[send_off[n_peers]]
  * (device, i32) lists the local entries to pack for each peer; entries from peer p land at

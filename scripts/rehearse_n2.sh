@@ -3,5 +3,5 @@
 set -e
 g++ -O2 -fPIC -shared -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/mock_rccl/mock_rccl.cpp -o /tmp/libmock_rccl.so -L/opt/rocm/lib -lamdhip64 -lrt -lpthread
 export SPRS_RCCL_LIB=/tmp/libmock_rccl.so SPRS_BENCH_DEVICE=0 OMP_NUM_THREADS=1
-timeout -k 10 280 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
+timeout -k 10 280 python \
     bench.py --gpus 2 --steps 20 --warmup 3 --grid 200x200x64 --dist-backend gloo "$@"

@@ -175,6 +175,7 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const T *__restrict__ p
 
 template <class T>
 int reduce_partials_host(sprs_ctx *c, const T *part, int P, T *out, sprs_comm *comm) {
+    CtxLock lock(c);   // d_scal / h_scal are per-context scratch
     T *d_out = reinterpret_cast<T *>(c->d_scal);
     hipLaunchKernelGGL((finalize_kernel<T>), dim3(1), dim3(BLOCK), 0, c->stream, part, P, d_out);
     SPRS_HIP_TRY(c, hipGetLastError());
@@ -194,6 +195,7 @@ static int red_grid(sprs_ctx *c, size_t n, int pk) {
 
 template <class T>
 int dot_host(sprs_ctx *c, size_t n, const T *x, const T *y, bool conj, T *out, sprs_comm *comm) {
+    CtxLock lock(c);   // d_part is per-context scratch
     constexpr int PKW = pack_width<T>::value;
     const bool al = aligned16(x) && aligned16(y);
     const int pk = (al && PKW > 1) ? PKW : 1;
@@ -210,6 +212,7 @@ int dot_host(sprs_ctx *c, size_t n, const T *x, const T *y, bool conj, T *out, s
 
 template <class T>
 int norm2_host(sprs_ctx *c, size_t n, const T *x, Real<T> *out, sprs_comm *comm) {
+    CtxLock lock(c);
     constexpr int PKW = pack_width<T>::value;
     const int pk = (aligned16(x) && PKW > 1) ? PKW : 1;
     const int g = red_grid(c, n, pk);

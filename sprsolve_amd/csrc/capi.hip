@@ -187,6 +187,7 @@ int csr_create_host(sprs_ctx *c, int64_t nrows, int64_t ncols, int64_t nnz, cons
                     int storage_csc, sprs_csr **out) {
     if (!c || !out || nrows < 0 || ncols < 0 || nnz < 0) return SPRS_INVALID_ARGUMENT;
     if (!ptr || (nnz > 0 && (!idx || !val))) return SPRS_INVALID_ARGUMENT;
+    CtxLock lock(c);
     *out = nullptr;
     if (nrows >= INT32_MAX || ncols >= INT32_MAX || nnz >= INT32_MAX) return SPRS_INVALID_ARGUMENT;
     const int64_t nouter = storage_csc ? ncols : nrows, ninner = storage_csc ? nrows : ncols;
@@ -243,6 +244,7 @@ int csr_create_dev(sprs_ctx *c, int64_t nrows, int64_t ncols, int64_t nnz, const
                    const T *d_val, int adopt, sprs_csr **out) {
     if (!c || !out || !d_rp || nrows < 0 || ncols < 0 || nnz < 0) return SPRS_INVALID_ARGUMENT;
     if (nnz > 0 && (!d_ci || !d_val)) return SPRS_INVALID_ARGUMENT;
+    CtxLock lock(c);
     *out = nullptr;
     if (nrows >= INT32_MAX || ncols >= INT32_MAX || nnz >= INT32_MAX) return SPRS_INVALID_ARGUMENT;
     SPRS_HIP_TRY(c, hipSetDevice(c->device));
@@ -298,6 +300,7 @@ int mul_vec_host(const sprs_csr *A, const T *x, size_t x_len, T *y, size_t y_len
     if (A->dtype != dtype_of<T>::value) return SPRS_INVALID_ARGUMENT;
     if ((size_t)A->ncols != x_len || x_len != y_len) return SPRS_DIM_MISMATCH;   // mat.rs:50-52
     sprs_ctx *c = A->ctx;
+    CtxLock lock(c);   // x_tmp / y_tmp / part are per-handle staging: `&self` calls from several threads queue here
     SPRS_HIP_TRY(c, hipSetDevice(c->device));
     SPRS_TRY(ensure_tmp<T>(A));
     T *dx = (T *)A->x_tmp, *dy = (T *)A->y_tmp;
@@ -316,6 +319,7 @@ int mul_vec_dev(const sprs_csr *A, const T *dx, T *dy, T *dot_out) {
     if (!A || !dx || !dy) return SPRS_INVALID_ARGUMENT;
     if (A->dtype != dtype_of<T>::value) return SPRS_INVALID_ARGUMENT;
     sprs_ctx *c = A->ctx;
+    CtxLock lock(c);
     SPRS_HIP_TRY(c, hipSetDevice(c->device));
     if (!dot_out) return launch_spmv<T>(A, dx, dy, 0, nullptr, nullptr, nullptr, nullptr);
     SPRS_TRY(ensure_tmp<T>(A));
@@ -330,7 +334,9 @@ int mul_vec_timed(const sprs_csr *A, const T *dx, T *dy, int reps, double *ms) {
     if (A->dtype != dtype_of<T>::value) return SPRS_INVALID_ARGUMENT;
     sprs_ctx *c = A->ctx;
     SPRS_HIP_TRY(c, hipSetDevice(c->device));
-    hipEvent_t e0, e1;
+    CtxLock lock(c);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct Ev { hipEvent_t &a, &b; ~Ev() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } guard{e0, e1};   // every return path
     SPRS_HIP_TRY(c, hipEventCreate(&e0));
     SPRS_HIP_TRY(c, hipEventCreate(&e1));
     SPRS_HIP_TRY(c, hipEventRecord(e0, c->stream));
@@ -339,7 +345,6 @@ int mul_vec_timed(const sprs_csr *A, const T *dx, T *dy, int reps, double *ms) {
     SPRS_HIP_TRY(c, hipEventSynchronize(e1));
     float t = 0.f;
     SPRS_HIP_TRY(c, hipEventElapsedTime(&t, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *ms = (double)t / reps;
     return SPRS_OK;
 }
@@ -351,6 +356,7 @@ namespace {
 template <class V>
 int diag_create(sprs_ctx *c, size_t n, const V *diag_host, int t_dtype, sprs_diag **out) {
     if (!c || !out || (!diag_host && n)) return SPRS_INVALID_ARGUMENT;
+    CtxLock lock(c);
     *out = nullptr;
     SPRS_HIP_TRY(c, hipSetDevice(c->device));
     sprs_diag *P = new sprs_diag();
@@ -387,6 +393,7 @@ int diag_apply_host(const sprs_diag *Pc, const T *in, size_t in_len, T *out, siz
     if (Pc->n != in_len || Pc->n != out_len) return SPRS_DIM_MISMATCH;     // precond.rs:39-41
     sprs_diag *P = const_cast<sprs_diag *>(Pc);
     sprs_ctx *c = P->ctx;
+    CtxLock lock(c);   // in_tmp / out_tmp are per-handle staging
     SPRS_HIP_TRY(c, hipSetDevice(c->device));
     if (!P->in_tmp) SPRS_HIP_TRY(c, hipMalloc(&P->in_tmp, sizeof(T) * (P->n + 2)));
     if (!P->out_tmp) SPRS_HIP_TRY(c, hipMalloc(&P->out_tmp, sizeof(T) * (P->n + 2)));
@@ -441,6 +448,7 @@ template <class T, class SolverT>
 int solve_host(SolverT *s, const sprs_diag *P, const T *rhs, size_t rl, T *x, size_t xl, size_t max_iter, Real<T> tol,
                size_t *its, Real<T> *res) {
     if (!s || !rhs || !x) return SPRS_INVALID_ARGUMENT;
+    CtxLock lock(s->ctx);   // one solve at a time per context (its stream, its scratch)
     return s->solve_host(rhs, rl, x, xl, [&](T *drhs, T *dx) {
         return s->solve_dev(P, drhs, rl, dx, xl, max_iter, tol, its, res);
     });
@@ -454,6 +462,7 @@ int solve_dev(SolverT *s, const sprs_diag *P, const T *rhs, size_t rl, T *x, siz
     if (rl != s->n) return SPRS_INCOMPATIBLE_RHS_SIZE;
     if (xl != s->n) return SPRS_INCOMPATIBLE_X_SIZE;
     sprs_ctx *c = s->ctx;
+    CtxLock lock(c);
     const bool al = ((reinterpret_cast<uintptr_t>(rhs) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
     if (al) return s->solve_dev(P, rhs, rl, x, xl, max_iter, tol, its, res);
     SPRS_HIP_TRY(c, hipSetDevice(c->device));
@@ -537,6 +546,7 @@ int sprs_csr_wide_blocks(const sprs_csr *A, int64_t *n_blocks, int64_t *n_unifor
     *n_blocks = 0; *n_uniform = 0;
     if (!A->dict || !A->dict->wide_desc || A->dict->n_wide == 0) return SPRS_OK;
     sprs_ctx *c = A->ctx;
+    CtxLock lock(c);
     std::vector<int32_t> d((size_t)A->dict->n_wide * 4);
     SPRS_HIP_TRY(c, hipSetDevice(c->device));
     SPRS_HIP_TRY(c, hipMemcpyAsync(d.data(), A->dict->wide_desc, d.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

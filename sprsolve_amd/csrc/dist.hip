@@ -15,6 +15,7 @@
 // shares whichever librccl.so.1 the process — e.g. PyTorch — has already loaded).
 #include <dlfcn.h>
 #include <cstdlib>
+#include <mutex>
 #include <rccl/rccl.h>
 
 #include "device.hpp"
@@ -33,12 +34,18 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;   // optional (evidence only)
     bool ok = false;
 };
 
+void rccl_load(Rccl &r);
 Rccl &rccl() {
     static Rccl r;
-    if (r.so || r.ok) return r;
+    static std::once_flag once;     // two contexts created from two host threads must not race the dlopen
+    std::call_once(once, [] { rccl_load(r); });
+    return r;
+}
+void rccl_load(Rccl &r) {
     // SPRS_RCCL_LIB selects another build of the library (the tests point it at a shared-memory
     // stand-in so that several ranks can share the single GPU of a test box)
     if (const char *alt = getenv("SPRS_RCCL_LIB")) r.so = dlopen(alt, RTLD_NOW | RTLD_LOCAL);
@@ -46,7 +53,7 @@ Rccl &rccl() {
         if (r.so) break;
         r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
-    if (!r.so) return r;
+    if (!r.so) return;
 #define SPRS_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.so, sym))
     SPRS_SYM(GetUniqueId, "ncclGetUniqueId");
     SPRS_SYM(CommInitRank, "ncclCommInitRank");
@@ -58,10 +65,10 @@ Rccl &rccl() {
     SPRS_SYM(GroupStart, "ncclGroupStart");
     SPRS_SYM(GroupEnd, "ncclGroupEnd");
     SPRS_SYM(GetErrorString, "ncclGetErrorString");
+    SPRS_SYM(CommCount, "ncclCommCount");
 #undef SPRS_SYM
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.AllGather && r.Send && r.Recv && r.GroupStart &&
            r.GroupEnd && r.GetErrorString;
-    return r;
 }
 
 #define SPRS_NCCL_TRY(ctx, expr)                                                                        \
@@ -336,6 +343,14 @@ int sprs_comm_destroy(sprs_comm *comm) {
     if (comm->ctx) (void)hipStreamSynchronize(comm->ctx->stream);
     if (comm->nccl && rccl().ok) (void)rccl().CommDestroy((ncclComm_t)comm->nccl);
     delete comm;
+    return SPRS_OK;
+}
+
+int sprs_comm_count(const sprs_comm *comm, int *count_out) {
+    if (!comm || !count_out) return SPRS_INVALID_ARGUMENT;
+    *count_out = 0;
+    if (!rccl().ok || !rccl().CommCount) return SPRS_ERR_RCCL;
+    SPRS_NCCL_TRY(comm->ctx, rccl().CommCount((ncclComm_t)comm->nccl, count_out));   // what RCCL itself says, not comm->world
     return SPRS_OK;
 }
 

@@ -149,6 +149,7 @@ template <class T>
 int gs_solve_dev(sprs_gauss_seidel *G, const T *rhs, T *x, size_t max_iter, Real<T> eps, size_t *its_out, Real<T> *res_out) {
     using R = Real<T>;
     sprs_ctx *c = G->A->ctx;
+    CtxLock lock(c);
     const size_t n = (size_t)G->n;
     *its_out = 0; *res_out = 0;
     if (max_iter == 0) return SPRS_INSUFFICIENT_ITER;                       // :52-54
@@ -215,6 +216,7 @@ int gs_solve_host(sprs_gauss_seidel *G, const T *rhs, size_t rl, T *x, size_t xl
     if (rl != (size_t)G->n) return SPRS_INCOMPATIBLE_RHS_SIZE;              // :41-45
     if (rl != xl) return SPRS_INCOMPATIBLE_X_SIZE;                          // :46-50
     sprs_ctx *c = G->A->ctx;
+    CtxLock lock(c);
     SPRS_HIP_TRY(c, hipSetDevice(c->device));
     T *drhs = (T *)G->rhs_buf;
     T *dx = nullptr;

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/sprsolve_hip.h"
@@ -51,6 +52,17 @@ struct sprs_ctx {
     double *d_scal = nullptr;  // small device result buffer
     double *h_scal = nullptr;  // pinned host mirror
     mutable char err[512] = {0};
+    // Serialises every entry point that uses per-context or per-handle scratch (reduction partials, the pinned
+    // scalar mirror, the host-slice staging buffers) or that must see its own results on the single stream: the
+    // reference shares `&M` between threads (bicg_stab.rs:17-18 `T: Send + Sync`, mat.rs:156-161), so concurrent
+    // sprs_mul_vec_* / solves on handles of ONE context must be safe.  They are: they queue behind this mutex (the
+    // GPU runs one stream anyway); callers that want concurrency create one context per thread.  Recursive because
+    // the blocking entry points nest (a solve calls norm2_host, mul_vec_dot calls reduce_partials_host).
+    mutable std::recursive_mutex mu;
+};
+struct CtxLock {
+    std::unique_lock<std::recursive_mutex> lk;
+    explicit CtxLock(const sprs_ctx *c) { if (c) lk = std::unique_lock<std::recursive_mutex>(c->mu); }
 };
 
 #define SPRS_HIP_TRY(ctx, expr)                                                                     \

@@ -239,6 +239,7 @@ __global__ __launch_bounds__(BLOCK) void validate_cols_kernel(int64_t nnz, const
 int validate_cols_device(const sprs_csr *A) {
     sprs_ctx *c = A->ctx;
     if (A->nnz == 0) return SPRS_OK;
+    CtxLock lock(c);
     int *d_bad = reinterpret_cast<int *>(c->d_scal);
     SPRS_HIP_TRY(c, hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
     const int g = (int)std::min<int64_t>((A->nnz + BLOCK - 1) / BLOCK, 2048);

@@ -31,6 +31,12 @@ class Comm:
         pre_sync(dev)
         check(_lib.lib().sprs_comm_allreduce_sum_f64(self.h, dev_ptr(dev), int(count)), self.ctx.h)
 
+    def count(self):
+        """ncclCommCount: how many ranks RCCL itself sees on this communicator."""
+        n = C.c_int(0)
+        check(_lib.lib().sprs_comm_count(self.h, C.byref(n)), self.ctx.h)
+        return int(n.value)
+
     def close(self):
         if self.h:
             _lib.lib().sprs_comm_destroy(self.h)
@@ -133,5 +139,12 @@ def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, t
     per_nnz = {0: 12, 1: 9, 2: 1}[mode]
     sinfo = dict(stream={0: "csr", 1: "offset-codes", 2: "pair-codes"}[mode], mode=mode, distinct_offsets=n_off,
                  distinct_pairs=n_pair, bytes_per_nnz=per_nnz,
-                 format_bytes_per_launch=nnz_loc * per_nnz + (n_loc + 1) * 4 + 2 * n_loc * 8)
-    return dt, prof, t_spmv, bs, check_, nx * ny * nz, int(tot), sinfo
+                 format_bytes_per_launch=nnz_loc * per_nnz + (n_loc + 1) * 4 + 2 * n_loc * 8, rows=n_loc, nnz=nnz_loc)
+    # evidence that the collectives really span `world` ranks, and what each rank moves per SpMV
+    halo_b = int(plan["n_ext"] - n_loc) * 8 if exchange != "allgather" else int(plan["slice"]) * (world - 1) * 8
+    send_b = int(plan["send_off"][-1]) * 8 if exchange != "allgather" else int(plan["slice"]) * 8
+    per_rank = gather(dict(rank=rank, rccl_ranks=comm.count(), halo_recv_bytes=halo_b, halo_send_bytes=send_b,
+                           peers=[int(p) for p in plan["peers"]], rows=n_loc, nnz=nnz_loc))
+    dist_info = dict(rccl_ranks=min(p["rccl_ranks"] for p in per_rank), exchange=exchange,
+                     halo_bytes=[p["halo_recv_bytes"] for p in per_rank], per_rank=per_rank)
+    return dt, prof, t_spmv, bs, check_, nx * ny * nz, int(tot), sinfo, dist_info

@@ -25,6 +25,25 @@ def splitmix64(seed, n, stream=0):
     return z
 
 
+def splitmix64_keys(seed, keys, stream=0):
+    """splitmix64 at arbitrary counters: output i = mix(seed + stream*C + (keys[i]+1)*gamma); equals splitmix64(seed, n)
+    for keys = arange(n).  Lets a generator key its randomness on (row, slot) so that a row block of a partitioned
+    matrix gets the same values as the whole matrix."""
+    with np.errstate(over="ignore"):
+        gamma = np.uint64(0x9E3779B97F4A7C15)
+        base = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + np.uint64(stream) * np.uint64(0xD1B54A32D192ED03)
+        z = base + ((np.asarray(keys).astype(np.uint64) + np.uint64(1)) * gamma)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform_keys(seed, keys, lo=-1.0, hi=1.0, stream=0):
+    u = (splitmix64_keys(seed, keys, stream) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return lo + (hi - lo) * u
+
+
 def uniform(seed, n, lo=-1.0, hi=1.0, stream=0):
     """U[lo,hi) doubles from the top 53 bits of splitmix64."""
     u = (splitmix64(seed, n, stream) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
@@ -210,10 +229,13 @@ def symmetric_banded(n, hbw=4, seed=SEED):
     return indptr, indices, data, rhs
 
 
-def poisson3d(nx, ny, nz, z0=0, z1=None, index_dtype=np.int32):
+def poisson3d(nx, ny, nz, z0=0, z1=None, index_dtype=np.int32, values="poisson", seed=SEED):
     """cfg 5: 7-point 3-D Poisson on an nx*ny*nz grid (x fastest), diag +6, neighbours -1,
     truncated at the faces.  Returns the CSR row block for planes [z0, z1) with GLOBAL column
-    indices, and rhs = A*1 (row sums) for those rows.  Columns ascending within a row."""
+    indices, and rhs = A*1 (row sums) for those rows.  Columns ascending within a row.
+    values="random": the same pattern with variable coefficients — off-diagonal (row g, slot j) = U(-1,1) keyed on
+    g*7 + j (stream 50), diagonal = 1 + sum |off-diagonals of the row| (strictly dominant), rhs = A*1 summed left to
+    right over the row's entries in column order."""
     if z1 is None:
         z1 = nz
     plane = nx * ny
@@ -221,9 +243,22 @@ def poisson3d(nx, ny, nz, z0=0, z1=None, index_dtype=np.int32):
     x = g % nx; y = (g // nx) % ny; z = g // plane
     cand = np.stack([g - plane, g - nx, g - 1, g, g + 1, g + nx, g + plane], axis=1)
     ok = np.stack([z > 0, y > 0, x > 0, np.ones_like(g, dtype=bool), x < nx - 1, y < ny - 1, z < nz - 1], axis=1)
-    vals = np.broadcast_to(np.array([-1.0, -1.0, -1.0, 6.0, -1.0, -1.0, -1.0]), cand.shape)
     cnt = ok.sum(axis=1)
     indptr = np.zeros(g.size + 1, dtype=np.int64); np.cumsum(cnt, out=indptr[1:])
-    indices = cand[ok]; data = np.ascontiguousarray(vals[ok])
-    rhs = 6.0 - (cnt - 1).astype(np.float64)
+    indices = cand[ok]
+    if values == "random":
+        vals = uniform_keys(seed, g[:, None] * 7 + np.arange(7)[None, :], stream=50)
+        vals = np.where(ok, vals, 0.0)
+        vals[:, 3] = 0.0
+        acc = np.zeros(g.size)
+        for j in range(7):                      # explicit slot order (numpy's axis sum is free to re-associate)
+            acc = acc + np.abs(vals[:, j])
+        vals[:, 3] = 1.0 + acc
+        rhs = np.zeros(g.size)
+        for j in range(7):                      # left-to-right row sum in column order (absent slots add 0.0 exactly)
+            rhs = rhs + vals[:, j]
+    else:
+        vals = np.broadcast_to(np.array([-1.0, -1.0, -1.0, 6.0, -1.0, -1.0, -1.0]), cand.shape)
+        rhs = 6.0 - (cnt - 1).astype(np.float64)
+    data = np.ascontiguousarray(vals[ok])
     return indptr.astype(index_dtype if indptr[-1] < 2**31 else np.int64), indices.astype(index_dtype), data, rhs

@@ -116,6 +116,7 @@ ncclResult_t ncclCommInitRank(void **comm, int nranks, ncclUniqueId id, int rank
     return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const void *comm, int *count) { *count = ((const Comm *)comm)->n; return ncclSuccess; }
 ncclResult_t ncclCommDestroy(void *comm) {
     Comm *c = (Comm *)comm;
     if (!c) return ncclSuccess;

@@ -62,3 +62,25 @@ def test_torch_generators_match_numpy():
     assert np.array_equal(tip.numpy(), ip) and np.array_equal(tix.numpy(), ix) and np.array_equal(td.numpy(), d)
     assert np.array_equal(trhs.numpy(), gen.dirichlet_rhs(13, 13))
     assert np.array_equal(tdiag.numpy(), np.where(np.diff(ip) == 1, 1.0, -4.0))
+
+
+def test_random_value_poisson3d():
+    """cfg-5 pattern with variable coefficients (bench.py's also.cfg5_random_values): keyed on (row, slot), so a
+    z-slab of the partitioned matrix carries the same values as the whole; strictly dominant diagonal; the torch twin
+    is bit-identical."""
+    from sprsolve_amd import gen_torch
+    ip, ix, d, rhs = gen.poisson3d(7, 6, 5, values="random")
+    ip0, ix0, d0, _ = gen.poisson3d(7, 6, 5)
+    assert np.array_equal(ip, ip0) and np.array_equal(ix, ix0) and not np.array_equal(d, d0)
+    A = sp.csr_matrix((d, ix, ip))
+    off = A - sp.diags(A.diagonal())
+    assert np.all(A.diagonal() > abs(off).sum(axis=1).A1)          # strict row dominance
+    assert np.allclose(A @ np.ones(210), rhs, rtol=0, atol=1e-14)
+    assert np.unique(d).size > 0.9 * d.size                          # no value dictionary to be had
+    ip2, ix2, d2, rhs2 = gen.poisson3d(7, 6, 5, 2, 4, values="random")
+    assert np.array_equal(d2, d[ip[84]:ip[168]]) and np.array_equal(rhs2, rhs[84:168])
+    tip, tix, td, trhs = gen_torch.poisson3d(7, 6, 5, 1, 4, device="cpu", values="random")
+    ip3, ix3, d3, rhs3 = gen.poisson3d(7, 6, 5, 1, 4, values="random")
+    assert np.array_equal(tip.numpy(), ip3) and np.array_equal(tix.numpy(), ix3)
+    assert np.array_equal(td.numpy(), d3) and np.array_equal(trhs.numpy(), rhs3)
+    assert np.array_equal(gen.splitmix64_keys(gen.SEED, np.arange(16)), gen.splitmix64(gen.SEED, 16))

@@ -71,3 +71,29 @@ def test_real_ranks_match_single_process(oracle, mock_lib, world, kind, exchange
         x = np.concatenate([r["x_pc"] for r in res])
         assert np.max(np.abs(x - refpc.x)) <= 1e-7
         assert len({int(r["its_pc"]) for r in res}) == 1
+
+
+def test_bench_launches_its_own_ranks(mock_lib):
+    """`python bench.py --gpus 2` with NO launcher around it (how the driver starts the scaling bench): the parent
+    must start the two ranks itself, relay rank 0's one JSON line and return 0.  Two ranks share this box's single GPU
+    (SPRS_BENCH_DEVICE) through the mock RCCL; gloo bootstraps."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, SPRS_RCCL_LIB=mock_lib, SPRS_BENCH_DEVICE="0", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--grid", "64x48x32",
+                        "--steps", "6", "--warmup", "2", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=420)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong"
+    assert d["rccl_ranks"] == 2 and len(d["halo_bytes"]) == 2 and all(b == 64 * 48 * 8 for b in d["halo_bytes"])
+    assert d["roofline"]["frac"] <= 1.0 and d["converge_check"]["max_abs_err_vs_exact"] < 1e-5
+    # a failing rank must fail the parent
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--grid", "64x48x32",
+                        "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--set", "no_such_knob=1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    assert p.returncode != 0 and not p.stdout.strip()

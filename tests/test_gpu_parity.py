@@ -340,8 +340,31 @@ def test_solver_trace_lockstep(sa, oracle, case, mode):
         # its=1 is noise and the trajectories part from there.  Lock-step is then only
         # defined for the unrolled iteration and the residual norm it leaves behind.
         assert np.allclose(tr[0], ref.trace[0], rtol=TRACE_RTOL, atol=0)
+        # row 1 in full: rho is a residue (1.4e-9 against 5e6) but the SAME residue — the few non-zero products are
+        # added in the same order — so alpha = rho / (r0.v), w and |r| agree to rounding as well
         assert np.isclose(tr[1][1], ref.trace[1][1], rtol=TRACE_RTOL)
-        assert abs(tr[1][2]) <= 1e-9 * ref.trace[0][2]          # a rounding residue in both
+        assert abs(tr[1][2]) <= 1e-9 * ref.trace[0][2]
+        assert np.allclose(tr[1][[4, 6]], ref.trace[1][[4, 6]], rtol=TRACE_RTOL, atol=0)
+        # from row 2 on, lock-step until the first LEGITIMATELY ill-conditioned branch: the trajectories may part only
+        # at a row whose rho is a cancellation residue on at least one side (|rho| < 1e-10 |r0| |r|: that is where
+        # bicg_stab.rs:131 compares it with (|r0| eps)^2 — on the 100x100 bench problem the oracle gets 4.4e-25, just
+        # above the threshold 2.6e-25, the GPU's summation order lands below it and restarts), and |r| of that row —
+        # computed before the branch — must still agree.  Rows before it must agree in every column.
+        r0n = ref.trace[0][1]
+        scale = np.maximum(np.max(np.abs(ref.trace), axis=0), 1e-300)
+        parted = None
+        for k in range(2, K):
+            if np.all(np.abs(tr[k] - ref.trace[k]) <= 1e-7 * scale):
+                continue
+            parted = k
+            break
+        if parted is not None:
+            k = parted
+            assert np.isclose(tr[k][1], ref.trace[k][1], rtol=1e-7), (k, tr[k], ref.trace[k])
+            residue = 1e-10 * r0n * ref.trace[k][1]
+            assert min(abs(tr[k][2]), abs(ref.trace[k][2])) < residue, (k, tr[k], ref.trace[k])
+        else:
+            assert np.max(np.abs(x - ref.x)) / max(1.0, np.max(np.abs(ref.x))) < 1e-7
         return
     # complex scalars: compare against the magnitude of the (re, im) pair, not of each part
     scale = np.maximum(np.max(np.abs(ref.trace), axis=0), 1e-300)
@@ -483,6 +506,111 @@ def test_csminres_complex_symmetric(sa, oracle, mode):
         tr = s.trace()
         assert np.allclose(tr, reft.trace, rtol=TRACE_RTOL, atol=1e-12)
         s.set_trace(0)
+
+
+@pytest.mark.parametrize("mode", ["fused", "literal"])
+@pytest.mark.parametrize("name", ["test_minres", "minres_ident"])
+def test_csminres_is_minres_for_real_scalars(sa, oracle, name, mode):
+    """Pins the shared Saunders code path on reference-held fixtures: for real T cs_minres.rs is arithmetically
+    minres.rs (conj = identity), so `csminres_d` must reproduce `minres_d` BIT FOR BIT — trace and x — on the
+    reference's two MINRES problems (tests/test_minres.rs:1-60), and both follow the oracle in lock-step."""
+    case = [c for c in G.load("solver_kat.json")["cases"] if c["name"] == name][0]
+    p = G.solver_problem(case)
+    n = p["rhs"].size
+    A = sa.HipCsr.new((n, n), p["indptr"], p["indices"], p["data"])
+    K = 24
+    got = {}
+    for cls in (sa.MinRes, sa.CSMinRes):
+        s = cls.new(A, n); s.set_mode(mode); s.set_trace(K)
+        x = np.zeros(n)
+        try:
+            s.solve(p["rhs"], x, K, 0.0)
+        except sa.error.InsufficientIterNum:
+            pass
+        got[cls.__name__] = (s.trace(), x.copy())
+    (ta, xa), (tb, xb) = got["MinRes"], got["CSMinRes"]
+    assert ta.shape == tb.shape and ta.shape[0] == K
+    assert np.array_equal(ta.view(np.uint64), tb.view(np.uint64))
+    assert np.array_equal(bits(xa), bits(xb))
+    ref = oracle.csminres(p["indptr"], p["indices"], p["data"], p["rhs"], np.zeros(n), K, 0.0, trace_cap=K)
+    # lock-step with the oracle while the recurrence residual is above rounding level (after convergence the Lanczos
+    # vectors are normalised noise; minres_ident converges exactly and its later rows are 0/0)
+    ok = np.isfinite(ref.trace).all(axis=1) & (ref.trace[:, 7] > 1e-7 * ref.trace[0, 7])
+    assert ok.sum() >= 4
+    assert np.allclose(tb[ok], ref.trace[ok], rtol=1e-6, atol=1e-12)
+    # to convergence, reference tolerance: same iteration count, same bits
+    res = {}
+    for cls in (sa.MinRes, sa.CSMinRes):
+        s = cls.new(A, n); s.set_mode(mode)
+        x = np.zeros(n)
+        res[cls.__name__] = s.solve(p["rhs"], x, case["max_iter"], case["tol"]) + (x.copy(),)
+    assert res["MinRes"][:2] == res["CSMinRes"][:2]
+    assert np.array_equal(bits(res["MinRes"][2]), bits(res["CSMinRes"][2]))
+    assert np.max(np.abs(res["CSMinRes"][2] - p["exact"])) < 1e-9
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES, ids=ALL_IDS)
+def test_copy_and_zero_direct(sa, dtype):
+    """a12 — the reference's `ptr::copy_nonoverlapping` (bicg_stab.rs:78,91,140; minres.rs:77,156) and zero fill
+    (minres.rs:86-88, bicg_stab.rs:58) as their own entry points: sprs_memcpy_d2d / sprs_memset_zero, every scalar
+    type, odd lengths and unaligned offsets, neighbours untouched."""
+    import ctypes as C
+
+    from sprsolve_amd import _lib
+    L = _lib.lib()
+    ctx = sa.default_ctx(0)
+    isz = np.dtype(dtype).itemsize
+    for n in (1, 63, 1000, 4097):
+        src = rand_vec(n + 8, dtype, 11)
+        a = sa.DevVec.from_numpy(src); b = sa.DevVec.from_numpy(rand_vec(n + 8, dtype, 12))
+        before = b.to_numpy()
+        for off in (0, 3):
+            st = L.sprs_memcpy_d2d(ctx.h, C.c_void_p(b.ptr.value + off * isz), C.c_void_p(a.ptr.value + (off + 1) * isz), n * isz)
+            assert st == 0
+            ctx.sync()
+            got = b.to_numpy()
+            assert np.array_equal(bits(got[off:off + n]), bits(src[off + 1:off + 1 + n]))
+            assert np.array_equal(bits(got[off + n:]), bits(before[off + n:])) and np.array_equal(bits(got[:off]), bits(before[:off]))
+            before = got
+        st = L.sprs_memset_zero(ctx.h, C.c_void_p(b.ptr.value + 2 * isz), (n - 1) * isz)
+        assert st == 0
+        ctx.sync()
+        got = b.to_numpy()
+        assert not np.any(bits(got[2:2 + n - 1])) and np.array_equal(bits(got[:2]), bits(before[:2]))
+        assert np.array_equal(bits(got[n + 1:]), bits(before[n + 1:]))
+        a.free(); b.free()
+
+
+def test_malformed_host_matrix_is_refused(sa):
+    """A matrix whose arrays would make a kernel read outside x / val must be refused at creation with
+    SPRS_INVALID_ARGUMENT — never reach a launch.  Covers the off-by-one that a page-boundary fault looks like
+    (column == ncols: one element past x), negative columns, a decreasing row_ptr, row_ptr[n] != nnz — for the plain
+    and for the dictionary-compressed stream (same creation path), CSR and CSC."""
+    from sprsolve_amd import gen
+    indptr, indices, data = gen.grid_laplacian_dirichlet(12, 12)
+    n = 144
+
+    def refused(ip, ix, dv, **kw):
+        with pytest.raises(ValueError):
+            sa.HipCsr.new((n, n), ip, ix, dv, **kw)
+    for stream in (0, -1):
+        sa.default_ctx(0).set("spmv_dict", stream)
+        try:
+            bad = indices.copy(); bad[len(bad) // 2] = n            # one past the end of x
+            refused(indptr, bad, data)
+            bad = indices.copy(); bad[0] = -1
+            refused(indptr, bad, data)
+            ipb = indptr.copy(); ipb[50] = ipb[51] + 2              # decreasing row_ptr
+            refused(ipb, indices, data)
+            ipb = indptr.copy(); ipb[-1] += 1                       # row_ptr[n] != nnz: the last row would run past val
+            refused(ipb, indices, data)
+            refused(indptr.astype(np.int64), np.where(np.arange(indices.size) == 7, 2**31 + 5, indices.astype(np.int64)), data)
+            bad = indices.copy(); bad[5] = n
+            refused(indptr, bad, data, storage="CSC")
+            A = sa.HipCsr.new((n, n), indptr, indices, data)      # the well-formed one is accepted
+            assert A.nnz() == int(indptr[-1])
+        finally:
+            sa.default_ctx(0).set("spmv_dict", -1)
 
 
 def test_device_resident_solve(sa, oracle):

@@ -95,3 +95,26 @@ def test_solver_kat(oracle, case):
     # true residual
     res = np.linalg.norm(oracle.spmv(p["indptr"], p["indices"], p["data"], r.x) - p["rhs"]) / np.linalg.norm(p["rhs"])
     assert res < 1e-10, res
+
+
+@pytest.mark.parametrize("name", ["test_minres", "minres_ident"])
+def test_csminres_is_minres_for_real_scalars(oracle, name):
+    """CSMinRes has no test in the reference (tests/test_minres.rs:14-15 are commented out).  For REAL T `conj` is the
+    identity, so cs_minres.rs:90-154 is arithmetically minres.rs:90-169 — same Lanczos products in the same order,
+    same Givens formulas.  The oracle's two restatements must therefore agree BIT FOR BIT on the reference's own two
+    MINRES problems (tests/test_minres.rs:1-60): that ties the Saunders code path to reference-held fixtures.  The
+    complex-symmetric branch (conjugations live) stays "parity unpinned"."""
+    case = [c for c in G.load("solver_kat.json")["cases"] if c["name"] == name][0]
+    p = G.solver_problem(case)
+    K = 40
+    a = oracle.minres(p["indptr"], p["indices"], p["data"], p["rhs"], np.zeros_like(p["rhs"]), K, 0.0, trace_cap=K)
+    b = oracle.csminres(p["indptr"], p["indices"], p["data"], p["rhs"], np.zeros_like(p["rhs"]), K, 0.0, trace_cap=K)
+    assert a.status == b.status and a.its == b.its
+    assert a.trace.shape == b.trace.shape and a.trace.shape[0] > 0
+    assert np.array_equal(a.trace.view(np.uint64), b.trace.view(np.uint64))
+    assert np.array_equal(a.x.view(np.uint64), b.x.view(np.uint64))
+    # and to convergence with the reference's own tolerance
+    a = oracle.minres(p["indptr"], p["indices"], p["data"], p["rhs"], np.zeros_like(p["rhs"]), case["max_iter"], case["tol"])
+    b = oracle.csminres(p["indptr"], p["indices"], p["data"], p["rhs"], np.zeros_like(p["rhs"]), case["max_iter"], case["tol"])
+    assert (a.status, a.its, a.res) == (b.status, b.its, b.res) and a.status == oracle.OK
+    assert np.array_equal(a.x.view(np.uint64), b.x.view(np.uint64))
