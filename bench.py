@@ -141,13 +141,14 @@ def pmc_traffic(key):
     """HBM-side bytes per SpMV launch from the committed rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE passes
     of this bench command, gfx950 x2 FETCH correction) — measured off-line, so it goes stale when the kernel changes:
     the file records the commit it was taken at."""
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r02_pmc_summary.json",):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
-                pm = json.load(f).get(key, {}).get("spmv_in_solve")
+                ent = json.load(f).get(key, {})
+            pm = ent.get("spmv_in_solve")
             if pm:
-                return pm["traffic_bytes"], "profiles/%s[%s]: %s" % (name, key, pm["note"])
+                return pm["traffic_bytes"], "profiles/%s[%s] (taken at commit %s): %s" % (name, key, ent.get("commit"), pm["note"])
     return None, "no PMC summary found"
 
 
@@ -476,7 +477,7 @@ def main():
                 tl = p_csr["spmv_ms_total"] / max(p_csr["spmv_launches"], 1) * 1e-3
                 csr_info = dict(stream="csr", mode=0, bytes_per_nnz=12, format_bytes_per_launch=bs)
                 roof_csr = roofline_of(csr_info, tl, p_csr["spmv_launches"], n, nnz)
-                roof_csr["traffic"], roof_csr["traffic_note"] = pmc_traffic("bench_csr")
+                roof_csr["traffic"], roof_csr["traffic_note"] = pmc_traffic("cfg5_csr")
                 if roof_csr["traffic"]:
                     roof_csr["traffic_over_algorithmic"] = roof_csr["traffic"] / bs
                 also["cfg5_plain_csr_stream"] = dict(
@@ -500,6 +501,8 @@ def main():
                 its_r, res_r = sr.solve(rhsr, xr, 5000, 1e-8)
                 err_r = float((xr - 1.0).abs().max().item())
                 rr = roofline_of(sinfo_r, tlr, p_r["spmv_launches"], n, nnz)
+                if (nx, ny, nz) == (500, 500, 200) and sinfo_r["mode"] == 1:
+                    rr["traffic"], rr["traffic_note"] = pmc_traffic("cfg5_random")
                 also["cfg5_random_values"] = dict(
                     workload="the cfg-5 pattern (500x500x200 7-point) with off-diagonals U(-1,1) and diagonal 1 + sum|row off-diagonals| "
                              "(splitmix64 by nnz position), rhs = A*1, BiCGStab tol=0 fixed %d iterations" % k_r,
@@ -518,8 +521,8 @@ def main():
         n_rank = sinfo.get("rows", n_glob)
         nnz_rank = sinfo.get("nnz", nnz_glob)
         roof = roofline_of(sinfo, t_spmv, prof["spmv_launches"], n_rank, nnz_rank)
-        if world == 1 and (nx, ny, nz) == (500, 500, 200) and args.values == "poisson":
-            roof["traffic"], roof["traffic_note"] = pmc_traffic({0: "bench_csr", 1: "bench_offsets", 2: "bench_pair"}[sinfo["mode"]])
+        if world == 1 and (nx, ny, nz) == (500, 500, 200):
+            roof["traffic"], roof["traffic_note"] = pmc_traffic({0: "cfg5_csr", 1: "cfg5_random", 2: "cfg5_pair"}[sinfo["mode"]])
         roof["note"] = ("per rank; `achieved` / `frac` = the bytes this kernel's stream must move (x, y once; row_ptr; %d B per nnz) / mean "
                         "launch time (HIP events on the solver's stream, inside the timed solve)" % sinfo["bytes_per_nnz"]
                         + ("; the kernel is bound by the CUs' vector-memory issue and gather latency, not by HBM (DESIGN.md §3)" if sinfo["mode"] == 2 else "")

@@ -340,6 +340,23 @@ int sprs_dist_csr_create_dev_z(sprs_comm *comm, int64_t n_local, int64_t n_ext, 
  * x slices (each padded to `slice` >= max n_local elements, the same value on every rank).  Column indices
  * address the gathered vector: col = owner_rank * slice + (global_col - first_row_of_owner).  Moves
  * world*slice elements per SpMV (400 MB for cfg 5) — kept for comparison; the sparse halo is the default. */
+/* The same operator from GLOBAL column indices — the exchange plan is derived inside the library (device passes +
+ * one ncclAllGather of the per-peer counts + one ncclSend/ncclRecv group of the index lists), which is what a host
+ * without numpy (the Rust binding) calls.  Collective over comm.  row_starts[world + 1] (host, identical on all ranks):
+ * rank r owns rows / x entries [row_starts[r], row_starts[r+1]); dev_col_idx_global (device, i32[nnz]) holds global
+ * column numbers and is renumbered IN PLACE into the rank's extended numbering when adopt != 0 (into a private copy
+ * otherwise).  exchange: 0 = sparse halo (only the referenced remote entries travel, from the ranks that own them),
+ * 1 = north_star's literal ncclAllGather of every rank's x slice.  Temporary device memory: 5 bytes per global column.
+ * SPRS_INVALID_ARGUMENT when a column index is outside [0, row_starts[world]). */
+int sprs_dist_csr_create_global_dev_d(sprs_comm *comm, const int64_t *row_starts, int64_t nnz, const int32_t *dev_row_ptr, int32_t *dev_col_idx_global, const double *dev_val, int adopt, int exchange, sprs_csr **out);
+int sprs_dist_csr_create_global_dev_z(sprs_comm *comm, const int64_t *row_starts, int64_t nnz, const int32_t *dev_row_ptr, int32_t *dev_col_idx_global, const sprs_c64 *dev_val, int adopt, int exchange, sprs_csr **out);
+int sprs_dist_csr_create_global_dev_s(sprs_comm *comm, const int64_t *row_starts, int64_t nnz, const int32_t *dev_row_ptr, int32_t *dev_col_idx_global, const float *dev_val, int adopt, int exchange, sprs_csr **out);
+int sprs_dist_csr_create_global_dev_c(sprs_comm *comm, const int64_t *row_starts, int64_t nnz, const int32_t *dev_row_ptr, int32_t *dev_col_idx_global, const sprs_c32 *dev_val, int adopt, int exchange, sprs_csr **out);
+/* The plan of a distributed operator, read back (tests, bench evidence): sizes; then peer ranks and element offsets
+ * (arrays of cap >= n_peers and n_peers + 1 entries); then the local indices this rank packs, grouped by peer. */
+int sprs_dist_csr_info(const sprs_csr *A, int64_t *n_local, int64_t *n_ext, int *n_peers, int64_t *send_entries, int64_t *recv_entries);
+int sprs_dist_csr_peers(const sprs_csr *A, int cap, int32_t *peer_rank, int64_t *send_off, int64_t *recv_off);
+int sprs_dist_csr_send_idx(const sprs_csr *A, int64_t cap, int32_t *send_idx_host);
 int sprs_dist_csr_create_allgather_dev_d(sprs_comm *comm, int64_t n_local, int64_t slice, int64_t nnz, const int32_t *dev_row_ptr, const int32_t *dev_col_idx_gathered, const double *dev_val, int adopt, sprs_csr **out);
 int sprs_dist_csr_create_allgather_dev_z(sprs_comm *comm, int64_t n_local, int64_t slice, int64_t nnz, const int32_t *dev_row_ptr, const int32_t *dev_col_idx_gathered, const sprs_c64 *dev_val, int adopt, sprs_csr **out);
 int sprs_dist_csr_create_allgather_dev_s(sprs_comm *comm, int64_t n_local, int64_t slice, int64_t nnz, const int32_t *dev_row_ptr, const int32_t *dev_col_idx_gathered, const float *dev_val, int adopt, sprs_csr **out);

@@ -3,7 +3,7 @@
 
   usage: python scripts/make_pmc_summary.py <fetch_dir> <write_dir> <key> [summary.json]
 
-Adds / replaces the entry <key> of profiles/r01_pmc_summary.json with, per kernel: launches, median
+Adds / replaces the entry <key> of profiles/r02_pmc_summary.json with, per kernel: launches, median
 FETCH_SIZE / WRITE_SIZE (KiB per dispatch), average duration, and for the dominant SpMV kernel the
 corrected traffic: 2 * FETCH_SIZE (gfx950 counts 128-B fabric requests at 64 B; calibrated 0.510 / 0.509,
 see "calibration" in the same file) + WRITE_SIZE."""
@@ -50,7 +50,7 @@ def short(name):
 def main():
     fetch_dir, write_dir, key = sys.argv[1:4]
     out_path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                                     "profiles", "r01_pmc_summary.json")
+                                                                     "profiles", "r02_pmc_summary.json")
     fe, wr, du = read_counter(fetch_dir, "FETCH_SIZE"), read_counter(write_dir, "WRITE_SIZE"), read_durations(fetch_dir)
     kernels = {}
     for k in sorted(set(fe) | set(wr)):
@@ -71,6 +71,15 @@ def main():
                                       note="launch-weighted mean over the in-solve SpMV launches; 2*FETCH_SIZE + WRITE_SIZE; "
                                            "L2->fabric bytes, Infinity-Cache hits included (upper bound on HBM bytes)")
     summary = json.load(open(out_path)) if os.path.exists(out_path) else {}
+    summary.setdefault("units", "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (rocprofv3 --pmc, one counter per pass); traffic_bytes = "
+                       "2 * FETCH_SIZE + WRITE_SIZE in bytes (gfx950 tallies 128-B fabric read requests at 64 B: MI355X_MICROARCH.md "
+                       "§HBM; calibration in r01_pmc_summary.json)")
+    import subprocess
+    try:
+        entry["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(out_path),
+                                                  stderr=subprocess.DEVNULL, text=True).strip()
+    except Exception:       # the GPU box has no .git: the commit is filled in when the summary is copied into profiles/
+        entry["commit"] = None
     summary[key] = entry
     json.dump(summary, open(out_path, "w"), indent=1)
     print(json.dumps(entry.get("spmv_in_solve", {}), indent=1))

@@ -119,6 +119,10 @@ def _protos():
         P["sprs_dist_csr_create_dev_" + s] = [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _pp]
         P["sprs_dist_mul_vec_dev_" + s] = [_vp, _vp, _vp]
         P["sprs_dist_csr_create_allgather_dev_" + s] = [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _pp]
+        P["sprs_dist_csr_create_global_dev_" + s] = [_vp, _vp, _i64, _vp, _vp, _vp, _int, _int, _pp]
+    P["sprs_dist_csr_info"] = [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int), C.POINTER(_i64), C.POINTER(_i64)]
+    P["sprs_dist_csr_peers"] = [_vp, _int, _vp, _vp, _vp]
+    P["sprs_dist_csr_send_idx"] = [_vp, _i64, _vp]
     P["sprs_csr_stream_format"] = [_vp, C.POINTER(_int), C.POINTER(_int)]
     P["sprs_csr_wide_blocks"] = [_vp, C.POINTER(_i64), C.POINTER(_i64)]
     P["sprs_gauss_seidel_create"] = [_vp, _pp]

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <rccl/rccl.h>
+#include <rocprim/device/device_scan.hpp>
 
 #include "device.hpp"
 
@@ -306,9 +307,218 @@ int dist_csr_create_allgather(sprs_comm *comm, int64_t n_local, int64_t slice, i
     *out = A;
     return SPRS_OK;
 }
+// ---------------------------------------------------------------------------------------------
+// Exchange plan from GLOBAL column indices, behind the C ABI (a Rust host has no numpy): the plan that
+// sprsolve_amd/partition.py derives on the host, derived here on the device and over RCCL.
+//   1. mark[g] = 1 for every remote column g the local rows reference (one byte per global column);
+//   2. exclusive scan of mark -> the position of g in the sorted list of needed columns == its offset in the halo
+//      tail (peers ascending, indices ascending within a peer == global ascending order);
+//   3. columns renumbered in place: owned g -> g - r0, remote g -> n_local + pos[g];
+//   4. the needed list is split by owner on the host (it is the halo, small), the per-peer counts travel in one
+//      ncclAllGather, the index lists in one group of ncclSend / ncclRecv; what arrives is what this rank must pack.
+// Temporary device memory: 5 bytes per GLOBAL column (cfg 5: 250 MB of the 288 GB), freed before returning.
+// PLAN_TRY frees the temporaries on every error path.
+#define PLAN_TRY(expr) do { const int st__ = (expr); if (st__ != SPRS_OK) { cleanup(); return st__; } } while (0)
+#define PLAN_HIP(expr) do { const hipError_t e__ = (expr); if (e__ != hipSuccess) { snprintf(c->err, sizeof(c->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); cleanup(); return SPRS_ERR_HIP; } } while (0)
+#define PLAN_NCCL(expr) do { const ncclResult_t e__ = (expr); if (e__ != ncclSuccess) { snprintf(c->err, sizeof(c->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, rccl().GetErrorString(e__)); cleanup(); return SPRS_ERR_RCCL; } } while (0)
+
+__global__ __launch_bounds__(sprs::BLOCK) void plan_mark_kernel(int64_t nnz, const int32_t *__restrict__ col, int32_t r0, int32_t r1,
+                                                                int32_t n_global, uint8_t *__restrict__ mark, int *__restrict__ bad) {
+    int local = 0;
+    for (int64_t k = (int64_t)blockIdx.x * sprs::BLOCK + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * sprs::BLOCK) {
+        const int32_t g = col[k];
+        if (g < 0 || g >= n_global) { local = 1; continue; }
+        if (g < r0 || g >= r1) mark[g] = 1;      // benign race: every writer stores the same byte
+    }
+    if (local) atomicOr(bad, 1);
+}
+__global__ __launch_bounds__(sprs::BLOCK) void plan_compact_kernel(int32_t n_global, const uint8_t *__restrict__ mark,
+                                                                   const int32_t *__restrict__ pos, int32_t *__restrict__ uniq) {
+    for (int64_t g = (int64_t)blockIdx.x * sprs::BLOCK + threadIdx.x; g < n_global; g += (int64_t)gridDim.x * sprs::BLOCK)
+        if (mark[g]) uniq[pos[g]] = (int32_t)g;
+}
+__global__ __launch_bounds__(sprs::BLOCK) void plan_renumber_kernel(int64_t nnz, const int32_t *__restrict__ col_in, int32_t *__restrict__ col_out,
+                                                                    int32_t r0, int32_t r1, const int32_t *__restrict__ pos) {
+    const int32_t n_local = r1 - r0;
+    for (int64_t k = (int64_t)blockIdx.x * sprs::BLOCK + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * sprs::BLOCK) {
+        const int32_t g = col_in[k];
+        col_out[k] = (g < r0 || g >= r1) ? n_local + pos[g] : g - r0;
+    }
+}
+// all-gather numbering: [rank 0 slice | rank 1 slice | ...], slices padded to `slice`
+__global__ __launch_bounds__(sprs::BLOCK) void plan_renumber_ag_kernel(int64_t nnz, const int32_t *__restrict__ col_in, int32_t *__restrict__ col_out,
+                                                                       int world, const int64_t *__restrict__ starts, int64_t slice,
+                                                                       int *__restrict__ bad) {
+    int local = 0;
+    for (int64_t k = (int64_t)blockIdx.x * sprs::BLOCK + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * sprs::BLOCK) {
+        const int64_t g = col_in[k];
+        if (g < 0 || g >= starts[world]) { local = 1; continue; }
+        int lo = 0, hi = world;                       // owner = last rank with starts[rank] <= g
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (starts[mid] <= g) lo = mid; else hi = mid; }
+        col_out[k] = (int32_t)((int64_t)lo * slice + (g - starts[lo]));
+    }
+    if (local) atomicOr(bad, 1);
+}
+__global__ __launch_bounds__(sprs::BLOCK) void plan_shift_kernel(int64_t n, int32_t *__restrict__ idx, int32_t r0) {
+    for (int64_t k = (int64_t)blockIdx.x * sprs::BLOCK + threadIdx.x; k < n; k += (int64_t)gridDim.x * sprs::BLOCK) idx[k] -= r0;
+}
+static inline int plan_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + sprs::BLOCK - 1) / sprs::BLOCK, 2048)); }
+
+template <class T>
+int dist_csr_create_global(sprs_comm *comm, const int64_t *row_starts, int64_t nnz, const int32_t *d_rp, int32_t *d_ci_global,
+                           const T *d_val, int adopt, int exchange, sprs_csr **out) {
+    if (!comm || !row_starts || !out || !d_rp || nnz < 0 || (nnz > 0 && (!d_ci_global || !d_val))) return SPRS_INVALID_ARGUMENT;
+    *out = nullptr;
+    sprs_ctx *c = comm->ctx;
+    const int world = comm->world, rank = comm->rank;
+    for (int r = 0; r < world; ++r)
+        if (row_starts[r + 1] < row_starts[r]) return SPRS_INVALID_ARGUMENT;
+    if (row_starts[0] != 0 || row_starts[world] >= INT32_MAX) return SPRS_INVALID_ARGUMENT;
+    const int32_t n_global = (int32_t)row_starts[world], r0 = (int32_t)row_starts[rank], r1 = (int32_t)row_starts[rank + 1];
+    const int64_t n_local = r1 - r0;
+    CtxLock lock(c);
+    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    uint8_t *mark = nullptr; int32_t *pos = nullptr, *uniq = nullptr, *send_idx = nullptr, *counts = nullptr, *col_copy = nullptr;
+    int64_t *d_starts = nullptr; void *scan_tmp = nullptr; int *d_bad = nullptr;
+    auto cleanup = [&]() {
+        for (void *q : {(void *)mark, (void *)pos, (void *)uniq, (void *)send_idx, (void *)counts, (void *)d_starts, scan_tmp, (void *)d_bad})
+            if (q) (void)hipFree(q);
+        if (col_copy) (void)hipFree(col_copy);
+    };
+    PLAN_HIP(hipMalloc((void **)&d_bad, sizeof(int)));
+    PLAN_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
+    int32_t *col_out = d_ci_global;
+    if (!adopt && nnz > 0) {      // the caller keeps its global indices: renumber into a private copy the handle will own
+        PLAN_HIP(hipMalloc((void **)&col_copy, sizeof(int32_t) * (size_t)nnz));
+        col_out = col_copy;
+    }
+    int bad = 0;
+    if (exchange == 1) {
+        int64_t slice = 0;
+        for (int r = 0; r < world; ++r) slice = std::max(slice, row_starts[r + 1] - row_starts[r]);
+        slice += slice & 1;                        // every slice stays 16-byte aligned
+        if ((int64_t)world * slice >= INT32_MAX) { cleanup(); return SPRS_INVALID_ARGUMENT; }
+        PLAN_HIP(hipMalloc((void **)&d_starts, sizeof(int64_t) * (size_t)(world + 1)));
+        PLAN_HIP(hipMemcpyAsync(d_starts, row_starts, sizeof(int64_t) * (size_t)(world + 1), hipMemcpyHostToDevice, c->stream));
+        if (nnz > 0) hipLaunchKernelGGL(plan_renumber_ag_kernel, dim3(plan_grid(nnz)), dim3(BLOCK), 0, c->stream, nnz, d_ci_global, col_out, world,
+                                        d_starts, slice, d_bad);
+        PLAN_HIP(hipGetLastError());
+        PLAN_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        PLAN_HIP(hipStreamSynchronize(c->stream));
+        if (bad) { cleanup(); return SPRS_INVALID_ARGUMENT; }
+        // a private copy is handed over to the handle (adopt = 0 semantics: copied again inside; keep it simple and correct)
+        const int st = dist_csr_create_allgather<T>(comm, n_local, slice, nnz, d_rp, col_out, d_val, adopt, out);
+        cleanup();
+        return st;
+    }
+    if (exchange != 0) { cleanup(); return SPRS_INVALID_ARGUMENT; }
+    // ---- 1. mark, 2. scan, compact
+    PLAN_HIP(hipMalloc((void **)&mark, (size_t)n_global + 16));
+    PLAN_HIP(hipMalloc((void **)&pos, sizeof(int32_t) * ((size_t)n_global + 1)));
+    PLAN_HIP(hipMemsetAsync(mark, 0, (size_t)n_global + 16, c->stream));
+    if (nnz > 0) hipLaunchKernelGGL(plan_mark_kernel, dim3(plan_grid(nnz)), dim3(BLOCK), 0, c->stream, nnz, d_ci_global, r0, r1, n_global, mark, d_bad);
+    PLAN_HIP(hipGetLastError());
+    size_t tmp_bytes = 0;
+    PLAN_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, mark, pos, (int32_t)0, (size_t)n_global + 1, rocprim::plus<int32_t>(), c->stream));
+    PLAN_HIP(hipMalloc(&scan_tmp, tmp_bytes ? tmp_bytes : 16));
+    PLAN_HIP(rocprim::exclusive_scan(scan_tmp, tmp_bytes, mark, pos, (int32_t)0, (size_t)n_global + 1, rocprim::plus<int32_t>(), c->stream));
+    int32_t n_halo = 0;
+    PLAN_HIP(hipMemcpyAsync(&n_halo, pos + n_global, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));   // mark[n_global] == 0: total
+    PLAN_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PLAN_HIP(hipStreamSynchronize(c->stream));
+    if (bad) { cleanup(); return SPRS_INVALID_ARGUMENT; }
+    std::vector<int32_t> h_uniq((size_t)n_halo);
+    if (n_halo > 0) {
+        PLAN_HIP(hipMalloc((void **)&uniq, sizeof(int32_t) * (size_t)n_halo));
+        hipLaunchKernelGGL(plan_compact_kernel, dim3(plan_grid(n_global)), dim3(BLOCK), 0, c->stream, n_global, mark, pos, uniq);
+        PLAN_HIP(hipGetLastError());
+        PLAN_HIP(hipMemcpyAsync(h_uniq.data(), uniq, sizeof(int32_t) * (size_t)n_halo, hipMemcpyDeviceToHost, c->stream));
+    }
+    // ---- 3. renumber the columns
+    if (nnz > 0) hipLaunchKernelGGL(plan_renumber_kernel, dim3(plan_grid(nnz)), dim3(BLOCK), 0, c->stream, nnz, d_ci_global, col_out, r0, r1, pos);
+    PLAN_HIP(hipGetLastError());
+    PLAN_HIP(hipStreamSynchronize(c->stream));
+    // ---- 4. who needs what: counts in one all-gather, index lists in one send/recv group
+    std::vector<int32_t> need(world, 0), need_off(world + 1, 0);
+    {
+        int p = 0;
+        for (int32_t i = 0; i < n_halo; ++i) {
+            while (h_uniq[(size_t)i] >= row_starts[p + 1]) ++p;      // ascending ids: owners ascend too
+            need[p]++;
+        }
+        for (int q = 0; q < world; ++q) need_off[q + 1] = need_off[q] + need[q];
+    }
+    PLAN_HIP(hipMalloc((void **)&counts, sizeof(int32_t) * (size_t)world * (size_t)(world + 1)));
+    PLAN_HIP(hipMemcpyAsync(counts, need.data(), sizeof(int32_t) * (size_t)world, hipMemcpyHostToDevice, c->stream));
+    PLAN_NCCL(rccl().AllGather(counts, counts + world, (size_t)world, ncclInt32, (ncclComm_t)comm->nccl, c->stream));
+    std::vector<int32_t> M((size_t)world * world);           // M[q * world + p]: rank q needs that many entries of rank p
+    PLAN_HIP(hipMemcpyAsync(M.data(), counts + world, sizeof(int32_t) * M.size(), hipMemcpyDeviceToHost, c->stream));
+    PLAN_HIP(hipStreamSynchronize(c->stream));
+    std::vector<int64_t> send_off_all(world + 1, 0);
+    for (int q = 0; q < world; ++q) {
+        const int32_t cnt = q == rank ? 0 : M[(size_t)q * world + rank];
+        if (cnt < 0 || cnt > n_local) { cleanup(); return SPRS_INVALID_ARGUMENT; }
+        send_off_all[q + 1] = send_off_all[q] + cnt;
+    }
+    const int64_t n_send = send_off_all[world];
+    if (n_send > 0) PLAN_HIP(hipMalloc((void **)&send_idx, sizeof(int32_t) * (size_t)n_send));
+    PLAN_NCCL(rccl().GroupStart());
+    for (int q = 0; q < world; ++q) {
+        if (q == rank) continue;
+        if (need[q] > 0) PLAN_NCCL(rccl().Send(uniq + need_off[q], (size_t)need[q], ncclInt32, q, (ncclComm_t)comm->nccl, c->stream));
+        const int64_t cnt = send_off_all[q + 1] - send_off_all[q];
+        if (cnt > 0) PLAN_NCCL(rccl().Recv(send_idx + send_off_all[q], (size_t)cnt, ncclInt32, q, (ncclComm_t)comm->nccl, c->stream));
+    }
+    PLAN_NCCL(rccl().GroupEnd());
+    if (n_send > 0) hipLaunchKernelGGL(plan_shift_kernel, dim3(plan_grid(n_send)), dim3(BLOCK), 0, c->stream, n_send, send_idx, r0);   // global -> local
+    PLAN_HIP(hipGetLastError());
+    PLAN_HIP(hipStreamSynchronize(c->stream));
+    // ---- one peer list for both directions
+    std::vector<int32_t> peers; std::vector<int64_t> s_off(1, 0), r_off(1, 0);
+    for (int q = 0; q < world; ++q) {
+        const int64_t ns = send_off_all[q + 1] - send_off_all[q], nr = q == rank ? 0 : need[q];
+        if (ns == 0 && nr == 0) continue;
+        peers.push_back(q); s_off.push_back(s_off.back() + ns); r_off.push_back(r_off.back() + nr);
+    }
+    // send_idx is grouped by ascending peer with no gaps: exactly the layout dist_csr_create expects
+    const int st = dist_csr_create<T>(comm, n_local, n_local + n_halo, nnz, d_rp, col_out, d_val, adopt, (int)peers.size(), peers.data(),
+                                      s_off.data(), send_idx, r_off.data(), out);
+    cleanup();
+    return st;
+}
+#undef PLAN_TRY
+#undef PLAN_HIP
+#undef PLAN_NCCL
 }  // namespace
 
 extern "C" {
+
+int sprs_dist_csr_info(const sprs_csr *A, int64_t *n_local, int64_t *n_ext, int *n_peers, int64_t *send_entries, int64_t *recv_entries) {
+    if (!A || !A->dist) return SPRS_INVALID_ARGUMENT;
+    const sprs_dist_info *D = A->dist;
+    if (n_local) *n_local = D->n_local;
+    if (n_ext) *n_ext = D->n_ext;
+    if (n_peers) *n_peers = (int)D->peer.size();
+    if (send_entries) *send_entries = D->ag_slice > 0 ? D->ag_slice : D->send_off.back();
+    if (recv_entries) *recv_entries = D->ag_slice > 0 ? D->ag_slice * (D->comm->world - 1) : D->recv_off.back();
+    return SPRS_OK;
+}
+int sprs_dist_csr_peers(const sprs_csr *A, int cap, int32_t *peer_rank, int64_t *send_off, int64_t *recv_off) {
+    if (!A || !A->dist || cap < (int)A->dist->peer.size() || (cap > 0 && (!peer_rank || !send_off || !recv_off))) return SPRS_INVALID_ARGUMENT;
+    const sprs_dist_info *D = A->dist;
+    for (size_t p = 0; p < D->peer.size(); ++p) peer_rank[p] = D->peer[p];
+    if (send_off) for (size_t p = 0; p < D->send_off.size(); ++p) send_off[p] = D->send_off[p];
+    if (recv_off) for (size_t p = 0; p < D->recv_off.size(); ++p) recv_off[p] = D->recv_off[p];
+    return SPRS_OK;
+}
+int sprs_dist_csr_send_idx(const sprs_csr *A, int64_t cap, int32_t *send_idx_host) {
+    if (!A || !A->dist || !send_idx_host) return SPRS_INVALID_ARGUMENT;
+    const sprs_dist_info *D = A->dist;
+    const int64_t n = D->send_off.back();
+    if (cap < n) return SPRS_INVALID_ARGUMENT;
+    if (n > 0) SPRS_HIP_TRY(A->ctx, hipMemcpy(send_idx_host, D->send_idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    return SPRS_OK;
+}
 
 int sprs_comm_unique_id(void *id128) {
     if (!id128) return SPRS_INVALID_ARGUMENT;
@@ -378,6 +588,11 @@ int sprs_comm_allreduce_sum_f64(sprs_comm *comm, double *dev, size_t count) {
     }                                                                                                                    \
     /* y_local = A_local * x_ext after exchanging the halo of x_ext (device vector of n_ext elements whose first        \
        n_local entries are this rank's slice of x) */                                                                    \
+    int sprs_dist_csr_create_global_dev_##X(sprs_comm *comm, const int64_t *row_starts, int64_t nnz, const int32_t *rp,   \
+                                            int32_t *ci_global, const CT *val, int adopt, int exchange, sprs_csr **out) { \
+        try { return dist_csr_create_global<T>(comm, row_starts, nnz, rp, ci_global, (const T *)val, adopt, exchange, out); } \
+        catch (...) { return SPRS_ERR_HIP; }                                                                             \
+    }                                                                                                                    \
     int sprs_dist_mul_vec_dev_##X(const sprs_csr *A, CT *x_ext, CT *y_local) {                                           \
         if (!A || !A->dist || A->dtype != dtype_of<T>::value) return SPRS_INVALID_ARGUMENT;                              \
         return dist_spmv<T>(A, (T *)x_ext, (T *)y_local, 0, nullptr, nullptr, nullptr, nullptr, false);                  \

@@ -82,6 +82,45 @@ class DistCsr(HipCsr):
         A.comm, A.plan = comm, plan
         return A
 
+    @classmethod
+    def from_global(cls, comm, starts, nnz, indptr_dev, col_global_dev, data_dev, exchange="halo", adopt=True):
+        """The whole setup behind the C ABI (sprs_dist_csr_create_global_dev_*): `col_global_dev` holds GLOBAL column
+        numbers (device, int32) and — with adopt — is renumbered in place; the exchange plan is derived on the device
+        and over RCCL (csrc/dist.hip), not in Python.  Collective."""
+        s = dev_sfx(data_dev)
+        st_ = np.ascontiguousarray(starts, dtype=np.int64)
+        assert st_.size == comm.world + 1
+        pre_sync(indptr_dev, col_global_dev, data_dev)
+        h = C.c_void_p()
+        st = getattr(_lib.lib(), "sprs_dist_csr_create_global_dev_" + s)(
+            comm.h, st_.ctypes.data_as(C.c_void_p), int(nnz), dev_ptr(indptr_dev), dev_ptr(col_global_dev), dev_ptr(data_dev),
+            1 if adopt else 0, {"halo": 0, "allgather": 1}[exchange], C.byref(h))
+        check(st, comm.ctx.h)
+        from .device import NP_OF
+        n_local = int(st_[comm.rank + 1] - st_[comm.rank])
+        A = cls(h, comm.ctx, NP_OF[s], (n_local, n_local), keepalive=(indptr_dev, col_global_dev, data_dev))
+        A.comm = comm
+        A.plan = A.plan_info()
+        A.plan["mode"] = exchange
+        if exchange == "allgather":
+            A.plan["slice"] = A.plan["send_entries"]        # every rank contributes its (padded) slice
+        A.shape = (n_local, A.plan["n_ext"])
+        return A
+
+    def plan_info(self):
+        """The exchange plan of this operator read back through the C ABI (sizes, peers, offsets, packed indices)."""
+        L = _lib.lib()
+        nl, ne, npeer, ns, nr = C.c_int64(), C.c_int64(), C.c_int(), C.c_int64(), C.c_int64()
+        check(L.sprs_dist_csr_info(self.h, C.byref(nl), C.byref(ne), C.byref(npeer), C.byref(ns), C.byref(nr)), self.ctx.h)
+        k = npeer.value
+        peers = np.zeros(max(k, 1), np.int32); so = np.zeros(k + 1, np.int64); ro = np.zeros(k + 1, np.int64)
+        check(L.sprs_dist_csr_peers(self.h, max(k, 1), peers.ctypes.data_as(C.c_void_p), so.ctypes.data_as(C.c_void_p),
+                                    ro.ctypes.data_as(C.c_void_p)), self.ctx.h)
+        sidx = np.zeros(max(int(so[-1]), 1), np.int32)
+        check(L.sprs_dist_csr_send_idx(self.h, sidx.size, sidx.ctypes.data_as(C.c_void_p)), self.ctx.h)
+        return dict(n_local=nl.value, n_ext=ne.value, peers=[int(p) for p in peers[:k]], send_off=so, recv_off=ro,
+                    send_idx=sidx[: int(so[-1])], send_entries=ns.value, recv_entries=nr.value)
+
     def cols(self):
         # the solvers are created with the number of OWNED entries
         return self.shape[0]
@@ -111,14 +150,9 @@ def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, t
         tdist.all_gather_object(out, obj)
         return out
     comm = Comm(ctx, rank, world, tdist)
-    if exchange == "allgather":
-        plan = partition.allgather_plan(ix, starts, rank)
-        plan.update(n_ext=plan["slice"] * world, peers=list(range(world)))
-        A = DistCsr.from_allgather_plan(comm, plan, nnz_loc, ip, dv, adopt=True)
-    else:
-        plan = partition.build_plan(ix, starts, rank, gather)
-        A = DistCsr.from_plan(comm, plan, nnz_loc, ip, dv, adopt=True,
-                              to_device=lambda a: torch.from_numpy(a).to(dev))
+    # the plan is built by the library (device passes + RCCL), partition.py only names the row ranges
+    A = DistCsr.from_global(comm, starts, nnz_loc, ip, ix, dv, exchange=exchange, adopt=True)
+    plan = A.plan
     n_loc = plan["n_local"]
     s = sa.BiCGStab.new(A, n_loc)
     x = torch.zeros(n_loc, dtype=torch.float64, device=dev)
@@ -134,15 +168,15 @@ def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, t
     err = reduce_scalar(float((x - 1.0).abs().max().item()), tdist.ReduceOp.MAX)
     tot = reduce_scalar(nnz_loc, tdist.ReduceOp.SUM)
     check_ = dict(tol=1e-8, iters=its, rel_res=res, max_abs_err_vs_exact=err,
-                  exchange=exchange, halo_entries_per_rank=int(plan["n_ext"] - n_loc), peers=[int(p) for p in plan["peers"]])
+                  exchange=exchange, halo_entries_per_rank=int(plan["recv_entries"]), peers=[int(p) for p in plan["peers"]])
     mode, n_off, n_pair = A.stream_format()      # what this rank's SpMV streams (csrc/spmv_dict.hip)
     per_nnz = {0: 12, 1: 9, 2: 1}[mode]
     sinfo = dict(stream={0: "csr", 1: "offset-codes", 2: "pair-codes"}[mode], mode=mode, distinct_offsets=n_off,
                  distinct_pairs=n_pair, bytes_per_nnz=per_nnz,
                  format_bytes_per_launch=nnz_loc * per_nnz + (n_loc + 1) * 4 + 2 * n_loc * 8, rows=n_loc, nnz=nnz_loc)
     # evidence that the collectives really span `world` ranks, and what each rank moves per SpMV
-    halo_b = int(plan["n_ext"] - n_loc) * 8 if exchange != "allgather" else int(plan["slice"]) * (world - 1) * 8
-    send_b = int(plan["send_off"][-1]) * 8 if exchange != "allgather" else int(plan["slice"]) * 8
+    halo_b = int(plan["recv_entries"]) * 8
+    send_b = int(plan["send_entries"]) * 8
     per_rank = gather(dict(rank=rank, rccl_ranks=comm.count(), halo_recv_bytes=halo_b, halo_send_bytes=send_b,
                            peers=[int(p) for p in plan["peers"]], rows=n_loc, nnz=nnz_loc))
     dist_info = dict(rccl_ranks=min(p["rccl_ranks"] for p in per_rank), exchange=exchange,

@@ -38,7 +38,23 @@ def main(rank, world, port, kind, outdir, exchange="halo"):
         return out
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     comm = sdist.Comm(ctx, rank, world, tdist)
-    if exchange == "allgather":
+    if exchange in ("halo_c", "allgather_c"):
+        # the plan builder behind the C ABI (csrc/dist.hip) against partition.py's plan of the same row block
+        ref = (partition.build_plan(np.asarray(ix), starts, rank, gather) if exchange == "halo_c"
+               else partition.allgather_plan(np.asarray(ix), starts, rank))
+        col_dev = t(ix)
+        A = sdist.DistCsr.from_global(comm, starts, int(ip[-1]), t(ip), col_dev, t(d), exchange=exchange[:-2], adopt=True)
+        plan = A.plan
+        assert np.array_equal(col_dev.cpu().numpy(), np.asarray(ref["col_ext"])), "renumbered columns differ from partition.py"
+        if exchange == "halo_c":
+            assert plan["n_local"] == ref["n_local"] and plan["n_ext"] == ref["n_ext"], (plan["n_ext"], ref["n_ext"])
+            assert plan["peers"] == [int(q) for q in ref["peers"]]
+            assert np.array_equal(plan["send_off"], ref["send_off"]) and np.array_equal(plan["recv_off"], ref["recv_off"])
+            assert np.array_equal(plan["send_idx"], ref["send_idx"])
+        else:
+            assert plan["send_entries"] == ref["slice"]
+            plan = dict(plan, n_ext=ref["slice"])
+    elif exchange == "allgather":
         plan = partition.allgather_plan(t(ix), starts, rank)
         plan["n_ext"] = plan["slice"]            # the SpMV input only needs this rank's (padded) slice
         A = sdist.DistCsr.from_allgather_plan(comm, plan, int(ip[-1]), t(ip), t(d), adopt=True)

@@ -38,7 +38,9 @@ def _run(world, kind, mock_lib, exchange="halo"):
 
 
 @pytest.mark.parametrize("world,kind,exchange", [(2, "poisson3d", "halo"), (3, "poisson3d", "halo"), (2, "banded", "halo"),
-                                                 (3, "poisson3d", "allgather"), (2, "banded", "allgather")])
+                                                 (3, "poisson3d", "allgather"), (2, "banded", "allgather"),
+                                                 (3, "poisson3d", "halo_c"), (2, "banded", "halo_c"), (3, "banded", "halo_c"),
+                                                 (2, "poisson3d", "allgather_c")])
 def test_real_ranks_match_single_process(oracle, mock_lib, world, kind, exchange):
     from sprsolve_amd import gen
     if kind == "poisson3d":
