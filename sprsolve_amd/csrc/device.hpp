@@ -61,6 +61,24 @@ __device__ __forceinline__ T reduce_partials(const T *__restrict__ part, int P, 
     return block_sum(acc, smem);
 }
 
+// Two partial arrays at once: both sets of loads are issued before either is consumed and the two block sums share
+// their barriers (a consumer prologue is a chain of dependent round trips; this removes one).  Same per-thread
+// addition order and same wave / block order as two reduce_partials calls => bit-identical values.
+template <class TA, class TB>
+__device__ __forceinline__ void reduce_partials2(const TA *__restrict__ pa, const TB *__restrict__ pb, int P, TA *smA, TB *smB,
+                                                 TA &ra, TB &rb) {
+    TA a = szero<TA>(); TB b = szero<TB>();
+    for (int i = threadIdx.x; i < P; i += BLOCK) { const TA va = pa[i]; const TB vb = pb[i]; a = sadd(a, va); b = sadd(b, vb); }
+    a = wave_sum(a); b = wave_sum(b);
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { smA[wv] = a; smB[wv] = b; }
+    __syncthreads();
+    ra = smA[0]; rb = smB[0];
+#pragma unroll
+    for (int w = 1; w < NWAVE; ++w) { ra = sadd(ra, smA[w]); rb = sadd(rb, smB[w]); }
+}
+
 // 16-byte packs: 2 doubles or 1 complex per lane per access (global_load_dwordx4).
 template <class T, int PK>
 struct alignas(sizeof(T) * PK) Pack {

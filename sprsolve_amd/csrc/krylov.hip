@@ -62,25 +62,33 @@ struct BicgK1 {
     __device__ __forceinline__ bool prologue() {
         __shared__ Real<T> smD[NWAVE];
         __shared__ T smT[NWAVE];
-        if (S->status != ST_RUNNING) return false;
+        // every load of the prologue is issued before any is consumed (state words, then both partial arrays): one
+        // memory round trip where the literal order (status -> |r| partials -> tol -> rho partials -> ...) paid four.
+        // Only fields that no workgroup of THIS launch writes are read (rho / r_norm / beta are written below).
+        const int status = S->status;
+        const Real<T> tol2 = S->tol2, r0_norm_tol = S->r0_norm_tol;
+        const T w = S->w, rho_old = S->rho_old, alpha = S->alpha;
         T rho; Real<T> r_norm;
         if (mode == 0) {
-            r_norm = ssqrt(reduce_partials(partN, P, smD));          // :123
-            if (r_norm <= S->tol2) {                                // :124
+            Real<T> sN; T sR;
+            reduce_partials2(partN, partRho, P, smD, smT, sN, sR);  // :123 |r|^2, :128 r0.r
+            if (status != ST_RUNNING) return false;
+            r_norm = ssqrt(sN);                                      // :123
+            if (r_norm <= tol2) {                                    // :124
                 if (first_thread()) { S->r_norm = r_norm; S->status = ST_CONVERGED; }
                 return false;
             }
-            rho = reduce_partials(partRho, P, smT);                 // :128
-            if (sabs(rho) < S->r0_norm_tol) {                       // :131 -> host runs :132-145
+            rho = sR;                                                // :128
+            if (sabs(rho) < r0_norm_tol) {                           // :131 -> host runs :132-145
                 if (first_thread()) { S->r_norm = r_norm; S->status = ST_RESTART; }
                 return false;
             }
         } else {  // resumed after the host-side restart: rho, r0_norm_tol already updated
+            if (status != ST_RUNNING) return false;
             rho = S->rho; r_norm = S->r_norm;
         }
-        const T w = S->w;
-        beta = smul(sdiv(rho, S->rho_old), sdiv(S->alpha, w));      // :146
-        a = smul(sneg(beta), w);                                    // :155  -beta * w
+        beta = smul(sdiv(rho, rho_old), sdiv(alpha, w));             // :146
+        a = smul(sneg(beta), w);                                     // :155  -beta * w
         if (first_thread()) { S->rho = rho; S->r_norm = r_norm; S->beta = beta; }
         return true;
     }
@@ -110,13 +118,15 @@ struct BicgK3 {
     T na;
     __device__ __forceinline__ bool prologue() {
         __shared__ T smT[NWAVE];
-        if (S->status != ST_RUNNING) return false;
+        const int status = S->status;                               // requested together with the partials
+        const T rho = S->rho;
         const T tmp = reduce_partials(partB, P, smT);               // :163
+        if (status != ST_RUNNING) return false;
         if (check_breakdown && sabs(tmp) <= 0.0) {                  // :164-167
             if (first_thread()) S->status = ST_BREAKDOWN;
             return false;
         }
-        const T alpha = sdiv(S->rho, tmp);                          // :169
+        const T alpha = sdiv(rho, tmp);                             // :169
         na = sneg(alpha);
         if (first_thread()) S->alpha = alpha;
         return true;
@@ -147,11 +157,14 @@ struct BicgK5 {
     Real<T> accN; T accR;
     __device__ __forceinline__ bool prologue() {
         __shared__ T smT[NWAVE];
-        if (S->status != ST_RUNNING) return false;
-        const T tt = reduce_partials(partTT, P, smT);               // :178
-        const T tr = reduce_partials(partTR, P, smT);               // :183
+        __shared__ T smT2[NWAVE];
+        const int status = S->status;                               // requested together with the partials
+        const T alpha = S->alpha;
+        T tt, tr;
+        reduce_partials2(partTT, partTR, P, smT, smT2, tt, tr);     // :178, :183
+        if (status != ST_RUNNING) return false;
         w = (sre(tt) > 0.0) ? sdiv(tr, tt) : szero<T>();            // :179-186
-        na = sneg(S->alpha); nw = sneg(w);
+        na = sneg(alpha); nw = sneg(w);
         accN = 0.0; accR = szero<T>();
         return true;
     }
@@ -193,9 +206,11 @@ struct MinresM2 {
     T nb, na; Real<T> accD; T accT;
     __device__ __forceinline__ bool prologue() {
         __shared__ T smT[NWAVE];
-        if (D->status != ST_RUNNING) return false;
+        const int status = D->status;                               // requested together with the partials
+        const Real<T> beta = D->st[par].beta;
         const T alpha = reduce_partials(partAlpha, P, smT);         // :116
-        nb = sfromr<T>(-D->st[par].beta);                           // :117 T::from_real(-beta)
+        if (status != ST_RUNNING) return false;
+        nb = sfromr<T>(-beta);                                      // :117 T::from_real(-beta)
         na = sneg(alpha);                                           // :118
         accD = 0.0; accT = szero<T>();
         if (first_thread()) D->st[par].alpha = alpha;
@@ -245,10 +260,11 @@ struct MinresM3 {
     __device__ __forceinline__ bool prologue() {
         __shared__ Real<T> smD[NWAVE];
         __shared__ T smT[NWAVE];
-        if (D->status != ST_RUNNING) return false;
-        const MinresState<T> &S = D->st[par];
+        const int status = D->status;                               // state words requested together with the partials
+        const MinresState<T> S = D->st[par];                        // (a copy: st[par] is not written by this launch)
         if (PC) {
             const T b2 = reduce_partials(partBeta2, P, smT);        // :278
+            if (status != ST_RUNNING) return false;
             if (sre(b2) < seps<Real<T>>() || sim(b2) > seps<Real<T>>() * sre(b2)) {         // :279-287
                 if (first_thread()) { D->st[par].pc_re = sre(b2); D->its = its; D->status = ST_INVALID_PC; }
                 return false;
@@ -256,6 +272,7 @@ struct MinresM3 {
             beta_new = ssqrt(sre(b2));                               // :288
         } else {
             beta_new = ssqrt(reduce_partials(partBeta, P, smD));     // :120
+            if (status != ST_RUNNING) return false;
         }
         inv = Real<T>(1) / beta_new;                                       // :121 / :289
         const Real<T> beta = S.beta;

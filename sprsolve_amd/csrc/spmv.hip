@@ -105,7 +105,9 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
     constexpr int ITEMS = CAP / WAVE;
     __shared__ T prod_all[NWAVE][CAP];
     __shared__ T red[NWAVE];
-    if (status != nullptr && *status != ST_RUNNING) return;
+    // requested now, looked at when the first descriptor has arrived: the two loads share one round trip
+    // (a kernel of a finished solve must not store anything; it may load)
+    const int run_state = status != nullptr ? *status : (int)ST_RUNNING;
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
     T *prod = prod_all[wv];
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
     // duplicates hit the same cache line.
     for (; b < bend; b += bstep) {
         const BlkDesc d = desc[order ? order[b] : b];
+        if (run_state != ST_RUNNING) return;       // uniform over the grid; nothing has been stored yet
         const int ra = d.ra, rb = d.rb & 0x7fffffff;
         if (d.rb >= 0) {
             // ---------------- stream block: products to LDS, then one lane per row
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
             }
         }
     }
+    if (run_state != ST_RUNNING) return;           // a wavefront that had no row block comes straight here
     if (DOT >= 1) {
         d0 = block_sum(d0, red);
         if (tid == 0) part0[blockIdx.x] = d0;

@@ -83,11 +83,22 @@ __global__ __launch_bounds__(BLOCK) void dict_collect_kernel(int n, const int32_
                                                              uint32_t *off_h, unsigned long long *val_h, int *counts) {
     uint32_t last_off = EMPTY32;
     uint64_t last_val = EMPTY64;
+    // Once a dictionary has overflowed nothing more can be learnt about it: a matrix with random values kept probing
+    // a dead table for every one of its 349 M entries (884 ms at handle creation, profiles/r02_tuning.md).  The
+    // overflow flags are re-read once per row, not per entry.
+    bool vals_dead = !VALS, offs_dead = false;
     for (int row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK) {
+        if (!offs_dead && __hip_atomic_load(counts + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > TAB) offs_dead = true;
+        if (offs_dead) return;                      // > 256 offsets: no compressed stream at all
+        if constexpr (VALS) {
+            if (!vals_dead && (__hip_atomic_load(counts + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > TAB ||
+                               __hip_atomic_load(counts + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) vals_dead = true;
+        }
         for (int k = row_ptr[row]; k < row_ptr[row + 1]; ++k) {
             const uint32_t d = (uint32_t)(col_idx[k] - row);
             if (d != last_off) { (void)probe32(off_h, counts + 0, d, true); last_off = d; }
             if constexpr (VALS) {
+                if (vals_dead) continue;
                 const uint64_t kv = key_of(val[k]);
                 if (kv == EMPTY64) { counts[2] = 1; continue; }
                 if (kv != last_val) { (void)probe64(val_h, counts + 1, kv, true); last_val = kv; }
@@ -170,7 +181,9 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
     __shared__ uint32_t s_c[NWAVE][CW];
     __shared__ T s_v[PAIR ? 1 : NWAVE][PAIR ? 1 : CAP + 8];
     __shared__ T red[NWAVE];
-    if (status != nullptr && *status != ST_RUNNING) return;
+    // the solve's status word is requested first and looked at after the table loads: one memory round trip, not two
+    // (a kernel of a finished solve must not store anything; it may load)
+    const int run_state = status != nullptr ? *status : (int)ST_RUNNING;
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     // the wavefront index as a SCALAR: the block walk (b, loop branches) then lives in SGPRs
@@ -180,6 +193,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
     for (int i = lane; i < CW; i += WAVE) s_c[wv][i] = 0;       // the pad is read (and ignored) before it is ever written
     if constexpr (!PAIR) for (int i = lane; i < CAP + 8; i += WAVE) s_v[wv][i] = szero<T>();
     __syncthreads();                                // the only workgroup barrier: tables are read-only afterwards
+    if (run_state != ST_RUNNING) return;
 
     const uint8_t *cb = reinterpret_cast<const uint8_t *>(s_c[wv]);
     [[maybe_unused]] T *vs = s_v[PAIR ? 0 : wv];
@@ -416,13 +430,14 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
     __shared__ PairEnt<T> s_pair[TAB];
     __shared__ __attribute__((aligned(16))) uint32_t s_c[NWAVE][CW2];
     __shared__ T red[NWAVE];
-    if (status != nullptr && *status != ST_RUNNING) return;
+    const int run_state = status != nullptr ? *status : (int)ST_RUNNING;       // looked at after the table loads (one round trip)
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     s_pair[tid] = PairEnt<T>{off_tab[tid] * 8, val_tab[tid]};                  // BLOCK == TAB
     for (int i = lane; i < CW2; i += WAVE) s_c[wv][i] = 0;                     // the pad is read (and ignored) before it is written
     __syncthreads();
+    if (run_state != ST_RUNNING) return;
 
     const uint8_t *cb = reinterpret_cast<const uint8_t *>(s_c[wv]);
     const char *xbytes = reinterpret_cast<const char *>(x);
