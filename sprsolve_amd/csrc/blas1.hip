@@ -131,19 +131,36 @@ int launch_diag_inv(sprs_ctx *c, size_t n, const V *diag, V *dinv) {
 }
 
 // ------------------------------------------------------------------ reductions
+// A read-only kernel with ONE 16-byte load in flight per lane is latency-bound at 2 workgroups per CU (nrm2 of cfg 5
+// ran at 3.3 TB/s where a read stream reaches 6.3, profiles/r02_tuning.md §1): the grid-stride loop is walked four packs
+// at a time — the four loads are issued together, the additions stay in the ORIGINAL order (one accumulator,
+// i, i+st, i+2st, i+3st, ...), so every partial is bit-identical to the plain loop's.
+constexpr int RED_UNROLL = 4;
+
 template <class T, bool CONJ, int PK>
 __global__ __launch_bounds__(BLOCK) void dot_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ y,
                                                     T *__restrict__ part) {
     __shared__ T smem[NWAVE];
     T acc = szero<T>();
-    SPRS_FOREACH_PACK(n, PK, i) {
+    const int64_t np = n / PK, st = (int64_t)gridDim.x * BLOCK;
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    for (; i + (RED_UNROLL - 1) * st < np; i += RED_UNROLL * st) {
+        Pack<T, PK> xv[RED_UNROLL], yv[RED_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RED_UNROLL; ++u) { xv[u] = ldp<T, PK>(x, i + u * st); yv[u] = ldp<T, PK>(y, i + u * st); }
+#pragma unroll
+        for (int u = 0; u < RED_UNROLL; ++u)
+#pragma unroll
+            for (int e = 0; e < PK; ++e) acc = sadd(acc, smul(CONJ ? sconj(xv[u].v[e]) : xv[u].v[e], yv[u].v[e]));
+    }
+    for (; i < np; i += st) {
         auto xv = ldp<T, PK>(x, i); auto yv = ldp<T, PK>(y, i);
 #pragma unroll
         for (int e = 0; e < PK; ++e) acc = sadd(acc, smul(CONJ ? sconj(xv.v[e]) : xv.v[e], yv.v[e]));
     }
     if (PK > 1) {
-        int64_t i = (n / PK) * PK + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-        if (i < n) acc = sadd(acc, smul(CONJ ? sconj(x[i]) : x[i], y[i]));
+        int64_t t = (n / PK) * PK + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+        if (t < n) acc = sadd(acc, smul(CONJ ? sconj(x[t]) : x[t], y[t]));
     }
     acc = block_sum(acc, smem);
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
@@ -153,14 +170,25 @@ template <class T, int PK>
 __global__ __launch_bounds__(BLOCK) void nrm2sq_kernel(int64_t n, const T *__restrict__ x, Real<T> *__restrict__ part) {
     __shared__ Real<T> smem[NWAVE];
     Real<T> acc = 0;
-    SPRS_FOREACH_PACK(n, PK, i) {
+    const int64_t np = n / PK, st = (int64_t)gridDim.x * BLOCK;
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    for (; i + (RED_UNROLL - 1) * st < np; i += RED_UNROLL * st) {
+        Pack<T, PK> xv[RED_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RED_UNROLL; ++u) xv[u] = ldp<T, PK>(x, i + u * st);
+#pragma unroll
+        for (int u = 0; u < RED_UNROLL; ++u)
+#pragma unroll
+            for (int e = 0; e < PK; ++e) acc = acc + ssq(xv[u].v[e]);
+    }
+    for (; i < np; i += st) {
         auto xv = ldp<T, PK>(x, i);
 #pragma unroll
         for (int e = 0; e < PK; ++e) acc = acc + ssq(xv.v[e]);
     }
     if (PK > 1) {
-        int64_t i = (n / PK) * PK + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-        if (i < n) acc = acc + ssq(x[i]);
+        int64_t t = (n / PK) * PK + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+        if (t < n) acc = acc + ssq(x[t]);
     }
     acc = block_sum(acc, smem);
     if (threadIdx.x == 0) part[blockIdx.x] = acc;

@@ -178,3 +178,35 @@ def test_invalid_plan_is_rejected(env):
     with pytest.raises(ValueError):
         sdist.DistCsr.from_plan(env["comm"], plan, int(indptr[-1]), torch.from_numpy(indptr).to(dev),
                                 torch.from_numpy(data).to(dev), to_device=lambda a: torch.from_numpy(a).to(dev))
+
+
+@pytest.mark.parametrize("exchange", ["halo", "allgather"])
+def test_plan_builder_with_the_real_rccl(env, oracle, exchange):
+    """sprs_dist_csr_create_global_dev_* on a world-size-1 communicator of the REAL librccl: the device passes
+    (mark / scan / renumber), ncclAllGather of the per-peer counts and the (empty) send/recv group all run; with one
+    rank every column is owned, so the operator must equal the plain one bit for bit, and ncclCommCount says 1.
+    Multi-rank plans are checked against partition.py in tests/test_gpu_dist_multirank.py (mock transport)."""
+    torch, sa, sdist, dev = env["torch"], env["sa"], env["sdist"], env["dev"]
+    from sprsolve_amd import gen
+    ip, ix, d, rhs = gen.poisson3d(20, 18, 16)
+    n = rhs.size
+    assert env["comm"].count() == 1
+    col = torch.from_numpy(ix).to(dev)
+    A = sdist.DistCsr.from_global(env["comm"], np.array([0, n], np.int64), int(ip[-1]), torch.from_numpy(ip).to(dev), col,
+                                  torch.from_numpy(d).to(dev), exchange=exchange)
+    assert np.array_equal(col.cpu().numpy(), ix)                       # nothing is remote: numbering unchanged
+    assert A.plan["peers"] == [] and A.plan["n_local"] == n
+    x = np.linspace(-1, 1, n) ** 3
+    x_ext = torch.zeros(A.plan["n_ext"] if exchange == "halo" else A.plan["slice"], dtype=torch.float64, device=dev)
+    x_ext[:n] = torch.from_numpy(x).to(dev)
+    y = torch.empty(n, dtype=torch.float64, device=dev)
+    A.mul_vec_ext(x_ext, y)
+    assert np.array_equal(y.cpu().numpy().view(np.uint64), oracle.spmv(ip, ix, d, x).view(np.uint64))
+    xs = torch.zeros(n, dtype=torch.float64, device=dev)
+    sa.BiCGStab.new(A, n).solve(torch.from_numpy(rhs).to(dev), xs, 3000, 1e-10)
+    assert np.max(np.abs(xs.cpu().numpy() - 1.0)) < 1e-7
+    # a column outside the global range is refused, not renumbered
+    bad = ix.copy(); bad[11] = n + 3
+    with pytest.raises(ValueError):
+        sdist.DistCsr.from_global(env["comm"], np.array([0, n], np.int64), int(ip[-1]), torch.from_numpy(ip).to(dev),
+                                  torch.from_numpy(bad).to(dev), torch.from_numpy(d).to(dev), exchange=exchange)

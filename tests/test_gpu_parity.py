@@ -831,3 +831,22 @@ def test_c_program_through_the_abi(tmp_path):
     out = subprocess.run([exe, "96"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "stream=2" in out.stdout and "max_err=" in out.stdout, out.stdout
+
+
+def test_host_owned_recurrence_through_the_abi(tmp_path):
+    """examples/host_loop_bicgstab.c — north_star's literal structure: a C host owns the BiCGStab recurrence
+    (bicg_stab.rs:35-200 statement for statement) and calls one kernel per reference op through the C ABI, vectors
+    resident in HBM.  Its iteration count, residual and x must be bit-identical to the library's own literal-mode solve
+    (same kernels, same order) and agree with the fused default to rounding."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_loop")
+    libdir = os.path.join(root, "sprsolve_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "host_loop_bicgstab.c"), "-o", exe, "-L", libdir, "-l:libsprsolve_hip.so",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"])
+    for size in ("48", "100"):
+        out = subprocess.run([exe, size], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "bit-identical: yes" in out.stdout, out.stdout
