@@ -119,8 +119,16 @@ def stream_info(A, n, nnz, s):
     (x and y counted once, like spmv_bytes): plain CSR nnz*(s+4); offset codes nnz*(s+1); pair codes nnz*1."""
     mode, n_off, n_pair = A.stream_format()
     per_nnz = {0: s + 4, 1: s + 1, 2: 1}[mode]
-    return dict(stream=STREAM_NAMES[mode], mode=mode, distinct_offsets=n_off, distinct_pairs=n_pair,
+    info = dict(stream=STREAM_NAMES[mode], mode=mode, distinct_offsets=n_off, distinct_pairs=n_pair,
                 bytes_per_nnz=per_nnz, format_bytes_per_launch=nnz * per_nnz + (n + 1) * 4 + 2 * n * s)
+    if mode != 0:
+        # uniform blocks (all rows repeat one code sequence) are multiplied without their code bytes and without row_ptr:
+        # what the kernel has to READ is less than the format's size (blocks are equal-sized to within the last one)
+        nb, nu = A.wide_blocks()
+        uf = nu / nb if nb else 0.0
+        info.update(row_blocks=nb, uniform_blocks=nu,
+                    compulsory_bytes_per_launch=int(nnz * (per_nnz - 1) + (1.0 - uf) * (nnz + (n + 1) * 4) + 2 * n * s))
+    return info
 
 
 def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8):
@@ -129,6 +137,11 @@ def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8):
     r = dict(bound="hbm", kernel=KERNEL_NAMES[sinfo["mode"]], achieved=fb / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
              frac=fb / t_spmv / 1e9 / HBM_PEAK_GBS, traffic=None, stream=sinfo["stream"], bytes_per_nnz=sinfo["bytes_per_nnz"],
              format_bytes_per_launch=fb, algorithmic_bytes_per_launch=fb, avg_launch_us=t_spmv * 1e6, launches=launches)
+    if "compulsory_bytes_per_launch" in sinfo:
+        r["compulsory_bytes_per_launch"] = sinfo["compulsory_bytes_per_launch"]
+        r["frac_compulsory"] = sinfo["compulsory_bytes_per_launch"] / t_spmv / 1e9 / HBM_PEAK_GBS
+        r["compulsory_note"] = ("format bytes minus the code bytes and row_ptr of the uniform blocks (%d of %d), which the kernel "
+                                "does not read" % (sinfo["uniform_blocks"], sinfo["row_blocks"]))
     if sinfo["mode"] != 0:
         r["csr_equivalent_GBs"] = spmv_bytes(n, nnz, s) / t_spmv / 1e9
         r["csr_equivalent_note"] = ("the same launch time against SURVEY §8d's CSR bytes nnz*12 + (n+1)*4 + 2*n*8: what a plain-CSR "

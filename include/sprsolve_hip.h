@@ -111,9 +111,10 @@ int64_t sprs_csr_nnz(const sprs_csr *A);
  * (and, for real scalars, <= 256 distinct values and pairs) and the ctx knob "spmv_dict" allows it; y is
  * bit-identical in all three.  n_offsets / n_pairs (may be NULL) receive the table sizes (0 = table absent). */
 int sprs_csr_stream_format(const sprs_csr *A, int *n_offsets, int *n_pairs);
-/* Diagnostics of the f64 pair-code stream: number of 128-row blocks, and how many of them are "uniform" (all rows
- * repeat one code sequence: multiplied from a scalar pattern, no code bytes and no row_ptr read).  0 / 0 when the
- * handle has no such blocks.  Copies the descriptors to the host: not for hot paths. */
+/* Diagnostics of the compressed streams: the number of row blocks the SpMV of this handle walks (128-row blocks of
+ * the f64 pair-code stream, 64-row blocks of the offset-code stream) and how many of them are "uniform" (all rows
+ * repeat one code sequence: multiplied from a scalar pattern, no code bytes and no row_ptr read).  0 / 0 for the
+ * plain stream.  Copies the descriptors to the host: not for hot paths. */
 int sprs_csr_wide_blocks(const sprs_csr *A, int64_t *n_blocks, int64_t *n_uniform);
 
 /* MatVecMul::mul_vec / mul_vec_dot (mat.rs:49-64): host slices, checked — returns

@@ -544,15 +544,21 @@ int64_t sprs_csr_nnz(const sprs_csr *A) { return A ? A->nnz : -1; }
 int sprs_csr_wide_blocks(const sprs_csr *A, int64_t *n_blocks, int64_t *n_uniform) {
     if (!A || !n_blocks || !n_uniform) return SPRS_INVALID_ARGUMENT;
     *n_blocks = 0; *n_uniform = 0;
-    if (!A->dict || !A->dict->wide_desc || A->dict->n_wide == 0) return SPRS_OK;
+    if (!A->dict) return SPRS_OK;
+    // the descriptors the SpMV of this handle walks: 128-row blocks of the f64 pair-code stream, else the 64-row
+    // blocks of the offset-code stream
+    const bool wide = A->dict->wide_desc && A->dict->n_wide > 0 && dict_mode(A) == 2;
+    const void *src = wide ? A->dict->wide_desc : A->dict->off_desc;
+    const int64_t nb = wide ? A->dict->n_wide : (A->dict->off_desc ? A->n_rowblk : 0);
+    if (!src || nb == 0) return SPRS_OK;
     sprs_ctx *c = A->ctx;
     CtxLock lock(c);
-    std::vector<int32_t> d((size_t)A->dict->n_wide * 4);
+    std::vector<int32_t> d((size_t)nb * 4);
     SPRS_HIP_TRY(c, hipSetDevice(c->device));
-    SPRS_HIP_TRY(c, hipMemcpyAsync(d.data(), A->dict->wide_desc, d.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    SPRS_HIP_TRY(c, hipMemcpyAsync(d.data(), src, d.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *n_blocks = A->dict->n_wide;
-    for (int64_t j = 0; j < A->dict->n_wide; ++j) *n_uniform += ((uint32_t)d[(size_t)j * 4 + 1] & sprs::UNI2) != 0;
+    *n_blocks = nb;
+    for (int64_t j = 0; j < nb; ++j) *n_uniform += ((uint32_t)d[(size_t)j * 4 + 1] & sprs::UNI2) != 0;
     return SPRS_OK;
 }
 int sprs_csr_stream_format(const sprs_csr *A, int *n_offsets, int *n_values) {

@@ -125,6 +125,8 @@ struct sprs_dict {
     int n_off = 0, n_val = 0, n_pair = 0;
     void *wide_desc = nullptr;     // device: descriptors of the 128-row blocks of the two-rows-per-lane kernel (f64 pair codes)
     int n_wide = 0;
+    void *off_desc = nullptr;      // device: copy of blk_desc for the offset-code stream with the uniform blocks flagged (bit 30, nn = row length)
+    int n_off_uniform = 0;
 };
 
 struct sprs_csr {

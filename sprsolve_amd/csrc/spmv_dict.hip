@@ -154,7 +154,8 @@ template <class T> struct alignas(sizeof(T) >= 8 ? 16 : 8) PairEnt { int32_t off
 // memory round trip — its x gather — instead of three dependent ones (descriptor -> codes/row_ptr -> x).
 template <class T, bool PAIR, int ITEMS>
 struct BlkLoads {
-    int ra, rb, pa, nn;      // descriptor
+    int ra, rb, pa, nn;      // descriptor (nn = entries of the block, also for uniform blocks)
+    int ulen;                // > 0: uniform block — every row repeats the first row's ulen codes; no row_ptr, 1-3 code dwords
     int s;                   // row_ptr[row] of this lane's row
     T uu;                    // dot operand of this lane's row
     uint32_t wc[2];          // code dwords
@@ -233,14 +234,21 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
     // Phase 1 of a block: issue its loads (unconditional, clamped addresses: they go out back to back).
     // Nothing here uses a loaded value, so the wavefront does not wait.
     auto issue = [&](const BlkDesc &d, Loads &L) {
-        L.ra = d.ra; L.rb = d.rb & 0x7fffffff; L.pa = d.pa; L.nn = d.nn;   // dictionary matrices have no vector blocks
+        // dictionary matrices have no vector blocks (bit 31); bit 30 = uniform block (descriptors of the offset-code
+        // stream only, mark_uniform_kernel): its nn field holds the common row length, not the block's entry count
+        L.ra = d.ra; L.rb = d.rb & 0x3fffffff; L.pa = d.pa;
+        const bool uni = ((uint32_t)d.rb & UNI2) != 0;                     // scalar
+        L.ulen = uni ? d.nn : 0;
+        L.nn = uni ? (L.rb - L.ra) * d.nn : d.nn;
         const int r = L.ra + lane;
         const int rcl = r < L.rb ? r : L.rb - 1;
         // uniform base + 32-bit lane offset everywhere (launch checks the sizes): no 64-bit address arithmetic
-        L.s = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(row_ptr) + (uint32_t)rcl * 4u);   // row_ptr[row + 1] comes from the next lane (adopt)
+        if (uni) L.s = L.pa + (rcl - L.ra) * L.ulen;                       // every row has ulen entries: row_ptr is not read
+        else L.s = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(row_ptr) + (uint32_t)rcl * 4u);   // row_ptr[row + 1] comes from the next lane (adopt)
         if (DOT != 0) L.uu = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(u) + (uint32_t)rcl * (uint32_t)sizeof(T));
         const int shift = L.pa & 3;
-        const int nd = max((shift + L.nn + 3) >> 2, 1);                    // dwords covering [pa, pa + nn), <= CAP/4 + 1
+        // dwords covering [pa, pa + nn) (<= CAP/4 + 1) — of a uniform block only the first row's codes: 1-3 dwords
+        const int nd = max((shift + (uni ? L.ulen : L.nn) + 3) >> 2, 1);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             L.di[i] = min(lane + i * WAVE, nd - 1);
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
 #pragma unroll
             for (int i = 0; i < 2; ++i) s_c[wv][L.di[i]] = L.wc[i];   // clamped duplicates store the same dword to the same slot
             if constexpr (CAP / 4 + 1 > 2 * WAVE) {
-                if (((shift + L.nn + 3) >> 2) > 2 * WAVE && lane == 0)     // the 129th dword exists only when shift + nn > 512
+                if (L.ulen == 0 && ((shift + L.nn + 3) >> 2) > 2 * WAVE && lane == 0)     // the 129th dword exists only when shift + nn > 512
                     s_c[wv][2 * WAVE] = reinterpret_cast<const uint32_t *>(code + (L.pa - shift))[2 * WAVE];
             }
             if constexpr (!PAIR) {
@@ -276,10 +284,11 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
 
     // loop-carried state of the block being processed: plain values, no load in flight behind them
     int c_ra = 0, c_rb = 0, c_s = 0, c_len = 0, c_shift = 0;
+    bool c_uni = false;      // scalar: every lane reads the FIRST row's codes
     T c_uu = szero<T>();
     auto adopt = [&](const Loads &L) {
         const int r = L.ra + lane;
-        c_ra = L.ra; c_rb = L.rb; c_shift = L.pa & 3;
+        c_ra = L.ra; c_rb = L.rb; c_shift = L.pa & 3; c_uni = L.ulen > 0;
         c_s = L.s - L.pa;
         int e = __shfl_down(L.s, 1, WAVE);          // next row's start; the block's last row ends at pa + nn
         if (r == L.rb - 1) e = L.pa + L.nn;
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
             // slots past a row's end read the (in-bounds, stale or zero) bytes behind it and are dropped below;
             // one clamp per chunk keeps the whole chunk inside the wavefront's slice
             const int kb = min(s + j0, CAP);
-            const uint8_t *cp = cb + c_shift + kb;
+            const uint8_t *cp = cb + c_shift + (c_uni ? j0 : kb);    // uniform block: the first row's codes, at one address for all lanes
             T xg[8], av[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) { xg[t] = szero<T>(); av[t] = szero<T>(); }
@@ -730,6 +739,17 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
     DICT_TRY2(hipMemcpyAsync(h_counts, counts, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
     DICT_TRY2(hipStreamSynchronize(c->stream));
     if (h_counts[3] != 0) { cleanup2(); free_dict(A); return SPRS_OK; }   // cannot happen (every key was inserted)
+    if (c->spmv_uniform != 0 && A->n_rowblk > 0) {
+        // Uniform 64-row blocks of the offset-code stream: all rows repeat the first row's (<= 8) offset codes — the
+        // interior of any stencil or band, whatever its VALUES.  Such a block needs neither row_ptr nor its code bytes
+        // (9 B/nnz + 4 B/row -> 8 B/nnz); flagged in a private copy of the descriptors (the plain kernel keeps its own).
+        DICT_TRY2(hipMalloc(&D->off_desc, sizeof(BlkDesc) * (size_t)A->n_rowblk));
+        DICT_TRY2(hipMemcpyAsync(D->off_desc, A->blk_desc, sizeof(BlkDesc) * (size_t)A->n_rowblk, hipMemcpyDeviceToDevice, c->stream));
+        const int gu = std::max(1, std::min(c->num_cu * 8, (A->n_rowblk + NWAVE - 1) / NWAVE));
+        hipLaunchKernelGGL(mark_uniform_kernel, dim3(gu), dim3(BLOCK), 0, c->stream, (int)A->n_rowblk,
+                           reinterpret_cast<BlkDesc *>(D->off_desc), A->row_ptr, D->idx_code);
+        DICT_TRY2(hipGetLastError());
+    }
     if (use_vals) {
         // ---- pair stage: which (offset code, value code) pairs occur?  <= 256 of them -> one byte per nnz
         const int gk = (int)std::max<int64_t>(1, std::min<int64_t>(c->num_cu * 8, (A->nnz + BLOCK - 1) / BLOCK));
@@ -793,7 +813,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
 void free_dict(sprs_csr *A) {
     if (!A || !A->dict) return;
     sprs_dict *D = A->dict;
-    for (void *q : {(void *)D->idx_code, (void *)D->pair_code, (void *)D->off_tab, (void *)D->pair_off, D->pair_val, D->wide_desc})
+    for (void *q : {(void *)D->idx_code, (void *)D->pair_code, (void *)D->off_tab, (void *)D->pair_off, D->pair_val, D->wide_desc, D->off_desc})
         if (q) (void)hipFree(q);
     delete D;
     A->dict = nullptr;
@@ -857,9 +877,11 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
     }
     const uint8_t *code = pair ? D->pair_code : D->idx_code;
     const int32_t *otab = pair ? D->pair_off : D->off_tab;
+    // the offset-code stream runs on its own descriptors (uniform blocks flagged); same block numbering as blk_desc
+    const BlkDesc *dsc = reinterpret_cast<const BlkDesc *>((!pair && D->off_desc && c->spmv_uniform != 0) ? D->off_desc : A->blk_desc);
 #define SPRS_DSPMV2(DM, CJ, PR)                                                                                         \
     hipLaunchKernelGGL((spmv_dict_kernel<T, DM, CJ, PR>), dim3(g), dim3(BLOCK), 0, c->stream, count, xcd_chunk,          \
-                       reinterpret_cast<const BlkDesc *>(A->blk_desc), order, A->row_ptr, code, otab, pv, v, x, y, u,   \
+                       dsc, order, A->row_ptr, code, otab, pv, v, x, y, u,                                              \
                        part0, part1, status)
 #define SPRS_DSPMV(DM, CJ) do { if (pair) SPRS_DSPMV2(DM, CJ, (has_val_dict<T>::value)); else SPRS_DSPMV2(DM, CJ, false); } while (0)
     if (conj_x && is_complex<T>::value) {

@@ -174,6 +174,11 @@ def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, t
     sinfo = dict(stream={0: "csr", 1: "offset-codes", 2: "pair-codes"}[mode], mode=mode, distinct_offsets=n_off,
                  distinct_pairs=n_pair, bytes_per_nnz=per_nnz,
                  format_bytes_per_launch=nnz_loc * per_nnz + (n_loc + 1) * 4 + 2 * n_loc * 8, rows=n_loc, nnz=nnz_loc)
+    if mode != 0:
+        nb, nu = A.wide_blocks()
+        uf = nu / nb if nb else 0.0
+        sinfo.update(row_blocks=nb, uniform_blocks=nu,
+                     compulsory_bytes_per_launch=int(nnz_loc * (per_nnz - 1) + (1.0 - uf) * (nnz_loc + (n_loc + 1) * 4) + 2 * n_loc * 8))
     # evidence that the collectives really span `world` ranks, and what each rank moves per SpMV
     halo_b = int(plan["recv_entries"]) * 8
     send_b = int(plan["send_entries"]) * 8

@@ -424,3 +424,96 @@ def test_uniform_blocks(sa, oracle, kind):
         assert np.array_equal(bits(y2), bits(ref))
     assert ys[0] == ys[1]           # same kernel, same lane/row grouping: even the fused dot is identical
     ctx.set("spmv_uniform", -1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("kind", ["band_random", "poisson3d_random", "ragged_mix", "len1_and_len8", "head_shift"])
+def test_offset_code_uniform_blocks(sa, oracle, dtype, kind):
+    """Uniform 64-row blocks of the OFFSET-code stream (variable coefficients: values stay 8 B/nnz, but rows that all
+    repeat one offset pattern need neither row_ptr nor their code bytes).  y must stay bit-identical to the reference
+    fold with the uniform path on and off, for every scalar type, for blocks at every 4-byte phase of the code stream,
+    for uniform blocks next to ragged ones and at the matrix end, for row lengths 1 and 8 (the longest a uniform block
+    may have) and 9 (never uniform)."""
+    from sprsolve_amd import gen
+    import scipy.sparse as sp
+    ctx = sa.default_ctx(0)
+    rng = np.random.default_rng(5)
+    if kind == "band_random":
+        indptr, cols, data, _ = gen.symmetric_banded(64 * 40 + 17, 3)               # 7 per interior row, random values
+        min_uniform = 36
+    elif kind == "poisson3d_random":
+        indptr, cols, data, _ = gen.poisson3d(150, 9, 7, values="random")
+        min_uniform = 7 * 9                                                          # >= one interior block per 150-row line
+    elif kind == "ragged_mix":
+        # rows 0..639: a 5-diagonal band (uniform blocks); rows 640..: random lengths 0..6 (ragged, incl. empty rows); then a band again
+        n = 2000
+        rows, cc = [], []
+        for r in range(n):
+            if r < 640 or r >= 1408:
+                c = [r + o for o in (-2, -1, 0, 1, 2) if 0 <= r + o < n]
+            else:
+                k = int(rng.integers(0, 7))
+                c = sorted(set(int(v) for v in np.clip(r + rng.integers(-9, 10, k), 0, n - 1)))
+            rows += [r] * len(c); cc += c
+        M = sp.csr_matrix((rng.uniform(-1, 1, len(cc)), (rows, cc)), shape=(n, n))
+        M.sort_indices()
+        indptr, cols, data = M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data
+        min_uniform = 8 + 7
+    elif kind == "len1_and_len8":
+        n = 64 * 12
+        rows, cc = [], []
+        for r in range(n):
+            L = 1 if r < 64 * 4 else (8 if r < 64 * 8 else 9)
+            c = [(r + 3 * j) % n for j in range(L)]
+            rows += [r] * L; cc += sorted(c)
+        M = sp.csr_matrix((rng.uniform(-1, 1, len(cc)), (rows, cc)), shape=(n, n))
+        M.sort_indices()
+        indptr, cols, data = M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data
+        min_uniform = 3 + 2
+    else:   # head_shift: 1, 2, 3 short rows in front so that the uniform run starts at every code-stream phase
+        out = []
+        for shift in (1, 2, 3):
+            n = 64 * 9 + 5
+            rows, cc = [0] * shift, list(range(shift))
+            for r in range(1, n):
+                c = [r + o for o in (-1, 0, 1) if 0 <= r + o < n]
+                rows += [r] * len(c); cc += c
+            M = sp.csr_matrix((rng.uniform(-1, 1, len(cc)), (rows, cc)), shape=(n, n))
+            M.sort_indices()
+            out.append((M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data))
+        for indptr, cols, data in out:
+            _check_offset_uniform(sa, oracle, ctx, dtype, indptr, cols, data, 6)
+        return
+    _check_offset_uniform(sa, oracle, ctx, dtype, indptr, cols, data, min_uniform)
+
+
+def _check_offset_uniform(sa, oracle, ctx, dtype, indptr, cols, data, min_uniform):
+    n = indptr.size - 1
+    d = data.astype(dtype)
+    if np.dtype(dtype).kind == "c":
+        d = d * (1 - 0.5j)
+    x = rand_vec(n, dtype, 23)
+    ref = oracle.spmv(indptr, cols, d, x)
+    ctx.set("spmv_dict", 1)
+    try:
+        for uni in (1, 0):
+            ctx.set("spmv_uniform", uni)
+            A = sa.HipCsr.new((n, n), indptr, cols, d)
+            assert A.stream_format()[0] == 1
+            nb, nu = A.wide_blocks()
+            if uni:
+                assert nb >= (n + 63) // 64 and min_uniform <= nu <= nb, (nb, nu, min_uniform)
+            else:
+                assert nu == 0
+            y = np.full(n, 3.0, dtype=dtype)
+            A.mul_vec(x, y)
+            assert np.array_equal(bits(y), bits(ref)), ("mul_vec", uni)
+            y2 = np.zeros(n, dtype=dtype)
+            dot = A.mul_vec_dot(x, y2)
+            assert np.array_equal(bits(y2), bits(ref)), ("mul_vec_dot", uni)
+            e = oracle.conj_dot(x, ref)
+            tol = 2e-4 if np.dtype(dtype).itemsize in (4, 8) and np.dtype(dtype) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-12
+            assert abs(dot - e) <= tol * max(1.0, abs(e))
+    finally:
+        ctx.set("spmv_uniform", -1)
+        ctx.set("spmv_dict", -1)
