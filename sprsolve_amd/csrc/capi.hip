@@ -108,6 +108,7 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     else if (k == "spmv_dict") { if (value < -1 || value > 2) return SPRS_INVALID_ARGUMENT; c->spmv_dict = (int)value; }
     else if (k == "spmv_wide") c->spmv_wide = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_uniform") c->spmv_uniform = value < 0 ? -1 : (value ? 1 : 0);
+    else if (k == "spmv_eqrows") c->spmv_eqrows = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "halo_overlap") c->halo_overlap = value ? 1 : 0;
     else if (k == "gs_graph") c->gs_graph = value ? 1 : 0;
     else if (k == "poll") { if (value < 1) return SPRS_INVALID_ARGUMENT; c->poll = (int)value; }
@@ -125,6 +126,7 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     if (k == "spmv_dict") return c->spmv_dict;
     if (k == "spmv_wide") return c->spmv_wide;
     if (k == "spmv_uniform") return c->spmv_uniform;
+    if (k == "spmv_eqrows") return c->spmv_eqrows;
     if (k == "halo_overlap") return c->halo_overlap;
     if (k == "gs_graph") return c->gs_graph;
     if (k == "poll") return c->poll;
@@ -518,6 +520,7 @@ int sprs_csr_destroy(sprs_csr *A) {
     if (A->rowblk) (void)hipFree(A->rowblk);
     if (A->blk_order) (void)hipFree(A->blk_order);
     if (A->blk_desc) (void)hipFree(A->blk_desc);
+    if (A->blk_desc_eq) (void)hipFree(A->blk_desc_eq);
     free_dict(A);
     if (A->x_tmp) (void)hipFree(A->x_tmp);
     if (A->y_tmp) (void)hipFree(A->y_tmp);

@@ -44,6 +44,7 @@ struct sprs_ctx {
     // 1 offset codes + values, 2 (offset, value) pair codes.  Read at handle creation (what is built) and at launch (what is used).
     int spmv_dict = -1;
     int spmv_wide = -1;   // f64 pair codes: two rows per lane (16-byte gathers); -1 / 1 on, 0 off
+    int spmv_eqrows = -1; // plain-CSR stream: blocks of equal-length rows take their extents from the descriptor (no row_ptr read); read at creation
     int spmv_uniform = -1; // ... and blocks whose rows all repeat one code sequence read neither codes nor row_ptr; read at creation
     int halo_overlap = 1;  // distributed SpMV: run the halo-free rows while the halo travels
     int gs_graph = 0;    // Gauss-Seidel: 1 = replay a sweep's level launches from a hipGraph (measured: no gain, r01_tuning.md)
@@ -141,6 +142,7 @@ struct sprs_csr {
     int32_t *rowblk = nullptr;   // device: n_rowblk+1 row starts, bit31 set on vector-mode blocks
     int32_t n_rowblk = 0;
     void *blk_desc = nullptr;      // device: one 16-byte {ra, rb|flag, pa, nn} descriptor per row block
+    void *blk_desc_eq = nullptr;   // device: the plain-CSR kernel's copy, equal-length blocks flagged (rb bit 30, row length in nn >> 16)
     int32_t *blk_order = nullptr;  // device: schedule of the row blocks (n_rowblk entries) or null = natural order
     int64_t sched_period = 0;      // rows between the far bands the schedule folds over (0 = no schedule)
     bool sched_strip_major = false;
