@@ -359,6 +359,23 @@ def bench100(args):
                converge_check=dict(tol=1e-16, max_iter=1500, status=int(r.status), iters=int(r.its), rel_res=float(r.res),
                                    max_abs_err_vs_exact=err),
                roofline=None)
+    # cfg 1 as BASELINE.json words it ("1e4-row random tridiagonal f64 CSR"; SURVEY §8d cfg 1 (ii)): off-diagonals U(-1,1),
+    # diagonal 2 + |l| + |u|, rhs U(-1,1), x0 = 0, tol 1e-10 — CPU restatement, 4 threads, same sampling
+    tip, tix, tdv, trhs = gen.random_tridiagonal(10000)
+    t64, tx64 = tip.astype(np.int64), tix.astype(np.int64)
+    orc.set_threads(4)
+    ts = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        rt = orc.bicgstab(t64, tx64, tdv, trhs, np.zeros(10000), K, 0.0, parallel=True)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    rc = orc.bicgstab(t64, tx64, tdv, trhs, np.zeros(10000), 1500, 1e-10, parallel=True)
+    true_res = float(np.linalg.norm(orc.spmv(tip, tix, tdv, rc.x) - trhs) / np.linalg.norm(trhs))
+    out["also"] = dict(cfg1_random_tridiagonal_1e4=dict(
+        workload="random tridiagonal n=1e4, nnz=%d, BiCGStab tol=0 fixed %d iterations, 4 threads, median of 7" % (int(tip[-1]), K),
+        value=K / ts[3], unit="iterations/s", median_s=ts[3], threads=4,
+        converge_check=dict(tol=1e-10, status=int(rc.status), iters=int(rc.its), rel_res=float(rc.res), true_rel_res=true_res)))
     try:
         import torch
         if torch.cuda.is_available():
