@@ -1,6 +1,7 @@
 // Internal declarations shared by the translation units of libsprsolve_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -53,6 +54,11 @@ struct sprs_ctx {
     double *d_scal = nullptr;  // small device result buffer
     double *h_scal = nullptr;  // pinned host mirror
     mutable char err[512] = {0};
+    // When both are set, the next SpMV kernel launch records them as its OWN begin / end (hipExtLaunchKernelGGL): the
+    // solver's profile then times the kernel exactly as rocprofv3 does, without the dispatch gap two hipEventRecord
+    // calls around the launch would include (1104 vs 1089 us on the cfg-5 plain stream).  Set and cleared by
+    // KrylovBase::spmv under the context mutex.
+    hipEvent_t prof_start = nullptr, prof_stop = nullptr;
     // Serialises every entry point that uses per-context or per-handle scratch (reduction partials, the pinned
     // scalar mirror, the host-slice staging buffers) or that must see its own results on the single stream: the
     // reference shares `&M` between threads (bicg_stab.rs:17-18 `T: Send + Sync`, mat.rs:156-161), so concurrent
@@ -74,6 +80,15 @@ struct CtxLock {
                      hipGetErrorString(e__));                                                       \
             return SPRS_ERR_HIP;                                                                    \
         }                                                                                           \
+    } while (0)
+
+// Launch of an SpMV kernel on the context's stream; timed by the launch itself when a profile is being taken.
+#define SPRS_LAUNCH_SPMV(c, kernel, grid, ...)                                                                            \
+    do {                                                                                                                 \
+        if ((c)->prof_start && (c)->prof_stop)                                                                           \
+            hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(sprs::BLOCK), 0, (c)->stream, (c)->prof_start, (c)->prof_stop, 0, __VA_ARGS__); \
+        else                                                                                                             \
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(sprs::BLOCK), 0, (c)->stream, __VA_ARGS__);                      \
     } while (0)
 
 #define SPRS_TRY(expr)                       \

@@ -422,7 +422,7 @@ static int launch_spmv_impl(const sprs_csr *A, const int32_t *order, int count, 
         return launch_spmv_dict<T>(A, dm, order, count, g, xcd_chunk, x, y, dot_mode, u, part0, part1, status, conj_x);
     const bool nt = c->spmv_nt > 0;   // measured: non-temporal stream loads never pay once the loads are batched
 #define SPRS_SPMV2(D, CJ, NTF)                                                                                        \
-    hipLaunchKernelGGL((spmv_kernel<T, D, CJ, NTF>), dim3(g), dim3(BLOCK), 0, c->stream, count,                       \
+    SPRS_LAUNCH_SPMV(c, (spmv_kernel<T, D, CJ, NTF>), g, count,                                                       \
                        xcd_chunk, A->blk_desc_eq ? 1 : 0, reinterpret_cast<const BlkDesc *>(A->blk_desc_eq ? A->blk_desc_eq : A->blk_desc), order, A->row_ptr, A->col_idx, v, x, y, u, part0, part1, status)
 #define SPRS_SPMV(D, CJ) do { if (nt) SPRS_SPMV2(D, CJ, true); else SPRS_SPMV2(D, CJ, false); } while (0)
     if (conj_x && is_complex<T>::value) {  // only CSMINRES on complex data needs the conjugated gather

@@ -867,7 +867,7 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
             const int gw = g;     // same grid as the 64-row kernel: the consumers reduce exactly spmv_num_partials(A) partials
             const BlkDesc *wd = reinterpret_cast<const BlkDesc *>(D->wide_desc);
             const double *pvd = reinterpret_cast<const double *>(D->pair_val);
-#define SPRS_WSPMV(DM) hipLaunchKernelGGL((spmv_pair2_kernel<DM>), dim3(gw), dim3(BLOCK), 0, c->stream, count_w, xcd_chunk, wd, order_w, \
+#define SPRS_WSPMV(DM) SPRS_LAUNCH_SPMV(c, (spmv_pair2_kernel<DM>), gw, count_w, xcd_chunk, wd, order_w, \
                                           A->row_ptr, D->pair_code, D->pair_off, pvd, x, y, u, part0, part1, status, (int)A->nrows, (int)A->ncols)
             if (dot_mode == 0) SPRS_WSPMV(0); else if (dot_mode == 1) SPRS_WSPMV(1); else SPRS_WSPMV(2);
 #undef SPRS_WSPMV
@@ -880,7 +880,7 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
     // the offset-code stream runs on its own descriptors (uniform blocks flagged); same block numbering as blk_desc
     const BlkDesc *dsc = reinterpret_cast<const BlkDesc *>((!pair && D->off_desc && c->spmv_uniform != 0) ? D->off_desc : A->blk_desc);
 #define SPRS_DSPMV2(DM, CJ, PR)                                                                                         \
-    hipLaunchKernelGGL((spmv_dict_kernel<T, DM, CJ, PR>), dim3(g), dim3(BLOCK), 0, c->stream, count, xcd_chunk,          \
+    SPRS_LAUNCH_SPMV(c, (spmv_dict_kernel<T, DM, CJ, PR>), g, count, xcd_chunk,                                          \
                        dsc, order, A->row_ptr, code, otab, pv, v, x, y, u,                                              \
                        part0, part1, status)
 #define SPRS_DSPMV(DM, CJ) do { if (pair) SPRS_DSPMV2(DM, CJ, (has_val_dict<T>::value)); else SPRS_DSPMV2(DM, CJ, false); } while (0)
