@@ -46,6 +46,9 @@ struct sprs_ctx {
     int spmv_dict = -1;
     int spmv_wide = -1;   // f64 pair codes: two rows per lane (16-byte gathers); -1 / 1 on, 0 off
     int spmv_eqrows = -1; // plain-CSR stream: blocks of equal-length rows take their extents from the descriptor (no row_ptr read); read at creation
+    int spmv_period = 0;   // f64 pair codes: XCD-period schedule for matrices with a far band (3-D stencils), 1 = on.  Read at creation
+                           // and at launch.  Off by default: it cuts the SpMV's fabric reads by 58 % (x crosses the fabric once) and the
+                           // kernel's time not at all (profiles/r02_tuning.md §7)
     int spmv_uniform = -1; // ... and blocks whose rows all repeat one code sequence read neither codes nor row_ptr; read at creation
     int halo_overlap = 1;  // distributed SpMV: run the halo-free rows while the halo travels
     int gs_graph = 0;    // Gauss-Seidel: 1 = replay a sweep's level launches from a hipGraph (measured: no gain, r01_tuning.md)
@@ -141,6 +144,8 @@ struct sprs_dict {
     int n_off = 0, n_val = 0, n_pair = 0;
     void *wide_desc = nullptr;     // device: descriptors of the 128-row blocks of the two-rows-per-lane kernel (f64 pair codes)
     int n_wide = 0;
+    int32_t *wide_order = nullptr; // device: XCD-period schedule of the 128-row blocks (null = natural order)
+    int64_t period = 0;            // the far band it folds over (rows)
     void *off_desc = nullptr;      // device: copy of blk_desc for the offset-code stream with the uniform blocks flagged (bit 30, nn = row length)
     int n_off_uniform = 0;
 };

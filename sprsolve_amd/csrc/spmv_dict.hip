@@ -799,6 +799,39 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
                 }
                 DICT_TRY2(hipStreamSynchronize(c->stream));
                 D->n_wide = nw;
+                // XCD-period schedule (knob "spmv_period").  The pair-code kernel streams ~26 B per row, so the x lines a
+                // row block gathers stay in its XCD's 4 MiB L2 for several planes' worth of that XCD's rows.  With the far
+                // band P = max |col - row| (a 3-D stencil's plane), rows are cut into chunks of P/8 and chunk c goes to XCD
+                // c mod 8: rows r and r +- P are multiplied on the SAME XCD one chunk apart, so x[r + P] is fetched over
+                // the fabric once — when row r needs it — and hits L2 as the centre of row r + P and the lower
+                // neighbour of row r + 2P.  Positions of the walk belong to XCD (pos / NWAVE) mod 8 (workgroups are
+                // dealt round-robin over the XCDs — a locality hint only, never needed for correctness).
+                int64_t P = 0;
+                for (const auto &o : offs) P = std::max<int64_t>(P, std::llabs((long long)o.first));
+                const int64_t G = P / 8;
+                if (c->spmv_period > 0 && G >= 16 * 128 && P * 4 <= A->nrows && nw >= 8 * NWAVE * 8) {
+                    std::vector<std::vector<int32_t>> q(8);
+                    for (int j = 0; j < nw; ++j) q[(size_t)((wd[(size_t)j].ra / G) % 8)].push_back(j);
+                    std::vector<int32_t> ord((size_t)nw);
+                    size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0}, filled = 0;
+                    while (filled < (size_t)nw) {
+                        for (int x = 0; x < 8 && filled < (size_t)nw; ++x) {
+                            for (int k = 0; k < NWAVE && filled < (size_t)nw; ++k) {
+                                int src = x;
+                                if (pos[src] >= q[src].size()) {          // this XCD's queue ran dry: take from the longest one
+                                    size_t best = 0;
+                                    for (int y2 = 0; y2 < 8; ++y2)
+                                        if (q[y2].size() - pos[y2] > best) { best = q[y2].size() - pos[y2]; src = y2; }
+                                }
+                                ord[filled++] = q[src][pos[src]++];
+                            }
+                        }
+                    }
+                    DICT_TRY2(hipMalloc((void **)&D->wide_order, sizeof(int32_t) * (size_t)nw));
+                    DICT_TRY2(hipMemcpyAsync(D->wide_order, ord.data(), sizeof(int32_t) * (size_t)nw, hipMemcpyHostToDevice, c->stream));
+                    DICT_TRY2(hipStreamSynchronize(c->stream));
+                    D->period = P;
+                }
             }
         }
     }
@@ -813,7 +846,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
 void free_dict(sprs_csr *A) {
     if (!A || !A->dict) return;
     sprs_dict *D = A->dict;
-    for (void *q : {(void *)D->idx_code, (void *)D->pair_code, (void *)D->off_tab, (void *)D->pair_off, D->pair_val, D->wide_desc, D->off_desc})
+    for (void *q : {(void *)D->idx_code, (void *)D->pair_code, (void *)D->off_tab, (void *)D->pair_off, D->pair_val, D->wide_desc, D->off_desc, (void *)D->wide_order})
         if (q) (void)hipFree(q);
     delete D;
     A->dict = nullptr;
@@ -860,7 +893,7 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
         // whose split is made on pairs of 64-row blocks for this purpose (dist.hip)
         const int32_t *order_w = nullptr;
         int count_w = -1;
-        if (order == nullptr && count == A->n_rowblk) count_w = D->n_wide;
+        if (order == nullptr && count == A->n_rowblk) { count_w = D->n_wide; order_w = c->spmv_period > 0 ? D->wide_order : nullptr; }
         else if (A->dist && A->dist->order_int_w && order == A->dist->order_int && count == A->dist->n_int) { order_w = A->dist->order_int_w; count_w = A->dist->n_int_w; }
         else if (A->dist && A->dist->order_bnd_w && order == A->dist->order_bnd && count == A->dist->n_bnd) { order_w = A->dist->order_bnd_w; count_w = A->dist->n_bnd_w; }
         if (pair && D->wide_desc && c->spmv_wide != 0 && count_w >= 0 && A->nrows >= 2 && A->ncols >= 2) {

@@ -517,3 +517,34 @@ def _check_offset_uniform(sa, oracle, ctx, dtype, indptr, cols, data, min_unifor
     finally:
         ctx.set("spmv_uniform", -1)
         ctx.set("spmv_dict", -1)
+
+
+def test_xcd_period_schedule_is_a_pure_reordering(sa, oracle):
+    """Knob spmv_period = 1: the 128-row blocks of the f64 pair-code stream are walked in the XCD-period order (rows r
+    and r +- plane on one XCD).  Only the ORDER in which blocks are multiplied changes: y bit-identical, the solve
+    reaches the same solution; the fused dot groups rows differently (tolerance)."""
+    from sprsolve_amd import gen
+    ctx = sa.default_ctx(0)
+    nx, ny, nz = 160, 128, 12                      # plane = 20480 rows: chunks of 2560 rows = 20 wide blocks
+    indptr, cols, data, rhs = gen.poisson3d(nx, ny, nz)
+    n = rhs.size
+    x = rand_vec(n, np.float64, 3)
+    ref = oracle.spmv(indptr, cols, data, x)
+    out = {}
+    try:
+        for period in (0, 1):
+            ctx.set("spmv_period", period)
+            A = sa.HipCsr.new((n, n), indptr, cols, data)
+            assert A.stream_format()[0] == 2
+            y = np.zeros(n); d = A.mul_vec_dot(x, y)
+            assert np.array_equal(bits(y), bits(ref)), period
+            e = oracle.conj_dot(x, ref)
+            assert abs(d - e) <= 1e-12 * max(1.0, abs(e))
+            s = sa.BiCGStab.new(A, n)
+            sol = np.zeros(n)
+            its, res = s.solve(rhs, sol, 2000, 1e-10)
+            assert np.max(np.abs(sol - 1.0)) < 1e-7
+            out[period] = its
+        assert abs(out[0] - out[1]) <= max(3, out[0] // 10)
+    finally:
+        ctx.set("spmv_period", 0)
