@@ -1,0 +1,87 @@
+"""Deep fuzz of every SpMV stream / kernel / knob combination against the oracle's fold (bit-exact y), far longer than
+the test suite's 200 matrices: structured matrices that hit the uniform-block paths (offset-code and pair-code), the
+equal-length-row shortcut of the plain kernel, the XCD-period schedule, ragged and empty rows, all four scalar types.
+  usage (GPU box): python scripts/fuzz_spmv.py [seconds] [seed]      -> prints a summary, exits 1 on the first mismatch"""
+import itertools
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import sprsolve_amd as sa            # noqa: E402
+from oracle import oracle           # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+ctx = sa.default_ctx(0)
+DT = [np.float64, np.complex128, np.float32, np.complex64]
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+def make(n):
+    kind = rng.integers(0, 5)
+    nb = int(rng.integers(1, 9))
+    offs = np.unique(np.concatenate([[0], rng.integers(-min(n - 1, 40), min(n - 1, 40) + 1, size=nb)]))
+    if kind == 3 and n > 600:       # far band (period schedule, plane-like)
+        offs = np.unique(np.concatenate([offs, [-(n // 5), n // 5]]))
+    rows = []
+    ragged_lo, ragged_hi = (int(rng.integers(0, n)), int(rng.integers(0, n)))
+    ragged_lo, ragged_hi = min(ragged_lo, ragged_hi), max(ragged_lo, ragged_hi)
+    for r in range(n):
+        c = r + offs
+        c = c[(c >= 0) & (c < n)]
+        if kind in (1, 4) and ragged_lo <= r < ragged_hi:
+            c = c[rng.uniform(size=c.size) < 0.6]
+        if kind == 2 and rng.uniform() < 0.02:
+            c = c[:0]
+        rows.append(c)
+    indptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum([len(c) for c in rows], out=indptr[1:])
+    cols = np.concatenate(rows).astype(np.int32) if indptr[-1] else np.zeros(0, np.int32)
+    if rng.uniform() < 0.5:
+        vals = np.array([1.0, -1.0, 0.5, 2.0, -3.25, 6.0])[rng.integers(0, 6, cols.size)]      # value dictionary
+    else:
+        vals = rng.uniform(-1, 1, cols.size)                                                 # none
+    return indptr, cols, vals
+
+
+t_end = time.time() + budget
+count = combos = 0
+while time.time() < t_end:
+    n = int(rng.choice([rng.integers(1, 400), rng.integers(400, 6000), rng.integers(6000, 40000)]))
+    indptr, cols, vals = make(n)
+    if indptr[-1] == 0:
+        continue
+    dtype = DT[int(rng.integers(0, 4))]
+    d = vals.astype(dtype)
+    if np.dtype(dtype).kind == "c":
+        d = d * (1 + 0.25j)
+    x = rng.uniform(-1, 1, n).astype(dtype)
+    if np.dtype(dtype).kind == "c":
+        x = x + 1j * rng.uniform(-1, 1, n).astype(x.real.dtype)
+    ref = oracle.spmv(indptr, cols, d, x)
+    for knob, wide, uni, eq, period in itertools.product((0, 1, 2), (0, 1), (0, 1), (0, 1), (0, 1)):
+        if (knob != 2 and (wide or period)) or (knob == 0 and uni) or (knob != 0 and eq == 0):
+            continue
+        for k, v in (("spmv_dict", knob), ("spmv_wide", wide), ("spmv_uniform", uni), ("spmv_eqrows", eq), ("spmv_period", period)):
+            ctx.set(k, v)
+        A = sa.HipCsr.new((n, n), indptr, cols, d)
+        y = np.full(n, 7.0, dtype=dtype)
+        A.mul_vec(x, y)
+        y2 = np.zeros(n, dtype=dtype)
+        A.mul_vec_dot(x, y2)
+        combos += 1
+        if not (np.array_equal(bits(y), bits(ref)) and np.array_equal(bits(y2), bits(ref))):
+            print("MISMATCH n=%d dtype=%s knobs dict=%d wide=%d uniform=%d eqrows=%d period=%d stream=%s bad=%d" % (
+                n, np.dtype(dtype).name, knob, wide, uni, eq, period, A.stream_format(), int(np.sum(bits(y) != bits(ref)))))
+            np.savez("gpurun_out/fuzz_fail.npz", indptr=indptr, cols=cols, d=d, x=x)
+            sys.exit(1)
+    count += 1
+for k in ("spmv_dict", "spmv_wide", "spmv_uniform", "spmv_eqrows"):
+    ctx.set(k, -1)
+ctx.set("spmv_period", 0)
+print("fuzz ok: %d matrices, %d (matrix, knob) combinations, all y bit-identical to the reference fold" % (count, combos))
