@@ -390,6 +390,7 @@ typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 constexpr int CAP2 = 2 * nnz_cap<double>::value;          // 1024 code bytes per wide block
 constexpr int CW2 = (CAP2 + 3 + CPAD + 15) / 16 * 4;      // dwords of a wavefront's slice (multiple of 4: b128 stores)
 
+constexpr int UNI_OFF_MAXLEN = 32;          // offset-code stream: the pattern is read from the staged first row, chunk by chunk
 constexpr int UNI2_MAXLEN = 8;              // ... of at most this many codes; the descriptor's nn then holds that length
 
 // One wavefront per 128-row block: are all its rows copies of the first one (same length, same codes)?  Interior
@@ -397,13 +398,13 @@ constexpr int UNI2_MAXLEN = 8;              // ... of at most this many codes; t
 // pattern is read once per block from the first row (spmv_pair2_kernel, uniform path).
 __global__ __launch_bounds__(BLOCK) void mark_uniform_kernel(int n_wide, BlkDesc *__restrict__ desc,
                                                              const int32_t *__restrict__ row_ptr,
-                                                             const uint8_t *__restrict__ code) {
+                                                             const uint8_t *__restrict__ code, int maxlen) {
     const int lane = threadIdx.x & (WAVE - 1);
     for (int b = blockIdx.x * NWAVE + (threadIdx.x >> 6); b < n_wide; b += gridDim.x * NWAVE) {
         const BlkDesc d = desc[b];
         const int nr = d.rb - d.ra;
         const int L0 = row_ptr[d.ra + 1] - row_ptr[d.ra];
-        bool ok = nr >= 1 && L0 >= 1 && L0 <= UNI2_MAXLEN && d.nn == nr * L0;
+        bool ok = nr >= 1 && L0 >= 1 && L0 <= maxlen && d.nn == nr * L0;
         if (ok) {
             for (int r = d.ra + lane; r < d.rb; r += WAVE) {
                 const int s = row_ptr[r];
@@ -747,8 +748,16 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
         DICT_TRY2(hipMemcpyAsync(D->off_desc, A->blk_desc, sizeof(BlkDesc) * (size_t)A->n_rowblk, hipMemcpyDeviceToDevice, c->stream));
         const int gu = std::max(1, std::min(c->num_cu * 8, (A->n_rowblk + NWAVE - 1) / NWAVE));
         hipLaunchKernelGGL(mark_uniform_kernel, dim3(gu), dim3(BLOCK), 0, c->stream, (int)A->n_rowblk,
-                           reinterpret_cast<BlkDesc *>(D->off_desc), A->row_ptr, D->idx_code);
+                           reinterpret_cast<BlkDesc *>(D->off_desc), A->row_ptr, D->idx_code, UNI_OFF_MAXLEN);
         DICT_TRY2(hipGetLastError());
+        // how many qualified: the auto policy wants to know for matrices that live in the Infinity Cache (small: a
+        // few MB of descriptors at most); HBM-sized ones take the offset stream anyway
+        if ((double)A->nnz * (sizeof(T) + 4) + 3.0 * A->nrows * sizeof(T) < 192.0 * 1024 * 1024) {
+            std::vector<BlkDescHost2> hd((size_t)A->n_rowblk);
+            DICT_TRY2(hipMemcpyAsync(hd.data(), D->off_desc, sizeof(BlkDescHost2) * hd.size(), hipMemcpyDeviceToHost, c->stream));
+            DICT_TRY2(hipStreamSynchronize(c->stream));
+            for (const auto &d : hd) D->n_off_uniform += ((uint32_t)d.rb & UNI2) != 0;
+        }
     }
     if (use_vals) {
         // ---- pair stage: which (offset code, value code) pairs occur?  <= 256 of them -> one byte per nnz
@@ -794,7 +803,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
                 if (c->spmv_uniform != 0 && nw > 0) {
                     const int gu = std::max(1, std::min(c->num_cu * 8, (nw + NWAVE - 1) / NWAVE));
                     hipLaunchKernelGGL(mark_uniform_kernel, dim3(gu), dim3(BLOCK), 0, c->stream, nw,
-                                       reinterpret_cast<BlkDesc *>(D->wide_desc), A->row_ptr, D->pair_code);
+                                       reinterpret_cast<BlkDesc *>(D->wide_desc), A->row_ptr, D->pair_code, UNI2_MAXLEN);
                     DICT_TRY2(hipGetLastError());
                 }
                 DICT_TRY2(hipStreamSynchronize(c->stream));
@@ -868,13 +877,14 @@ int dict_mode(const sprs_csr *A) {
     if ((uint64_t)std::max(A->ncols, A->nrows + 1) * std::max<size_t>(dtype_size(A->dtype), 4) >= (1ull << 32)) return 0;
     if (A->dict->pair_code && A->ctx->spmv_dict != 1) return 2;
     if (A->ctx->spmv_dict == -1) {
-        // offset codes + values pay only where the saved 3 B/nnz matter (measured, profiles/r01_tuning.md): f64 / f32
-        // matrices that stream from HBM (cfg-5 size: 940 vs 1110 us).  Cache-resident ones run the same (cfg 3:
-        // 25 vs 25 us) and complex ones slower (cfg 4: 27 vs 16 us; 17 instead of 20 B/nnz is not worth the
-        // lane-per-row layout), so auto keeps the plain stream for those.
+        // offset codes + values for every REAL matrix that has them (measured, profiles/r02_tuning.md): HBM-sized ones
+        // (cfg-5 pattern, random values: 885 vs 1130 us) and cache-resident ones alike (cfg 3: 21.8 vs 23.9 us, MINRES
+        // 21.8 k vs 20.8 k it/s).  Complex ones run slower (cfg 4: 24.7 vs 15.0 us; 17 instead of 20 B/nnz is not worth
+        // the lane-per-row layout): auto keeps the plain stream for those.
         const double sz = (double)dtype_size(A->dtype);
         const bool cache_resident = (double)A->nnz * (sz + 4) + 3.0 * A->nrows * sz < 192.0 * 1024 * 1024;
-        if (dtype_is_complex(A->dtype) || cache_resident) return 0;
+        if (dtype_is_complex(A->dtype)) return 0;
+        (void)cache_resident;
     }
     return 1;
 }

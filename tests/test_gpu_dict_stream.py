@@ -71,8 +71,9 @@ def test_formats_bit_identical(sa, oracle, dtype, name):
             assert mode == 1 and n_val == 0
         else:
             few_values = real and name != "banded_random_values"
-            # auto (-1) keeps the plain stream where offset codes alone do not pay (complex, cache-resident)
-            assert mode == (2 if few_values else (1 if knob == 2 else 0)), (mode, n_off, n_val)
+            # auto (-1): offset codes for every real matrix that has them; the plain stream for complex ones (where
+            # offset codes alone do not pay: 17 instead of 20 B/nnz against the lane-per-row layout)
+            assert mode == (2 if few_values else (1 if (knob == 2 or real) else 0)), (mode, n_off, n_val)
             if few_values:
                 assert n_val == (7 if name == "poisson3d" else 6)      # distinct (offset, value) pairs
         if knob != 0:
@@ -432,8 +433,8 @@ def test_offset_code_uniform_blocks(sa, oracle, dtype, kind):
     """Uniform 64-row blocks of the OFFSET-code stream (variable coefficients: values stay 8 B/nnz, but rows that all
     repeat one offset pattern need neither row_ptr nor their code bytes).  y must stay bit-identical to the reference
     fold with the uniform path on and off, for every scalar type, for blocks at every 4-byte phase of the code stream,
-    for uniform blocks next to ragged ones and at the matrix end, for row lengths 1 and 8 (the longest a uniform block
-    may have) and 9 (never uniform)."""
+    for uniform blocks next to ragged ones and at the matrix end, for row lengths 1, 8, 9 (a second 8-slot chunk of the
+    pattern), 32 (the longest a uniform block may have) and 33 (never uniform)."""
     from sprsolve_amd import gen
     import scipy.sparse as sp
     ctx = sa.default_ctx(0)
@@ -463,13 +464,13 @@ def test_offset_code_uniform_blocks(sa, oracle, dtype, kind):
         n = 64 * 12
         rows, cc = [], []
         for r in range(n):
-            L = 1 if r < 64 * 4 else (8 if r < 64 * 8 else 9)
+            L = 1 if r < 64 * 3 else (8 if r < 64 * 6 else (9 if r < 64 * 8 else (32 if r < 64 * 10 else 33)))
             c = [(r + 3 * j) % n for j in range(L)]
             rows += [r] * L; cc += sorted(c)
         M = sp.csr_matrix((rng.uniform(-1, 1, len(cc)), (rows, cc)), shape=(n, n))
         M.sort_indices()
         indptr, cols, data = M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data
-        min_uniform = 3 + 2
+        min_uniform = 2 + 2 + 1
     else:   # head_shift: 1, 2, 3 short rows in front so that the uniform run starts at every code-stream phase
         out = []
         for shift in (1, 2, 3):
