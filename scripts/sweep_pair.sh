@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for knobs in "xcd_chunk=0" "xcd_chunk=1" "xcd_chunk=0 --set spmv_grid=768" "xcd_chunk=1 --set spmv_grid=768" "xcd_chunk=0 --set spmv_grid=1280" "xcd_chunk=1 --set spmv_grid=1280" "xcd_chunk=0" "xcd_chunk=1"; do
+for knobs in "spmv_period=0" "spmv_period=1" "spmv_period=0 --set spmv_grid=1280" "spmv_period=1 --set spmv_grid=1280" "spmv_period=0" "spmv_period=1"; do
   timeout -k 10 100 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-also --set $knobs > gpurun_out/pr.json 2> gpurun_out/pr.err || { tail -3 gpurun_out/pr.err; exit 1; }
   python - <<PY
 import json

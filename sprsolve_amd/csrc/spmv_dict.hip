@@ -568,6 +568,31 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
             uint32_t hi_bits = 0;
 #pragma unroll
             for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; av[t] = 0.0; }
+            if (c_rb - c_ra == 2 * WAVE) {
+                // FULL uniform block (every lane has both rows — the interior of a stencil): no row masks, and no clamp
+                // either: the second row's column r0 + 1 + off is valid, so the 16-byte load at r0 + off stays inside x.
+                // Offset and value of a slot are wave-uniform: made scalars, the gather is SGPR base + lane offset and
+                // the products take the value from SGPRs — 4 vector ALU instructions per slot instead of ~25
+                // (the kernel ran at 43 % VALU utilisation, profiles/r02_tuning.md §9).
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (t >= ulen) break;
+                    const PairEnt<T> e = s_pair[(int)((c_pat >> (8 * t)) & 255u)];
+                    const int off8 = __builtin_amdgcn_readfirstlane(e.off8);
+                    const uint32_t vlo = __builtin_amdgcn_readfirstlane((int)(uint32_t)__double_as_longlong(e.val));
+                    const uint32_t vhi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(__double_as_longlong(e.val) >> 32));
+                    av[t] = __longlong_as_double((long long)(((uint64_t)vhi << 32) | vlo));
+                    const D2 px = *reinterpret_cast<const D2 *>(xbytes + (int64_t)off8 + r8);
+                    pl[t] = px.lo; ph[t] = px.hi;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (t >= ulen) break;
+                    acc0 = acc0 + pl[t] * av[t];
+                    acc1 = acc1 + ph[t] * av[t];
+                }
+            } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 if (t >= ulen) break;
@@ -585,6 +610,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
                 if (t >= ulen) break;
                 if (len0 > 0) acc0 = acc0 + (((hi_bits >> t) & 1u) ? ph[t] : pl[t]) * av[t];
                 if (len1 > 0) acc1 = acc1 + ph[t] * av[t];
+            }
             }
         } else
         for (int j0 = 0; __builtin_amdgcn_ballot_w64(j0 < lenm) != 0; j0 += 8) {
