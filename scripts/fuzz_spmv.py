@@ -23,9 +23,12 @@ def bits(a):
 
 
 def make(n):
-    kind = rng.integers(0, 5)
+    kind = rng.integers(0, 7)
     nb = int(rng.integers(1, 9))
     offs = np.unique(np.concatenate([[0], rng.integers(-min(n - 1, 40), min(n - 1, 40) + 1, size=nb)]))
+    if kind >= 5 and n > 8:         # stencil-like: runs of consecutive columns (column triples), at most 8 per row
+        o0 = int(rng.integers(-min(n - 1, 40), min(n - 1, 40) - 3))
+        offs = np.unique(np.concatenate([offs[:int(rng.integers(0, 4))], o0 + np.arange(int(rng.integers(3, 6)))]))[:8]
     if kind == 3 and n > 600:       # far band (period schedule, plane-like)
         offs = np.unique(np.concatenate([offs, [-(n // 5), n // 5]]))
     rows = []
@@ -42,7 +45,9 @@ def make(n):
     indptr = np.zeros(n + 1, dtype=np.int32)
     np.cumsum([len(c) for c in rows], out=indptr[1:])
     cols = np.concatenate(rows).astype(np.int32) if indptr[-1] else np.zeros(0, np.int32)
-    if rng.uniform() < 0.5:
+    if kind >= 5:                   # one value per offset: interior blocks are uniform
+        vals = (np.concatenate([c - r for r, c in enumerate(rows)]) * 0.375 + 1.0) if indptr[-1] else np.zeros(0)
+    elif rng.uniform() < 0.5:
         vals = np.array([1.0, -1.0, 0.5, 2.0, -3.25, 6.0])[rng.integers(0, 6, cols.size)]      # value dictionary
     else:
         vals = rng.uniform(-1, 1, cols.size)                                                 # none
@@ -64,10 +69,11 @@ while time.time() < t_end:
     if np.dtype(dtype).kind == "c":
         x = x + 1j * rng.uniform(-1, 1, n).astype(x.real.dtype)
     ref = oracle.spmv(indptr, cols, d, x)
-    for knob, wide, uni, eq, period in itertools.product((0, 1, 2), (0, 1), (0, 1), (0, 1), (0, 1)):
-        if (knob != 2 and (wide or period)) or (knob == 0 and uni) or (knob != 0 and eq == 0):
+    for knob, wide, uni, eq, period, tri in itertools.product((0, 1, 2), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1)):
+        if (knob != 2 and (wide or period)) or (knob == 0 and uni) or (knob != 0 and eq == 0) or (not tri and not wide):
             continue
-        for k, v in (("spmv_dict", knob), ("spmv_wide", wide), ("spmv_uniform", uni), ("spmv_eqrows", eq), ("spmv_period", period)):
+        for k, v in (("spmv_dict", knob), ("spmv_wide", wide), ("spmv_uniform", uni), ("spmv_eqrows", eq), ("spmv_period", period),
+                     ("spmv_triple", tri)):
             ctx.set(k, v)
         A = sa.HipCsr.new((n, n), indptr, cols, d)
         y = np.full(n, 7.0, dtype=dtype)
@@ -76,12 +82,13 @@ while time.time() < t_end:
         A.mul_vec_dot(x, y2)
         combos += 1
         if not (np.array_equal(bits(y), bits(ref)) and np.array_equal(bits(y2), bits(ref))):
-            print("MISMATCH n=%d dtype=%s knobs dict=%d wide=%d uniform=%d eqrows=%d period=%d stream=%s bad=%d" % (
-                n, np.dtype(dtype).name, knob, wide, uni, eq, period, A.stream_format(), int(np.sum(bits(y) != bits(ref)))))
+            print("MISMATCH n=%d dtype=%s knobs dict=%d wide=%d uniform=%d eqrows=%d period=%d triple=%d stream=%s bad=%d" % (
+                n, np.dtype(dtype).name, knob, wide, uni, eq, period, tri, A.stream_format(), int(np.sum(bits(y) != bits(ref)))))
             np.savez("gpurun_out/fuzz_fail.npz", indptr=indptr, cols=cols, d=d, x=x)
             sys.exit(1)
     count += 1
 for k in ("spmv_dict", "spmv_wide", "spmv_uniform", "spmv_eqrows"):
     ctx.set(k, -1)
 ctx.set("spmv_period", 0)
+ctx.set("spmv_triple", -1)
 print("fuzz ok: %d matrices, %d (matrix, knob) combinations, all y bit-identical to the reference fold" % (count, combos))

@@ -396,9 +396,15 @@ constexpr int UNI2_MAXLEN = 8;              // ... of at most this many codes; t
 // One wavefront per 128-row block: are all its rows copies of the first one (same length, same codes)?  Interior
 // rows of a constant-coefficient stencil are; such a block needs neither its 1 KiB of codes nor row_ptr — the
 // pattern is read once per block from the first row (spmv_pair2_kernel, uniform path).
+//
+// off_tab != nullptr (pair codes): the descriptor also names the CENTRE of a column triple (c - 1, c, c + 1) where the
+// pattern has one — three consecutive slots whose offsets differ by one, as the i-neighbours of a stencil are in a
+// row with sorted columns.  The kernel reads x for all three from the centre slot's 16-byte loads (nn bits 8..15 =
+// the centre's slot index, 0 = none; bits 0..7 = the row length).
 __global__ __launch_bounds__(BLOCK) void mark_uniform_kernel(int n_wide, BlkDesc *__restrict__ desc,
                                                              const int32_t *__restrict__ row_ptr,
-                                                             const uint8_t *__restrict__ code, int maxlen) {
+                                                             const uint8_t *__restrict__ code, int maxlen,
+                                                             const int32_t *__restrict__ off_tab) {
     const int lane = threadIdx.x & (WAVE - 1);
     for (int b = blockIdx.x * NWAVE + (threadIdx.x >> 6); b < n_wide; b += gridDim.x * NWAVE) {
         const BlkDesc d = desc[b];
@@ -413,13 +419,95 @@ __global__ __launch_bounds__(BLOCK) void mark_uniform_kernel(int n_wide, BlkDesc
             }
         }
         const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
-        if (all_ok && lane == 0) desc[b] = BlkDesc{d.ra, (int32_t)((uint32_t)d.rb | UNI2), d.pa, L0};
+        if (all_ok && lane == 0) {
+            int centre = 0;
+            if (off_tab != nullptr)
+                for (int j = 1; j + 1 < L0 && centre == 0; ++j) {
+                    const int o = off_tab[code[d.pa + j]];
+                    if (off_tab[code[d.pa + j - 1]] == o - 1 && off_tab[code[d.pa + j + 1]] == o + 1) centre = j;
+                }
+            desc[b] = BlkDesc{d.ra, (int32_t)((uint32_t)d.rb | UNI2), d.pa, L0 | (centre << 8)};
+        }
     }
 }
+
+// FULL uniform block of the two-rows-per-lane kernels (every lane has both rows — the interior of a stencil): no row
+// masks, and no clamp either: the second row's column r0 + 1 + off is valid, so the 16-byte load at r0 + off stays
+// inside x.  Offset and value of a slot are wave-uniform: made scalars, the gather is SGPR base + lane offset and the
+// products take the value from SGPRs — 4 vector ALU instructions per slot instead of ~25 (the kernel ran at 43 % VALU
+// utilisation, profiles/r02_tuning.md §9).
+//
+// UL, SC > 0 (compile time): the pattern has UL slots and a column triple (c - 1, c, c + 1) in slots SC - 1, SC, SC + 1
+// (mark_uniform_kernel).  The outer two are not loaded: lane l's x[r0 - 1 + o] is lane l - 1's second half of the
+// centre pair, x[r0 + 2 + o] lane l + 1's first half (wavefront shifts); the two ends of the block come from one
+// extra load that touches two lines.  UL - 2 loads + 1 instead of UL, all issued in straight-line code.
+// UL == 0: run-time length `ulen`, every slot loaded.  after_loads() runs between the last load and the first product.
+__device__ __forceinline__ double wave_shift_up(double prev_for_lane0, double v) {       // lane l <- lane l - 1
+    const long long o = __double_as_longlong(prev_for_lane0), q = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)q, 0x138, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(q >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_shift_down(double next_for_last_lane, double v) { // lane l <- lane l + 1
+    const long long o = __double_as_longlong(next_for_last_lane), q = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)q, 0x130, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(q >> 32), 0x130, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+template <int UL, int SC, class AfterLoads>
+__device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair, uint64_t pat, int ulen, const char *xbytes,
+                                                   uint32_t r8, uint32_t ra8, int lane, AfterLoads &&after_loads,
+                                                   double &acc0, double &acc1) {
+    using T = double;
+    T pl[8], ph[8], av[8];
+    T edge = 0.0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; av[t] = 0.0; }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (UL == 0 ? t >= ulen : t >= UL) break;
+        const PairEnt<T> e = s_pair[(int)((pat >> (8 * t)) & 255u)];
+        const int off8 = __builtin_amdgcn_readfirstlane(e.off8);
+        const uint32_t vlo = __builtin_amdgcn_readfirstlane((int)(uint32_t)__double_as_longlong(e.val));
+        const uint32_t vhi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(__double_as_longlong(e.val) >> 32));
+        av[t] = __longlong_as_double((long long)(((uint64_t)vhi << 32) | vlo));
+        if (SC > 0 && (t == SC - 1 || t == SC + 1)) continue;
+        const D2 px = *reinterpret_cast<const D2 *>(xbytes + (int64_t)off8 + r8);
+        pl[t] = px.lo; ph[t] = px.hi;
+        if (SC > 0 && t == SC)      // x[ra - 1 + o] for the first lane, x[ra + 128 + o] for the last: two lines
+            edge = *reinterpret_cast<const T *>(xbytes + (int64_t)off8 + ra8 + (lane < WAVE / 2 ? -8 : 8 * 2 * WAVE));
+    }
+    after_loads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (SC > 0) {
+        constexpr int C = SC > 0 ? SC : 1;
+        const T left = wave_shift_up(edge, ph[C]), right = wave_shift_down(edge, pl[C]);
+        pl[C - 1] = left; ph[C - 1] = pl[C];
+        pl[C + 1] = ph[C]; ph[C + 1] = right;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (UL == 0 ? t >= ulen : t >= UL) break;
+        acc0 = acc0 + pl[t] * av[t];
+        acc1 = acc1 + ph[t] * av[t];
+    }
+}
+template <class AfterLoads>
+__device__ __forceinline__ void full_uniform_dispatch(const PairEnt<double> *s_pair, uint64_t pat, int ulen, int sc, const char *xbytes,
+                                                      uint32_t r8, uint32_t ra8, int lane, AfterLoads &&after_loads,
+                                                      double &acc0, double &acc1) {
+    // (scalar branches) the stencils: 7-point 3-D, 5-point 2-D, 3-point 1-D with sorted columns; anything else generic
+    if (ulen == 7 && sc == 3) full_uniform_block<7, 3>(s_pair, pat, ulen, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
+    else if (ulen == 5 && sc == 2) full_uniform_block<5, 2>(s_pair, pat, ulen, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
+    else if (ulen == 3 && sc == 1) full_uniform_block<3, 1>(s_pair, pat, ulen, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
+    else full_uniform_block<0, 0>(s_pair, pat, ulen, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
+}
+
 
 struct Blk2Loads {
     int ra, rb, pa, nn;      // descriptor of the 128-row block
     bool uni; int ulen;      // uniform block (every row = the first row's ulen codes)
+    int tri;                 // ... and the slot of its column triple's centre (0: none)
     int a, b;                // row_ptr[i0], row_ptr[i0 + 1], i0 = min(ra + 2 lane, rb - 1)
     double u0, u1;           // dot operands of the lane's two rows
     u4v wc;                  // 16 code bytes
@@ -483,8 +571,9 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
     auto issue = [&](const BlkDesc &d, Blk2Loads &L) {
         L.uni = ((uint32_t)d.rb & UNI2) != 0;                                   // scalar: all rows share one code sequence of d.nn codes
         L.ra = d.ra; L.rb = (int)((uint32_t)d.rb & ~UNI2); L.pa = d.pa;
-        L.nn = L.uni ? d.nn * (L.rb - L.ra) : d.nn;
-        L.ulen = L.uni ? d.nn : 0;
+        L.ulen = L.uni ? (d.nn & 0xff) : 0;
+        L.tri = L.uni ? (d.nn >> 8) : 0;
+        L.nn = L.uni ? L.ulen * (L.rb - L.ra) : d.nn;
         const int r0 = L.ra + 2 * lane;
         L.a = 0; L.b = 0;
         if (!L.uni) {                                                           // a uniform block needs no row_ptr
@@ -506,6 +595,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
     int c_ra = 0, c_rb = 0, c_shift = 0, c_s0 = 0, c_s1 = 0, c_len0 = 0, c_len1 = 0;
     bool c_uni = false;
     uint64_t c_pat = 0;      // uniform block: its (at most 8) codes, first code in the low byte
+    int c_tri = 0;           // ... and the centre slot of its column triple
     T c_u0 = 0.0, c_u1 = 0.0;
     auto stage = [&](const Blk2Loads &L) {
         const int shift = L.pa & 3;
@@ -516,7 +606,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
             const uint64_t hi = (uint64_t)__builtin_amdgcn_readfirstlane(L.wc.z);
             c_pat = shift ? (lo >> (8 * shift)) | (hi << (64 - 8 * shift)) : lo;
             const int r0 = L.ra + 2 * lane;
-            c_ra = L.ra; c_rb = L.rb; c_shift = shift;
+            c_ra = L.ra; c_rb = L.rb; c_shift = shift; c_tri = L.tri;
             c_s0 = 0; c_s1 = 0;
             c_len0 = r0 < L.rb ? L.ulen : 0;
             c_len1 = r0 + 1 < L.rb ? L.ulen : 0;
@@ -569,29 +659,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
 #pragma unroll
             for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; av[t] = 0.0; }
             if (c_rb - c_ra == 2 * WAVE) {
-                // FULL uniform block (every lane has both rows — the interior of a stencil): no row masks, and no clamp
-                // either: the second row's column r0 + 1 + off is valid, so the 16-byte load at r0 + off stays inside x.
-                // Offset and value of a slot are wave-uniform: made scalars, the gather is SGPR base + lane offset and
-                // the products take the value from SGPRs — 4 vector ALU instructions per slot instead of ~25
-                // (the kernel ran at 43 % VALU utilisation, profiles/r02_tuning.md §9).
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    if (t >= ulen) break;
-                    const PairEnt<T> e = s_pair[(int)((c_pat >> (8 * t)) & 255u)];
-                    const int off8 = __builtin_amdgcn_readfirstlane(e.off8);
-                    const uint32_t vlo = __builtin_amdgcn_readfirstlane((int)(uint32_t)__double_as_longlong(e.val));
-                    const uint32_t vhi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(__double_as_longlong(e.val) >> 32));
-                    av[t] = __longlong_as_double((long long)(((uint64_t)vhi << 32) | vlo));
-                    const D2 px = *reinterpret_cast<const D2 *>(xbytes + (int64_t)off8 + r8);
-                    pl[t] = px.lo; ph[t] = px.hi;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    if (t >= ulen) break;
-                    acc0 = acc0 + pl[t] * av[t];
-                    acc1 = acc1 + ph[t] * av[t];
-                }
+                full_uniform_dispatch(s_pair, c_pat, ulen, c_tri, xbytes, r8, (uint32_t)c_ra * 8u, lane, [] {}, acc0, acc1);
             } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -774,7 +842,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
         DICT_TRY2(hipMemcpyAsync(D->off_desc, A->blk_desc, sizeof(BlkDesc) * (size_t)A->n_rowblk, hipMemcpyDeviceToDevice, c->stream));
         const int gu = std::max(1, std::min(c->num_cu * 8, (A->n_rowblk + NWAVE - 1) / NWAVE));
         hipLaunchKernelGGL(mark_uniform_kernel, dim3(gu), dim3(BLOCK), 0, c->stream, (int)A->n_rowblk,
-                           reinterpret_cast<BlkDesc *>(D->off_desc), A->row_ptr, D->idx_code, UNI_OFF_MAXLEN);
+                           reinterpret_cast<BlkDesc *>(D->off_desc), A->row_ptr, D->idx_code, UNI_OFF_MAXLEN, (const int32_t *)nullptr);
         DICT_TRY2(hipGetLastError());
         // how many qualified: the auto policy wants to know for matrices that live in the Infinity Cache (small: a
         // few MB of descriptors at most); HBM-sized ones take the offset stream anyway
@@ -829,7 +897,8 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
                 if (c->spmv_uniform != 0 && nw > 0) {
                     const int gu = std::max(1, std::min(c->num_cu * 8, (nw + NWAVE - 1) / NWAVE));
                     hipLaunchKernelGGL(mark_uniform_kernel, dim3(gu), dim3(BLOCK), 0, c->stream, nw,
-                                       reinterpret_cast<BlkDesc *>(D->wide_desc), A->row_ptr, D->pair_code, UNI2_MAXLEN);
+                                       reinterpret_cast<BlkDesc *>(D->wide_desc), A->row_ptr, D->pair_code, UNI2_MAXLEN,
+                                       c->spmv_triple != 0 ? (const int32_t *)D->pair_off : (const int32_t *)nullptr);
                     DICT_TRY2(hipGetLastError());
                 }
                 DICT_TRY2(hipStreamSynchronize(c->stream));

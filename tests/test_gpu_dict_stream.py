@@ -22,6 +22,7 @@ def _restore_knob(sa):
     yield
     sa.default_ctx(0).set("spmv_dict", -1)
     sa.default_ctx(0).set("spmv_wide", -1)
+    sa.default_ctx(0).set("spmv_triple", -1)
 
 
 def bits(a):
@@ -427,6 +428,43 @@ def test_uniform_blocks(sa, oracle, kind):
     ctx.set("spmv_uniform", -1)
 
 
+@pytest.mark.parametrize("offs", [(-1, 0, 1), (-40, -1, 0, 1, 40), (-900, -30, -1, 0, 1, 30, 900), (-1, 0, 1, 5), (-7, -1, 0, 1),
+                                  (-3, -2, -1), (2, 3, 4, 9), (-2, 0, 1, 2), (-5, -4, -3, 0, 3, 4, 5), (0, 1, 2, 3, 4, 5, 6, 7)],
+                         ids=lambda o: "_".join(map(str, o)))
+def test_column_triples_of_uniform_blocks(sa, oracle, offs):
+    """Full uniform blocks whose pattern holds a column triple (c - 1, c, c + 1) read x for c -+ 1 from column c's loads
+    (wavefront shifts + one two-line load for the block's ends; compile-time paths for 3, 5 and 7 slots with the triple
+    in the middle, the general path for every other shape).  Same values, same fold: y and the fused dot are
+    bit-identical with the shortcut on and off, at every alignment of the interior run against the 128-row blocks."""
+    ctx = sa.default_ctx(0)
+    offs = np.array(offs)
+    for n, lead in ((6000, 0), (6151, 37)):
+        # rows [lo, hi) carry the full pattern (one value per offset); the rest only their diagonal-ish first entry
+        lo, hi = max(0, -offs.min()) + lead, n - max(0, offs.max())
+        rows = [r + offs if lo <= r < hi else np.array([r]) for r in range(n)]
+        indptr = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum([len(c) for c in rows], out=indptr[1:])
+        cols = np.concatenate(rows).astype(np.int32)
+        data = np.concatenate([(c - r) * 0.375 + 1.25 for r, c in enumerate(rows)])
+        x = rand_vec(n, np.float64, 29)
+        ref = oracle.spmv(indptr, cols, data, x)
+        dots = {}
+        for tri in (1, 0):
+            ctx.set("spmv_triple", tri)
+            A = sa.HipCsr.new((n, n), indptr, cols, data)
+            assert A.stream_format()[0] == 2
+            nb, nu = A.wide_blocks()
+            assert nu >= (hi - lo) // 128 - 1, (nb, nu)
+            y = np.full(n, -3.0)
+            A.mul_vec(x, y)
+            assert np.array_equal(bits(y), bits(ref)), (tri, n)
+            y2 = np.zeros(n)
+            dots[tri] = A.mul_vec_dot(x, y2)
+            assert np.array_equal(bits(y2), bits(ref))
+        assert dots[0] == dots[1]
+    ctx.set("spmv_triple", -1)
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("kind", ["band_random", "poisson3d_random", "ragged_mix", "len1_and_len8", "head_shift"])
 def test_offset_code_uniform_blocks(sa, oracle, dtype, kind):
@@ -533,8 +571,9 @@ def test_xcd_period_schedule_is_a_pure_reordering(sa, oracle):
     ref = oracle.spmv(indptr, cols, data, x)
     out = {}
     try:
-        for period in (0, 1):
+        for period, triple in ((0, 1), (1, 1), (0, 0), (1, 0)):
             ctx.set("spmv_period", period)
+            ctx.set("spmv_triple", triple)   # columns c -+ 1 of a uniform block read from column c's loads: same values
             A = sa.HipCsr.new((n, n), indptr, cols, data)
             assert A.stream_format()[0] == 2
             y = np.zeros(n); d = A.mul_vec_dot(x, y)
@@ -545,7 +584,9 @@ def test_xcd_period_schedule_is_a_pure_reordering(sa, oracle):
             sol = np.zeros(n)
             its, res = s.solve(rhs, sol, 2000, 1e-10)
             assert np.max(np.abs(sol - 1.0)) < 1e-7
-            out[period] = its
-        assert abs(out[0] - out[1]) <= max(3, out[0] // 10)
+            out[period, triple] = (its, d)
+        assert abs(out[0, 1][0] - out[1, 1][0]) <= max(3, out[0, 1][0] // 10)
+        assert out[0, 1] == out[0, 0] and out[1, 1] == out[1, 0]        # the triple shortcut changes timing only
     finally:
         ctx.set("spmv_period", 0)
+        ctx.set("spmv_triple", -1)
