@@ -17,8 +17,9 @@ def main(rank, world, port, kind, outdir, exchange="halo"):
     from sprsolve_amd import dist as sdist, gen, partition
     dev = torch.device("cuda", 0)
     ctx = sa.default_ctx(0)
-    if kind == "poisson3d":
-        nx, ny, nz = 24, 20, 18
+    if kind.startswith("poisson3d"):
+        # "_long": x-lines of 272 rows hold full uniform 128-row blocks (scalar pattern, column triples) on every rank
+        nx, ny, nz = (272, 6, 8) if kind == "poisson3d_long" else (24, 20, 18)
         plane = nx * ny
         starts = partition.slab_starts(nz, plane, world)
         ip, ix, d, rhs = gen.poisson3d(nx, ny, nz, int(starts[rank] // plane), int(starts[rank + 1] // plane))

@@ -40,11 +40,12 @@ def _run(world, kind, mock_lib, exchange="halo"):
 @pytest.mark.parametrize("world,kind,exchange", [(2, "poisson3d", "halo"), (3, "poisson3d", "halo"), (2, "banded", "halo"),
                                                  (3, "poisson3d", "allgather"), (2, "banded", "allgather"),
                                                  (3, "poisson3d", "halo_c"), (2, "banded", "halo_c"), (3, "banded", "halo_c"),
-                                                 (2, "poisson3d", "allgather_c")])
+                                                 (2, "poisson3d", "allgather_c"), (2, "poisson3d_long", "halo"),
+                                                 (3, "poisson3d_long", "halo_c")])
 def test_real_ranks_match_single_process(oracle, mock_lib, world, kind, exchange):
     from sprsolve_amd import gen
-    if kind == "poisson3d":
-        ip, ix, d, rhs = gen.poisson3d(24, 20, 18)
+    if kind.startswith("poisson3d"):
+        ip, ix, d, rhs = gen.poisson3d(*((272, 6, 8) if kind == "poisson3d_long" else (24, 20, 18)))
         ref = oracle.bicgstab(ip, ix, d, rhs, np.zeros(rhs.size), 3000, 1e-10, trace_cap=6)
         refpc = oracle.bicgstab(ip, ix, d, rhs, np.zeros(rhs.size), 3000, 1e-10, precond_diag=np.full(rhs.size, 6.0))
     else:
