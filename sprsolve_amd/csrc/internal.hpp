@@ -146,6 +146,7 @@ struct sprs_dict {
     void *wide_desc = nullptr;     // device: descriptors of the 128-row blocks of the two-rows-per-lane kernel (f64 pair codes)
     int n_wide = 0;
     int32_t *wide_order = nullptr; // device: XCD-period schedule of the 128-row blocks (null = natural order)
+    int32_t *off_order = nullptr;  // device: the same schedule for the 64-row blocks of the offset-code stream
     int64_t period = 0;            // the far band it folds over (rows)
     void *off_desc = nullptr;      // device: copy of blk_desc for the offset-code stream with the uniform blocks flagged (bit 30, nn = row length)
     int n_off_uniform = 0;

@@ -741,6 +741,34 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
     }
 }
 
+// XCD-period schedule (knob "spmv_period") of a stream's row blocks.  With the far band P = max |col - row| (a 3-D
+// stencil's plane), rows are cut into chunks of P/8 and chunk c goes to XCD c mod 8: rows r and r +- P are multiplied on
+// the SAME XCD one chunk apart, so x[r + P] is fetched over the fabric once — when row r needs it — and hits that
+// XCD's L2 as the centre of row r + P (and, where the stream between them is short enough, as the lower neighbour of
+// row r + 2P).  Positions of the walk belong to XCD (pos / NWAVE) mod 8 (workgroups are dealt round-robin over the
+// XCDs — a locality hint only, never needed for correctness).  first_row(j) = first row of block j.
+template <class FirstRow>
+static std::vector<int32_t> xcd_period_order(int nblk, int64_t G, FirstRow first_row) {
+    std::vector<std::vector<int32_t>> q(8);
+    for (int j = 0; j < nblk; ++j) q[(size_t)((first_row(j) / G) % 8)].push_back(j);
+    std::vector<int32_t> ord((size_t)nblk);
+    size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0}, filled = 0;
+    while (filled < (size_t)nblk) {
+        for (int x = 0; x < 8 && filled < (size_t)nblk; ++x) {
+            for (int k = 0; k < NWAVE && filled < (size_t)nblk; ++k) {
+                int src = x;
+                if (pos[src] >= q[src].size()) {          // this XCD's queue ran dry: take from the longest one
+                    size_t best = 0;
+                    for (int y2 = 0; y2 < 8; ++y2)
+                        if (q[y2].size() - pos[y2] > best) { best = q[y2].size() - pos[y2]; src = y2; }
+                }
+                ord[filled++] = q[src][pos[src]++];
+            }
+        }
+    }
+    return ord;
+}
+
 struct BlkDescHost2 { int32_t ra, rb, pa, nn; };
 template <class T> struct has_val_dict { static constexpr bool value = false; };
 template <> struct has_val_dict<double> { static constexpr bool value = true; };
@@ -834,6 +862,20 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
     DICT_TRY2(hipMemcpyAsync(h_counts, counts, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
     DICT_TRY2(hipStreamSynchronize(c->stream));
     if (h_counts[3] != 0) { cleanup2(); free_dict(A); return SPRS_OK; }   // cannot happen (every key was inserted)
+    {
+        // the same schedule for the 64-row blocks of the offset-code stream (variable coefficients: 8-9 B per entry, at
+        // the fabric's ceiling with the x re-reads of the natural sweep — profiles/r02_tuning.md §4)
+        int64_t P = 0;
+        for (const auto &o : offs) P = std::max<int64_t>(P, std::llabs((long long)o.first));
+        const int64_t G = P / 8;
+        if (c->spmv_period > 0 && G >= 16 * 128 && P * 4 <= A->nrows && A->n_rowblk >= 8 * NWAVE * 8) {
+            const std::vector<int32_t> ord = xcd_period_order(A->n_rowblk, G, [&](int j) { return (int64_t)blk[(size_t)j]; });
+            DICT_TRY2(hipMalloc((void **)&D->off_order, sizeof(int32_t) * ord.size()));
+            DICT_TRY2(hipMemcpyAsync(D->off_order, ord.data(), sizeof(int32_t) * ord.size(), hipMemcpyHostToDevice, c->stream));
+            DICT_TRY2(hipStreamSynchronize(c->stream));
+            D->period = P;
+        }
+    }
     if (c->spmv_uniform != 0 && A->n_rowblk > 0) {
         // Uniform 64-row blocks of the offset-code stream: all rows repeat the first row's (<= 8) offset codes — the
         // interior of any stencil or band, whatever its VALUES.  Such a block needs neither row_ptr nor its code bytes
@@ -903,34 +945,13 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
                 }
                 DICT_TRY2(hipStreamSynchronize(c->stream));
                 D->n_wide = nw;
-                // XCD-period schedule (knob "spmv_period").  The pair-code kernel streams ~26 B per row, so the x lines a
-                // row block gathers stay in its XCD's 4 MiB L2 for several planes' worth of that XCD's rows.  With the far
-                // band P = max |col - row| (a 3-D stencil's plane), rows are cut into chunks of P/8 and chunk c goes to XCD
-                // c mod 8: rows r and r +- P are multiplied on the SAME XCD one chunk apart, so x[r + P] is fetched over
-                // the fabric once — when row r needs it — and hits L2 as the centre of row r + P and the lower
-                // neighbour of row r + 2P.  Positions of the walk belong to XCD (pos / NWAVE) mod 8 (workgroups are
-                // dealt round-robin over the XCDs — a locality hint only, never needed for correctness).
+                // XCD-period schedule: the pair-code kernel streams ~26 B per row, so the x lines a row block gathers
+                // stay in its XCD's 4 MiB L2 for several planes' worth of that XCD's rows (xcd_period_order above)
                 int64_t P = 0;
                 for (const auto &o : offs) P = std::max<int64_t>(P, std::llabs((long long)o.first));
                 const int64_t G = P / 8;
                 if (c->spmv_period > 0 && G >= 16 * 128 && P * 4 <= A->nrows && nw >= 8 * NWAVE * 8) {
-                    std::vector<std::vector<int32_t>> q(8);
-                    for (int j = 0; j < nw; ++j) q[(size_t)((wd[(size_t)j].ra / G) % 8)].push_back(j);
-                    std::vector<int32_t> ord((size_t)nw);
-                    size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0}, filled = 0;
-                    while (filled < (size_t)nw) {
-                        for (int x = 0; x < 8 && filled < (size_t)nw; ++x) {
-                            for (int k = 0; k < NWAVE && filled < (size_t)nw; ++k) {
-                                int src = x;
-                                if (pos[src] >= q[src].size()) {          // this XCD's queue ran dry: take from the longest one
-                                    size_t best = 0;
-                                    for (int y2 = 0; y2 < 8; ++y2)
-                                        if (q[y2].size() - pos[y2] > best) { best = q[y2].size() - pos[y2]; src = y2; }
-                                }
-                                ord[filled++] = q[src][pos[src]++];
-                            }
-                        }
-                    }
+                    const std::vector<int32_t> ord = xcd_period_order(nw, G, [&](int j) { return (int64_t)wd[(size_t)j].ra; });
                     DICT_TRY2(hipMalloc((void **)&D->wide_order, sizeof(int32_t) * (size_t)nw));
                     DICT_TRY2(hipMemcpyAsync(D->wide_order, ord.data(), sizeof(int32_t) * (size_t)nw, hipMemcpyHostToDevice, c->stream));
                     DICT_TRY2(hipStreamSynchronize(c->stream));
@@ -950,7 +971,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
 void free_dict(sprs_csr *A) {
     if (!A || !A->dict) return;
     sprs_dict *D = A->dict;
-    for (void *q : {(void *)D->idx_code, (void *)D->pair_code, (void *)D->off_tab, (void *)D->pair_off, D->pair_val, D->wide_desc, D->off_desc, (void *)D->wide_order})
+    for (void *q : {(void *)D->idx_code, (void *)D->pair_code, (void *)D->off_tab, (void *)D->pair_off, D->pair_val, D->wide_desc, D->off_desc, (void *)D->wide_order, (void *)D->off_order})
         if (q) (void)hipFree(q);
     delete D;
     A->dict = nullptr;
@@ -1015,6 +1036,7 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
     }
     const uint8_t *code = pair ? D->pair_code : D->idx_code;
     const int32_t *otab = pair ? D->pair_off : D->off_tab;
+    if (!pair && order == nullptr && count == A->n_rowblk && c->spmv_period > 0 && D->off_order) order = D->off_order;
     // the offset-code stream runs on its own descriptors (uniform blocks flagged); same block numbering as blk_desc
     const BlkDesc *dsc = reinterpret_cast<const BlkDesc *>((!pair && D->off_desc && c->spmv_uniform != 0) ? D->off_desc : A->blk_desc);
 #define SPRS_DSPMV2(DM, CJ, PR)                                                                                         \
