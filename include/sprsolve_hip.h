@@ -65,10 +65,25 @@ int sprs_ctx_sync(sprs_ctx *ctx);
 const char *sprs_last_error(const sprs_ctx *ctx);  /* text of the last SPRS_ERR_* on this ctx */
 const char *sprs_status_str(int status);
 int sprs_version(void);
-/* tuning knobs (defaults chosen for MI355X): key = "grid" (blocks of the streaming kernels),
- * "xcd_chunk" (1: contiguous row-block chunk per XCD), "poll" (iterations between host polls),
- * "spmv_dict" (-1 auto / 0 plain CSR / 1 offset codes / 2 (offset, value) pair codes: dictionary-compressed
- * SpMV stream, see sprs_csr_stream_format), "gs_graph" (1: Gauss-Seidel replays a sweep's level launches from a hipGraph; default 0) */
+/* Tuning knobs.  Defaults are the measured best on MI355X (profiles/r0*_tuning.md); none changes a result except through
+ * the summation order of the fused reductions' partials (y of every SpMV is bit-identical under all of them).
+ * -1 = automatic where noted.  Knobs marked (creation) are read when a matrix handle is created.
+ *   "grid"          workgroups of the streaming (BLAS-1 / fused recurrence) kernels, 8..4096, multiple of 8
+ *   "spmv_grid"     workgroups of the SpMV kernels (-1: 4 per CU)
+ *   "poll"          iterations between two host looks at the device-side status word (>= 1)
+ *   "xcd_chunk"     1: one contiguous chunk of row blocks per XCD (-1: automatic — cache-resident matrices only)
+ *   "spmv_dict"     SpMV stream: -1 auto / 0 plain CSR / 1 offset codes / 2 (offset, value) pair codes
+ *                   (sprs_csr_stream_format reports what a handle got)                                   (creation)
+ *   "spmv_wide"     f64 pair codes: two rows per lane, 128-row blocks (-1 / 1 on, 0 off)
+ *   "spmv_uniform"  blocks whose rows repeat one code sequence are multiplied from that pattern          (creation)
+ *   "spmv_triple"   ... and read columns c - 1, c + 1 of a column triple from column c's loads           (creation)
+ *   "spmv_eqrows"   plain CSR: blocks of equal-length rows do not read row_ptr                           (creation)
+ *   "spmv_period"   1: XCD-period walk of the compressed streams' blocks for matrices with a far band;
+ *                   default 0 (measured: fabric traffic -58 %, time unchanged)                           (creation)
+ *   "spmv_nt"       1: non-temporal loads of the plain stream; "spmv_strip": experimental walks of the plain stream
+ *   "halo_overlap"  distributed SpMV: 1 (default) multiplies the interior rows while the halo travels
+ *   "gs_graph"      1: Gauss-Seidel replays a sweep's level launches from a hipGraph (default 0)
+ * sprs_ctx_get also answers "num_cu" and "device".  Unknown key: SPRS_INVALID_ARGUMENT / -1. */
 int sprs_ctx_set(sprs_ctx *ctx, const char *key, int64_t value);
 int64_t sprs_ctx_get(const sprs_ctx *ctx, const char *key);
 
