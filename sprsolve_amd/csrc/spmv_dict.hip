@@ -439,8 +439,8 @@ __global__ __launch_bounds__(BLOCK) void mark_uniform_kernel(int n_wide, BlkDesc
 //
 // UL, SC > 0 (compile time): the pattern has UL slots and a column triple (c - 1, c, c + 1) in slots SC - 1, SC, SC + 1
 // (mark_uniform_kernel).  The outer two are not loaded: lane l's x[r0 - 1 + o] is lane l - 1's second half of the
-// centre pair, x[r0 + 2 + o] lane l + 1's first half (wavefront shifts); the two ends of the block come from one
-// extra load that touches two lines.  UL - 2 loads + 1 instead of UL, all issued in straight-line code.
+// centre pair, x[r0 + 2 + o] lane l + 1's first half (wavefront shifts); the two ends of the block come from two
+// scalar loads.  UL - 2 vector loads instead of UL, all issued in straight-line code.
 // UL == 0: run-time length `ulen`, every slot loaded.  after_loads() runs between the last load and the first product.
 __device__ __forceinline__ double wave_shift_up(double prev_for_lane0, double v) {       // lane l <- lane l - 1
     const long long o = __double_as_longlong(prev_for_lane0), q = __double_as_longlong(v);
@@ -460,7 +460,7 @@ __device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair
                                                    double &acc0, double &acc1) {
     using T = double;
     T pl[8], ph[8], av[8];
-    T edge = 0.0;
+    int off8c = 0;
 #pragma unroll
     for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; av[t] = 0.0; }
 #pragma unroll
@@ -474,14 +474,21 @@ __device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair
         if (SC > 0 && (t == SC - 1 || t == SC + 1)) continue;
         const D2 px = *reinterpret_cast<const D2 *>(xbytes + (int64_t)off8 + r8);
         pl[t] = px.lo; ph[t] = px.hi;
-        if (SC > 0 && t == SC)      // x[ra - 1 + o] for the first lane, x[ra + 128 + o] for the last: two lines
-            edge = *reinterpret_cast<const T *>(xbytes + (int64_t)off8 + ra8 + (lane < WAVE / 2 ? -8 : 8 * 2 * WAVE));
+        if (SC > 0 && t == SC) off8c = off8;
+    }
+    // the two ends of the block, x[ra - 1 + o] and x[ra + 128 + o]: wave-uniform addresses, read through the SCALAR
+    // cache after the last LDS read of the block (scalar loads return out of order and share the LDS counter) — a
+    // 64-lane load of them would cost the vector-memory pipe as much as a gather
+    T e_lo = 0.0, e_hi = 0.0;
+    if (SC > 0) {
+        const T *xe = reinterpret_cast<const T *>(xbytes + (int64_t)off8c + ra8);
+        e_lo = xe[-1]; e_hi = xe[2 * WAVE];
     }
     after_loads();
     __builtin_amdgcn_sched_barrier(0);
     if (SC > 0) {
         constexpr int C = SC > 0 ? SC : 1;
-        const T left = wave_shift_up(edge, ph[C]), right = wave_shift_down(edge, pl[C]);
+        const T left = wave_shift_up(e_lo, ph[C]), right = wave_shift_down(e_hi, pl[C]);
         pl[C - 1] = left; ph[C - 1] = pl[C];
         pl[C + 1] = ph[C]; ph[C + 1] = right;
     }
@@ -554,15 +561,13 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
     }
     if (b >= bend) b = bend;
 
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    typedef const v4i __attribute__((address_space(1))) *gv4i_p;
     typedef const int32_t __attribute__((address_space(1))) *gi32_p;
-    uintptr_t desc_a = reinterpret_cast<uintptr_t>(desc), order_a = reinterpret_cast<uintptr_t>(order);
-    asm volatile("" : "+v"(desc_a));                // vector (in-order) descriptor loads, as in spmv_dict_kernel
-    asm volatile("" : "+v"(order_a));
-    const gv4i_p desc_v = reinterpret_cast<gv4i_p>(desc_a);
+    uintptr_t order_a = reinterpret_cast<uintptr_t>(order);
+    asm volatile("" : "+v"(order_a));               // vector (in-order, 4 bytes per lane) loads of the walk order
     const gi32_p order_v = reinterpret_cast<gi32_p>(order_a);
-    auto load_desc = [&](int bi) -> BlkDesc { const v4i q = desc_v[bi]; return BlkDesc{q.x, q.y, q.z, q.w}; };
+    // descriptors: wave-uniform index, read through the scalar cache (`desc` must stay un-captured for that: the
+    // compiler only uses scalar loads on memory it can prove nothing in the kernel writes)
+    auto load_desc = [&](int bi) -> BlkDesc { return desc[bi]; };
     auto block_index = [&](int bi) -> int { return order ? order_v[bi] : bi; };
     auto uniform = [&](const BlkDesc &d) -> BlkDesc {
         return BlkDesc{__builtin_amdgcn_readfirstlane(d.ra), __builtin_amdgcn_readfirstlane(d.rb),
@@ -642,9 +647,14 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
         Blk2Loads nxt;
         BlkDesc dn2{0, 1, 0, 0};
         int o3 = 0;
-        if (b + 2 * bstep < bend) dn2 = load_desc(o2);
         if (b + 3 * bstep < bend) o3 = block_index(b + 3 * bstep);
         if (more) issue(dn, nxt);
+        // The descriptor of the block after next comes through the SCALAR cache (its index is wave-uniform): a 64-lane
+        // 16-byte load of it costs the vector-memory pipe as much as a gather.  Scalar loads return out of order and
+        // share their counter with the LDS, so it is requested after the block's gathers (and the LDS reads that
+        // address them) are out, and looked at when the block is done.
+        const bool want_dn2 = b + 2 * bstep < bend;
+        auto after_gathers = [&]() { if (want_dn2) dn2 = load_desc(o2); };
         wave_lds_fence();
         const int r0 = c_ra + 2 * lane;
         const uint32_t r8 = (uint32_t)r0 * 8u;
@@ -659,7 +669,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
 #pragma unroll
             for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; av[t] = 0.0; }
             if (c_rb - c_ra == 2 * WAVE) {
-                full_uniform_dispatch(s_pair, c_pat, ulen, c_tri, xbytes, r8, (uint32_t)c_ra * 8u, lane, [] {}, acc0, acc1);
+                full_uniform_dispatch(s_pair, c_pat, ulen, c_tri, xbytes, r8, (uint32_t)c_ra * 8u, lane, after_gathers, acc0, acc1);
             } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -672,6 +682,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
                 const D2 px = *reinterpret_cast<const D2 *>(xbytes + vp);
                 pl[t] = px.lo; ph[t] = px.hi;
             }
+            after_gathers();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -680,7 +691,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
                 if (len1 > 0) acc1 = acc1 + ph[t] * av[t];
             }
             }
-        } else
+        } else {
+        if (__builtin_amdgcn_ballot_w64(0 < lenm) == 0) after_gathers();        // (a block of empty rows)
         for (int j0 = 0; __builtin_amdgcn_ballot_w64(j0 < lenm) != 0; j0 += 8) {
             const uint8_t *cp0 = cb + c_shift + min(c_s0 + j0, CAP2);
             const uint8_t *cp1 = cb + c_shift + min(c_s1 + j0, CAP2);
@@ -710,6 +722,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
                 if (__builtin_amdgcn_ballot_w64(need1) != 0)                    // scalar branch: interior stencil blocks skip it
                     xs[t] = *reinterpret_cast<const T *>(xbytes + (need1 ? r8 + 8u + (uint32_t)off1 : 0u));
             }
+            if (j0 == 0) after_gathers();
             __builtin_amdgcn_sched_barrier(0);                                  // every gather out before the first product
             asm volatile("" ::: "memory");      // the values are looked up again below rather than held in 32 registers across the wait
 #pragma unroll
@@ -717,6 +730,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
                 if (j0 + t < len0) acc0 = acc0 + (((hi_bits >> t) & 1u) ? ph[t] : pl[t]) * s_pair[cp0[t]].val;
                 if (j0 + t < len1) acc1 = acc1 + (((same_bits >> t) & 1u) ? ph[t] : xs[t]) * s_pair[cp1[t]].val;
             }
+        }
         }
         if (r0 + 1 < c_rb) {
             *reinterpret_cast<D2 *>(reinterpret_cast<char *>(y) + r8) = D2{acc0, acc1};
