@@ -850,3 +850,16 @@ def test_host_owned_recurrence_through_the_abi(tmp_path):
         out = subprocess.run([exe, size], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "bit-identical: yes" in out.stdout, out.stdout
+
+
+def test_randomised_solver_parity_short():
+    """scripts/fuzz_solvers.py for a few seconds (the long runs are recorded in profiles/r02_tuning.md): random small
+    systems, all four scalar types, three solvers, plain / Jacobi, fused / literal — outcome, iteration count and
+    solution against the oracle's restatement of the reference recurrences."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_solvers.py"), "6", "77"], cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert "0 hard mismatches" in p.stdout
