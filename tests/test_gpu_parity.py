@@ -856,6 +856,7 @@ def test_randomised_solver_parity_short():
     """scripts/fuzz_solvers.py for a few seconds (the long runs are recorded in profiles/r02_tuning.md): random small
     systems, all four scalar types, three solvers, plain / Jacobi, fused / literal — outcome, iteration count and
     solution against the oracle's restatement of the reference recurrences."""
+    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
