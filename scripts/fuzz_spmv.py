@@ -31,6 +31,8 @@ def make(n):
         offs = np.unique(np.concatenate([offs[:int(rng.integers(0, 4))], o0 + np.arange(int(rng.integers(3, 6)))]))[:8]
     if kind == 3 and n > 600:       # far band (period schedule, plane-like)
         offs = np.unique(np.concatenate([offs, [-(n // 5), n // 5]]))
+    line = int(rng.integers(130, 700)) if kind == 6 else 0
+    rng_seam = bool(rng.integers(0, 2))
     rows = []
     ragged_lo, ragged_hi = (int(rng.integers(0, n)), int(rng.integers(0, n)))
     ragged_lo, ragged_hi = min(ragged_lo, ragged_hi), max(ragged_lo, ragged_hi)
@@ -41,6 +43,11 @@ def make(n):
             c = c[rng.uniform(size=c.size) < 0.6]
         if kind == 2 and rng.uniform() < 0.02:
             c = c[:0]
+        if kind == 6 and line > 0:        # truncated lines: the last row of a line lacks its largest offset, the first its smallest
+            if r % line == line - 1 and c.size > 1:
+                c = c[:-1] if rng_seam else c[c != r + 1]
+            elif r % line == 0 and c.size > 1:
+                c = c[1:] if rng_seam else c[c != r - 1]
         rows.append(c)
     indptr = np.zeros(n + 1, dtype=np.int32)
     np.cumsum([len(c) for c in rows], out=indptr[1:])
@@ -69,11 +76,11 @@ while time.time() < t_end:
     if np.dtype(dtype).kind == "c":
         x = x + 1j * rng.uniform(-1, 1, n).astype(x.real.dtype)
     ref = oracle.spmv(indptr, cols, d, x)
-    for knob, wide, uni, eq, period, tri in itertools.product((0, 1, 2), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1)):
-        if (knob != 2 and (wide or period)) or (knob == 0 and uni) or (knob != 0 and eq == 0) or (not tri and not wide):
+    for knob, wide, uni, eq, period, tri, seam in itertools.product((0, 1, 2), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1)):
+        if (knob != 2 and (wide or period)) or (knob == 0 and uni) or (knob != 0 and eq == 0) or (not tri and not wide) or (not seam and not (wide and uni)):
             continue
         for k, v in (("spmv_dict", knob), ("spmv_wide", wide), ("spmv_uniform", uni), ("spmv_eqrows", eq), ("spmv_period", period),
-                     ("spmv_triple", tri)):
+                     ("spmv_triple", tri), ("spmv_seam", seam)):
             ctx.set(k, v)
         A = sa.HipCsr.new((n, n), indptr, cols, d)
         y = np.full(n, 7.0, dtype=dtype)
@@ -82,8 +89,8 @@ while time.time() < t_end:
         A.mul_vec_dot(x, y2)
         combos += 1
         if not (np.array_equal(bits(y), bits(ref)) and np.array_equal(bits(y2), bits(ref))):
-            print("MISMATCH n=%d dtype=%s knobs dict=%d wide=%d uniform=%d eqrows=%d period=%d triple=%d stream=%s bad=%d" % (
-                n, np.dtype(dtype).name, knob, wide, uni, eq, period, tri, A.stream_format(), int(np.sum(bits(y) != bits(ref)))))
+            print("MISMATCH n=%d dtype=%s knobs dict=%d wide=%d uniform=%d eqrows=%d period=%d triple=%d seam=%d stream=%s bad=%d" % (
+                n, np.dtype(dtype).name, knob, wide, uni, eq, period, tri, seam, A.stream_format(), int(np.sum(bits(y) != bits(ref)))))
             np.savez("gpurun_out/fuzz_fail.npz", indptr=indptr, cols=cols, d=d, x=x)
             sys.exit(1)
     count += 1
@@ -91,4 +98,5 @@ for k in ("spmv_dict", "spmv_wide", "spmv_uniform", "spmv_eqrows"):
     ctx.set(k, -1)
 ctx.set("spmv_period", 0)
 ctx.set("spmv_triple", -1)
+ctx.set("spmv_seam", -1)
 print("fuzz ok: %d matrices, %d (matrix, knob) combinations, all y bit-identical to the reference fold" % (count, combos))

@@ -110,6 +110,7 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     else if (k == "spmv_uniform") c->spmv_uniform = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_period") c->spmv_period = value > 0 ? 1 : 0;
     else if (k == "spmv_triple") c->spmv_triple = value < 0 ? -1 : (value ? 1 : 0);
+    else if (k == "spmv_seam") c->spmv_seam = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_eqrows") c->spmv_eqrows = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "halo_overlap") c->halo_overlap = value ? 1 : 0;
     else if (k == "gs_graph") c->gs_graph = value ? 1 : 0;
@@ -130,6 +131,7 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     if (k == "spmv_uniform") return c->spmv_uniform;
     if (k == "spmv_period") return c->spmv_period;
     if (k == "spmv_triple") return c->spmv_triple;
+    if (k == "spmv_seam") return c->spmv_seam;
     if (k == "spmv_eqrows") return c->spmv_eqrows;
     if (k == "halo_overlap") return c->halo_overlap;
     if (k == "gs_graph") return c->gs_graph;

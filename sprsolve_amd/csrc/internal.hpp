@@ -48,6 +48,7 @@ struct sprs_ctx {
     int spmv_eqrows = -1; // plain-CSR stream: blocks of equal-length rows take their extents from the descriptor (no row_ptr read); read at creation
     int spmv_period = 0;   // f64 pair codes: XCD-period schedule for matrices with a far band (3-D stencils), 1 = on.  Read at creation
     int spmv_triple = -1;  // f64 pair codes, uniform blocks: columns c - 1 and c + 1 read from column c's loads; 0 = off.  Read at creation
+    int spmv_seam = -1;    // f64 pair codes: blocks that are uniform but for one or two adjacent rows lacking one slot run the uniform path; 0 = off.  Read at creation
                            // and at launch.  Off by default: it cuts the SpMV's fabric reads by 58 % (x crosses the fabric once) and the
                            // kernel's time not at all (profiles/r02_tuning.md §7)
     int spmv_uniform = -1; // ... and blocks whose rows all repeat one code sequence read neither codes nor row_ptr; read at creation

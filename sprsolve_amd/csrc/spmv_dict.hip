@@ -397,14 +397,15 @@ constexpr int UNI2_MAXLEN = 8;              // ... of at most this many codes; t
 // rows of a constant-coefficient stencil are; such a block needs neither its 1 KiB of codes nor row_ptr — the
 // pattern is read once per block from the first row (spmv_pair2_kernel, uniform path).
 //
-// off_tab != nullptr (pair codes): the descriptor also names the CENTRE of a column triple (c - 1, c, c + 1) where the
+// off_tab != nullptr (pair codes) and `triple`: the descriptor also names the CENTRE of a column triple (c - 1, c, c + 1) where the
 // pattern has one — three consecutive slots whose offsets differ by one, as the i-neighbours of a stencil are in a
 // row with sorted columns.  The kernel reads x for all three from the centre slot's 16-byte loads (nn bits 8..15 =
 // the centre's slot index, 0 = none; bits 0..7 = the row length).
 __global__ __launch_bounds__(BLOCK) void mark_uniform_kernel(int n_wide, BlkDesc *__restrict__ desc,
                                                              const int32_t *__restrict__ row_ptr,
                                                              const uint8_t *__restrict__ code, int maxlen,
-                                                             const int32_t *__restrict__ off_tab) {
+                                                             const int32_t *__restrict__ off_tab, int triple, int seam,
+                                                             int ncols) {
     const int lane = threadIdx.x & (WAVE - 1);
     for (int b = blockIdx.x * NWAVE + (threadIdx.x >> 6); b < n_wide; b += gridDim.x * NWAVE) {
         const BlkDesc d = desc[b];
@@ -421,12 +422,67 @@ __global__ __launch_bounds__(BLOCK) void mark_uniform_kernel(int n_wide, BlkDesc
         const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
         if (all_ok && lane == 0) {
             int centre = 0;
-            if (off_tab != nullptr)
+            if (off_tab != nullptr && triple != 0)
                 for (int j = 1; j + 1 < L0 && centre == 0; ++j) {
                     const int o = off_tab[code[d.pa + j]];
                     if (off_tab[code[d.pa + j - 1]] == o - 1 && off_tab[code[d.pa + j + 1]] == o + 1) centre = j;
                 }
             desc[b] = BlkDesc{d.ra, (int32_t)((uint32_t)d.rb | UNI2), d.pa, L0 | (centre << 8)};
+        }
+        if (all_ok || off_tab == nullptr || seam == 0 || nr != 2 * WAVE) continue;
+        // ---- SEAM blocks (pair codes, full 128-row blocks): every row repeats one pattern except one row, or two
+        // adjacent ones, that lack exactly one of its slots — the x = nx - 1 | x = 0 seam of a truncated stencil sits in
+        // one block out of nx / 128.  Such a block runs the uniform path with the absent products skipped (same fold
+        // over the entries the rows do have).  nn bits 16..22 = the first exceptional row (0..127), 23..26 = its
+        // missing slot + 1, 27..30 = the next row's missing slot + 1 (0: that row is regular).
+        int len[2], start[2];
+        int Lmax = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int r = d.ra + lane + h * WAVE;
+            start[h] = row_ptr[r]; len[h] = row_ptr[r + 1] - start[h];
+            Lmax = max(Lmax, len[h]);
+        }
+        for (int o = 32; o > 0; o >>= 1) Lmax = max(Lmax, __shfl_xor(Lmax, o, WAVE));
+        if (Lmax < 2 || Lmax > 8) continue;                                       // (wave-uniform)
+        // the pattern: the first row of full length
+        const uint64_t f0 = __builtin_amdgcn_ballot_w64(len[0] == Lmax), f1 = __builtin_amdgcn_ballot_w64(len[1] == Lmax);
+        const int prow = f0 ? (int)__builtin_ctzll(f0) : WAVE + (int)__builtin_ctzll(f1);
+        const int pA = row_ptr[d.ra + prow];
+        uint8_t A[8];
+        int omin = 0x7fffffff, omax = -0x7fffffff;
+        for (int j = 0; j < 8; ++j) A[j] = j < Lmax ? code[pA + j] : (uint8_t)0;
+        for (int j = 0; j < Lmax; ++j) { const int o = off_tab[A[j]]; omin = min(omin, o); omax = max(omax, o); }
+        int miss[2];
+        bool bad = false;
+        for (int h = 0; h < 2; ++h) {
+            miss[h] = 0;
+            if (len[h] == Lmax) {
+                for (int j = 0; j < Lmax; ++j) bad = bad || code[start[h] + j] != A[j];
+            } else if (len[h] == Lmax - 1) {
+                int j = 0;
+                while (j < Lmax - 1 && code[start[h] + j] == A[j]) ++j;             // the first disagreement is the missing slot
+                miss[h] = j + 1;
+                for (; j < Lmax - 1; ++j) bad = bad || code[start[h] + j] != A[j + 1];
+            } else bad = true;
+        }
+        if (__builtin_amdgcn_ballot_w64(bad) != 0) continue;
+        if ((int64_t)d.ra + omin < 0 || (int64_t)d.rb - 1 + omax > (int64_t)ncols - 1) continue;   // the uniform path does not clamp
+        const uint64_t e0 = __builtin_amdgcn_ballot_w64(miss[0] != 0), e1 = __builtin_amdgcn_ballot_w64(miss[1] != 0);
+        const int ne = __builtin_popcountll(e0) + __builtin_popcountll(e1);
+        if (ne < 1 || ne > 2) continue;
+        const int k = e0 ? (int)__builtin_ctzll(e0) : WAVE + (int)__builtin_ctzll(e1);     // first exceptional row (local index)
+        // missing slots of rows k and k + 1, fetched from the lanes that hold them
+        const int mk = __shfl(k < WAVE ? miss[0] : miss[1], k & (WAVE - 1), WAVE);
+        const int k1 = k + 1;
+        const int mk1 = k1 < 2 * WAVE ? __shfl(k1 < WAVE ? miss[0] : miss[1], k1 & (WAVE - 1), WAVE) : 0;
+        if (ne == 2 && mk1 == 0) continue;                                        // two exceptional rows that are not adjacent
+        if (lane == 0) {
+            int centre = 0;
+            for (int j = 1; triple != 0 && j + 1 < Lmax && centre == 0; ++j) {
+                const int o = off_tab[A[j]];
+                if (off_tab[A[j - 1]] == o - 1 && off_tab[A[j + 1]] == o + 1) centre = j;
+            }
+            desc[b] = BlkDesc{d.ra, (int32_t)((uint32_t)d.rb | UNI2), pA, Lmax | (centre << 8) | (k << 16) | (mk << 23) | (mk1 << 27)};
         }
     }
 }
@@ -455,7 +511,7 @@ __device__ __forceinline__ double wave_shift_down(double next_for_last_lane, dou
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 template <int UL, int SC, class AfterLoads>
-__device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair, uint64_t pat, int ulen, const char *xbytes,
+__device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair, uint64_t pat, int ulen, int seam, const char *xbytes,
                                                    uint32_t r8, uint32_t ra8, int lane, AfterLoads &&after_loads,
                                                    double &acc0, double &acc1) {
     using T = double;
@@ -492,22 +548,37 @@ __device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair
         pl[C - 1] = left; ph[C - 1] = pl[C];
         pl[C + 1] = ph[C]; ph[C + 1] = right;
     }
+    if (seam == 0) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        if (UL == 0 ? t >= ulen : t >= UL) break;
-        acc0 = acc0 + pl[t] * av[t];
-        acc1 = acc1 + ph[t] * av[t];
+        for (int t = 0; t < 8; ++t) {
+            if (UL == 0 ? t >= ulen : t >= UL) break;
+            acc0 = acc0 + pl[t] * av[t];
+            acc1 = acc1 + ph[t] * av[t];
+        }
+    } else {
+        // seam block: local rows k and k + 1 lack slot ma / slot mb (-1: none) — their products are left out of the fold
+        const int k = seam & 127, ma = ((seam >> 7) & 15) - 1, mb = ((seam >> 11) & 15) - 1;
+        const bool a0 = 2 * lane == k, a1 = 2 * lane + 1 == k, b0 = 2 * lane == k + 1, b1 = 2 * lane + 1 == k + 1;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (UL == 0 ? t >= ulen : t >= UL) break;
+            const T n0 = acc0 + pl[t] * av[t], n1 = acc1 + ph[t] * av[t];
+            if (t == ma || t == mb) {                                   // (scalar) one of the two affected slots
+                acc0 = ((a0 && t == ma) || (b0 && t == mb)) ? acc0 : n0;
+                acc1 = ((a1 && t == ma) || (b1 && t == mb)) ? acc1 : n1;
+            } else { acc0 = n0; acc1 = n1; }
+        }
     }
 }
 template <class AfterLoads>
-__device__ __forceinline__ void full_uniform_dispatch(const PairEnt<double> *s_pair, uint64_t pat, int ulen, int sc, const char *xbytes,
+__device__ __forceinline__ void full_uniform_dispatch(const PairEnt<double> *s_pair, uint64_t pat, int ulen, int sc, int seam, const char *xbytes,
                                                       uint32_t r8, uint32_t ra8, int lane, AfterLoads &&after_loads,
                                                       double &acc0, double &acc1) {
     // (scalar branches) the stencils: 7-point 3-D, 5-point 2-D, 3-point 1-D with sorted columns; anything else generic
-    if (ulen == 7 && sc == 3) full_uniform_block<7, 3>(s_pair, pat, ulen, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
-    else if (ulen == 5 && sc == 2) full_uniform_block<5, 2>(s_pair, pat, ulen, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
-    else if (ulen == 3 && sc == 1) full_uniform_block<3, 1>(s_pair, pat, ulen, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
-    else full_uniform_block<0, 0>(s_pair, pat, ulen, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
+    if (ulen == 7 && sc == 3) full_uniform_block<7, 3>(s_pair, pat, ulen, seam, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
+    else if (ulen == 5 && sc == 2) full_uniform_block<5, 2>(s_pair, pat, ulen, seam, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
+    else if (ulen == 3 && sc == 1) full_uniform_block<3, 1>(s_pair, pat, ulen, seam, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
+    else full_uniform_block<0, 0>(s_pair, pat, ulen, seam, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
 }
 
 
@@ -515,6 +586,7 @@ struct Blk2Loads {
     int ra, rb, pa, nn;      // descriptor of the 128-row block
     bool uni; int ulen;      // uniform block (every row = the first row's ulen codes)
     int tri;                 // ... and the slot of its column triple's centre (0: none)
+    int seam;                // ... and its seam rows (mark_uniform_kernel: row | slot + 1 << 7 | next row's slot + 1 << 11; 0: none)
     int a, b;                // row_ptr[i0], row_ptr[i0 + 1], i0 = min(ra + 2 lane, rb - 1)
     double u0, u1;           // dot operands of the lane's two rows
     u4v wc;                  // 16 code bytes
@@ -577,7 +649,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
         L.uni = ((uint32_t)d.rb & UNI2) != 0;                                   // scalar: all rows share one code sequence of d.nn codes
         L.ra = d.ra; L.rb = (int)((uint32_t)d.rb & ~UNI2); L.pa = d.pa;
         L.ulen = L.uni ? (d.nn & 0xff) : 0;
-        L.tri = L.uni ? (d.nn >> 8) : 0;
+        L.tri = L.uni ? ((d.nn >> 8) & 0xff) : 0;
+        L.seam = L.uni ? (d.nn >> 16) : 0;
         L.nn = L.uni ? L.ulen * (L.rb - L.ra) : d.nn;
         const int r0 = L.ra + 2 * lane;
         L.a = 0; L.b = 0;
@@ -601,6 +674,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
     bool c_uni = false;
     uint64_t c_pat = 0;      // uniform block: its (at most 8) codes, first code in the low byte
     int c_tri = 0;           // ... and the centre slot of its column triple
+    int c_seam = 0;          // ... and its seam rows
     T c_u0 = 0.0, c_u1 = 0.0;
     auto stage = [&](const Blk2Loads &L) {
         const int shift = L.pa & 3;
@@ -611,7 +685,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
             const uint64_t hi = (uint64_t)__builtin_amdgcn_readfirstlane(L.wc.z);
             c_pat = shift ? (lo >> (8 * shift)) | (hi << (64 - 8 * shift)) : lo;
             const int r0 = L.ra + 2 * lane;
-            c_ra = L.ra; c_rb = L.rb; c_shift = shift; c_tri = L.tri;
+            c_ra = L.ra; c_rb = L.rb; c_shift = shift; c_tri = L.tri; c_seam = L.seam;
             c_s0 = 0; c_s1 = 0;
             c_len0 = r0 < L.rb ? L.ulen : 0;
             c_len1 = r0 + 1 < L.rb ? L.ulen : 0;
@@ -669,7 +743,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
 #pragma unroll
             for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; av[t] = 0.0; }
             if (c_rb - c_ra == 2 * WAVE) {
-                full_uniform_dispatch(s_pair, c_pat, ulen, c_tri, xbytes, r8, (uint32_t)c_ra * 8u, lane, after_gathers, acc0, acc1);
+                full_uniform_dispatch(s_pair, c_pat, ulen, c_tri, c_seam, xbytes, r8, (uint32_t)c_ra * 8u, lane, after_gathers, acc0, acc1);
             } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -898,7 +972,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
         DICT_TRY2(hipMemcpyAsync(D->off_desc, A->blk_desc, sizeof(BlkDesc) * (size_t)A->n_rowblk, hipMemcpyDeviceToDevice, c->stream));
         const int gu = std::max(1, std::min(c->num_cu * 8, (A->n_rowblk + NWAVE - 1) / NWAVE));
         hipLaunchKernelGGL(mark_uniform_kernel, dim3(gu), dim3(BLOCK), 0, c->stream, (int)A->n_rowblk,
-                           reinterpret_cast<BlkDesc *>(D->off_desc), A->row_ptr, D->idx_code, UNI_OFF_MAXLEN, (const int32_t *)nullptr);
+                           reinterpret_cast<BlkDesc *>(D->off_desc), A->row_ptr, D->idx_code, UNI_OFF_MAXLEN, (const int32_t *)nullptr, 0, 0, 0);
         DICT_TRY2(hipGetLastError());
         // how many qualified: the auto policy wants to know for matrices that live in the Infinity Cache (small: a
         // few MB of descriptors at most); HBM-sized ones take the offset stream anyway
@@ -954,7 +1028,8 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
                     const int gu = std::max(1, std::min(c->num_cu * 8, (nw + NWAVE - 1) / NWAVE));
                     hipLaunchKernelGGL(mark_uniform_kernel, dim3(gu), dim3(BLOCK), 0, c->stream, nw,
                                        reinterpret_cast<BlkDesc *>(D->wide_desc), A->row_ptr, D->pair_code, UNI2_MAXLEN,
-                                       c->spmv_triple != 0 ? (const int32_t *)D->pair_off : (const int32_t *)nullptr);
+                                       (const int32_t *)D->pair_off, c->spmv_triple != 0 ? 1 : 0, c->spmv_seam != 0 ? 1 : 0,
+                                       (int)A->ncols);
                     DICT_TRY2(hipGetLastError());
                 }
                 DICT_TRY2(hipStreamSynchronize(c->stream));

@@ -23,6 +23,7 @@ def _restore_knob(sa):
     sa.default_ctx(0).set("spmv_dict", -1)
     sa.default_ctx(0).set("spmv_wide", -1)
     sa.default_ctx(0).set("spmv_triple", -1)
+    sa.default_ctx(0).set("spmv_seam", -1)
 
 
 def bits(a):
@@ -463,6 +464,37 @@ def test_column_triples_of_uniform_blocks(sa, oracle, offs):
             assert np.array_equal(bits(y2), bits(ref))
         assert dots[0] == dots[1]
     ctx.set("spmv_triple", -1)
+
+
+@pytest.mark.parametrize("shape", [(300, 6, 5), (517, 5, 4), (129, 7, 3), (1000, 4, 1)], ids=lambda sh: "x".join(map(str, sh)))
+def test_seam_blocks_run_the_uniform_path(sa, oracle, shape):
+    """A 128-row block that holds the x = nx - 1 | x = 0 seam of a truncated stencil is uniform but for two adjacent rows
+    that lack one slot each: flagged at creation (knob spmv_seam), it runs the uniform path with those two products left
+    out of the fold.  More blocks flagged, y bit-identical, the fused dot identical (same lanes, same rows, same order)."""
+    from sprsolve_amd import gen
+    ctx = sa.default_ctx(0)
+    indptr, cols, data, _ = gen.poisson3d(*shape)
+    n = indptr.size - 1
+    x = rand_vec(n, np.float64, 41)
+    ref = oracle.spmv(indptr, cols, data, x)
+    got = {}
+    try:
+        for seam in (0, 1):
+            ctx.set("spmv_seam", seam)
+            A = sa.HipCsr.new((n, n), indptr, cols, data)
+            assert A.stream_format()[0] == 2
+            nb, nu = A.wide_blocks()
+            y = np.full(n, 9.0)
+            A.mul_vec(x, y)
+            assert np.array_equal(bits(y), bits(ref)), seam
+            y2 = np.zeros(n)
+            d = A.mul_vec_dot(x, y2)
+            assert np.array_equal(bits(y2), bits(ref))
+            got[seam] = (nu, d)
+        assert got[1][0] > got[0][0], got              # seam blocks were found
+        assert got[1][1] == got[0][1]
+    finally:
+        ctx.set("spmv_seam", -1)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
