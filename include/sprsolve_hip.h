@@ -77,8 +77,8 @@ int sprs_version(void);
  *   "spmv_wide"     f64 pair codes: two rows per lane, 128-row blocks (-1 / 1 on, 0 off)
  *   "spmv_uniform"  blocks whose rows repeat one code sequence are multiplied from that pattern          (creation)
  *   "spmv_triple"   ... and read columns c - 1, c + 1 of a column triple from column c's loads           (creation)
- *   "spmv_seam"     ... and so are blocks that are uniform but for one row, or two adjacent ones, lacking
- *                   one slot of the pattern (the line seam of a truncated stencil)                      (creation)
+ *   "spmv_seam"     ... and so are blocks that are uniform but for one row, or two adjacent ones, holding only
+ *                   part of the pattern or one entry of their own (line seams of truncated / Dirichlet grids) (creation)
  *   "spmv_eqrows"   plain CSR: blocks of equal-length rows do not read row_ptr                           (creation)
  *   "spmv_period"   1: XCD-period walk of the compressed streams' blocks for matrices with a far band;
  *                   default 0 (measured: fabric traffic -58 %, time unchanged)                           (creation)

@@ -32,7 +32,7 @@ def make(n):
     if kind == 3 and n > 600:       # far band (period schedule, plane-like)
         offs = np.unique(np.concatenate([offs, [-(n // 5), n // 5]]))
     line = int(rng.integers(130, 700)) if kind == 6 else 0
-    rng_seam = bool(rng.integers(0, 2))
+    seam_kind = int(rng.integers(0, 3))
     rows = []
     ragged_lo, ragged_hi = (int(rng.integers(0, n)), int(rng.integers(0, n)))
     ragged_lo, ragged_hi = min(ragged_lo, ragged_hi), max(ragged_lo, ragged_hi)
@@ -44,16 +44,19 @@ def make(n):
         if kind == 2 and rng.uniform() < 0.02:
             c = c[:0]
         if kind == 6 and line > 0:        # truncated lines: the last row of a line lacks its largest offset, the first its smallest
-            if r % line == line - 1 and c.size > 1:
-                c = c[:-1] if rng_seam else c[c != r + 1]
+            if seam_kind == 2:            # ... or Dirichlet rows: the two rows at a seam hold one entry (not always the diagonal)
+                if r % line in (0, line - 1) and c.size > 1:
+                    c = c[[int(c.size // 2) if r % 3 else 0]]
+            elif r % line == line - 1 and c.size > 1:
+                c = c[:-1] if seam_kind else c[c != r + 1]
             elif r % line == 0 and c.size > 1:
-                c = c[1:] if rng_seam else c[c != r - 1]
+                c = c[1:] if seam_kind else c[c != r - 1]
         rows.append(c)
     indptr = np.zeros(n + 1, dtype=np.int32)
     np.cumsum([len(c) for c in rows], out=indptr[1:])
     cols = np.concatenate(rows).astype(np.int32) if indptr[-1] else np.zeros(0, np.int32)
-    if kind >= 5:                   # one value per offset: interior blocks are uniform
-        vals = (np.concatenate([c - r for r, c in enumerate(rows)]) * 0.375 + 1.0) if indptr[-1] else np.zeros(0)
+    if kind >= 5:                   # one value per offset: interior blocks are uniform; single-entry rows carry a value of their own
+        vals = (np.concatenate([(c - r) * 0.375 + (1.0 if c.size > 1 else 7.5) for r, c in enumerate(rows)])) if indptr[-1] else np.zeros(0)
     elif rng.uniform() < 0.5:
         vals = np.array([1.0, -1.0, 0.5, 2.0, -3.25, 6.0])[rng.integers(0, 6, cols.size)]      # value dictionary
     else:

@@ -15,6 +15,7 @@ namespace sprs {
 
 constexpr int BLOCK = 256;     // threads per workgroup (4 wavefronts of 64)
 constexpr uint32_t UNI2 = 0x40000000u;  // 128-row block descriptors (spmv_dict.hip), rb bit 30: every row has the SAME code sequence
+constexpr uint32_t SEAM2 = 0x20000000u; // ... bit 29 (with UNI2, full 128-row blocks): all rows but one or two; rb's low bits then describe those (spmv_dict.hip)
 constexpr int MAX_GRID = 4096; // upper bound of the streaming-kernel grid (= max partials per reduction)
 
 // device-side status word of a running solve

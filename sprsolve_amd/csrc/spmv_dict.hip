@@ -430,11 +430,16 @@ __global__ __launch_bounds__(BLOCK) void mark_uniform_kernel(int n_wide, BlkDesc
             desc[b] = BlkDesc{d.ra, (int32_t)((uint32_t)d.rb | UNI2), d.pa, L0 | (centre << 8)};
         }
         if (all_ok || off_tab == nullptr || seam == 0 || nr != 2 * WAVE) continue;
-        // ---- SEAM blocks (pair codes, full 128-row blocks): every row repeats one pattern except one row, or two
-        // adjacent ones, that lack exactly one of its slots — the x = nx - 1 | x = 0 seam of a truncated stencil sits in
-        // one block out of nx / 128.  Such a block runs the uniform path with the absent products skipped (same fold
-        // over the entries the rows do have).  nn bits 16..22 = the first exceptional row (0..127), 23..26 = its
-        // missing slot + 1, 27..30 = the next row's missing slot + 1 (0: that row is regular).
+        // ---- SEAM blocks (pair codes, full 128-row blocks): every row repeats one pattern A (the longest row's) except
+        // one row, or two adjacent ones, which hold
+        //   * a subsequence of A's codes (the x = nx - 1 | x = 0 seam of a truncated stencil: one slot missing), or
+        //   * a single entry on one of A's offsets with a value of its own (a Dirichlet / identity row inside a stencil).
+        // Such a block runs the uniform path: all rows gather with A's offsets (checked in bounds for every row here, since
+        // that path does not clamp), the exceptional rows fold only the slots they have, with their own value where
+        // they have one.  Same entries, same order per row.  Encoding (rb is redundant for a full block: ra + 128):
+        //   nn  bits 0..7 length of A, 8..15 centre slot, 16..22 first exceptional row k, 23..30 its slot mask
+        //   rb  bit 30 UNI2, bit 29 SEAM, 0..7 slot mask of row k + 1 (0xff..: regular), 8..15 / 16..23 the value-bearing
+        //       pair code of row k / k + 1, bit 24 / 25: that row takes its value from that code
         int len[2], start[2];
         int Lmax = 0;
         for (int h = 0; h < 2; ++h) {
@@ -444,45 +449,61 @@ __global__ __launch_bounds__(BLOCK) void mark_uniform_kernel(int n_wide, BlkDesc
         }
         for (int o = 32; o > 0; o >>= 1) Lmax = max(Lmax, __shfl_xor(Lmax, o, WAVE));
         if (Lmax < 2 || Lmax > 8) continue;                                       // (wave-uniform)
-        // the pattern: the first row of full length
         const uint64_t f0 = __builtin_amdgcn_ballot_w64(len[0] == Lmax), f1 = __builtin_amdgcn_ballot_w64(len[1] == Lmax);
-        const int prow = f0 ? (int)__builtin_ctzll(f0) : WAVE + (int)__builtin_ctzll(f1);
+        const int prow = f0 ? (int)__builtin_ctzll(f0) : WAVE + (int)__builtin_ctzll(f1);     // the first row of full length
         const int pA = row_ptr[d.ra + prow];
         uint8_t A[8];
         int omin = 0x7fffffff, omax = -0x7fffffff;
         for (int j = 0; j < 8; ++j) A[j] = j < Lmax ? code[pA + j] : (uint8_t)0;
         for (int j = 0; j < Lmax; ++j) { const int o = off_tab[A[j]]; omin = min(omin, o); omax = max(omax, o); }
-        int miss[2];
+        const int full = (1 << Lmax) - 1;
+        int mask[2], ovc[2];           // slots the row has; its own value-bearing code or -1
         bool bad = false;
         for (int h = 0; h < 2; ++h) {
-            miss[h] = 0;
-            if (len[h] == Lmax) {
-                for (int j = 0; j < Lmax; ++j) bad = bad || code[start[h] + j] != A[j];
-            } else if (len[h] == Lmax - 1) {
-                int j = 0;
-                while (j < Lmax - 1 && code[start[h] + j] == A[j]) ++j;             // the first disagreement is the missing slot
-                miss[h] = j + 1;
-                for (; j < Lmax - 1; ++j) bad = bad || code[start[h] + j] != A[j + 1];
+            mask[h] = 0; ovc[h] = -1;
+            int j = 0;
+            bool sub = true;
+            for (int i = 0; i < len[h] && sub; ++i) {
+                const uint8_t cd = code[start[h] + i];
+                while (j < Lmax && A[j] != cd) ++j;
+                if (j == Lmax) sub = false; else { mask[h] |= 1 << j; ++j; }
+            }
+            if (sub) continue;
+            mask[h] = 0;
+            if (len[h] == 1) {
+                const int cd = code[start[h]], o = off_tab[cd];
+                for (int q = 0; q < Lmax && mask[h] == 0; ++q) if (off_tab[A[q]] == o) mask[h] = 1 << q;
+                if (mask[h] != 0) ovc[h] = cd; else bad = true;
             } else bad = true;
         }
         if (__builtin_amdgcn_ballot_w64(bad) != 0) continue;
-        if ((int64_t)d.ra + omin < 0 || (int64_t)d.rb - 1 + omax > (int64_t)ncols - 1) continue;   // the uniform path does not clamp
-        const uint64_t e0 = __builtin_amdgcn_ballot_w64(miss[0] != 0), e1 = __builtin_amdgcn_ballot_w64(miss[1] != 0);
+        if ((int64_t)d.ra + omin < 0 || (int64_t)d.rb - 1 + omax > (int64_t)ncols - 1) continue;
+        const uint64_t e0 = __builtin_amdgcn_ballot_w64(mask[0] != full), e1 = __builtin_amdgcn_ballot_w64(mask[1] != full);
         const int ne = __builtin_popcountll(e0) + __builtin_popcountll(e1);
         if (ne < 1 || ne > 2) continue;
         const int k = e0 ? (int)__builtin_ctzll(e0) : WAVE + (int)__builtin_ctzll(e1);     // first exceptional row (local index)
-        // missing slots of rows k and k + 1, fetched from the lanes that hold them
-        const int mk = __shfl(k < WAVE ? miss[0] : miss[1], k & (WAVE - 1), WAVE);
         const int k1 = k + 1;
-        const int mk1 = k1 < 2 * WAVE ? __shfl(k1 < WAVE ? miss[0] : miss[1], k1 & (WAVE - 1), WAVE) : 0;
-        if (ne == 2 && mk1 == 0) continue;                                        // two exceptional rows that are not adjacent
+        if (ne == 2 && k1 >= 2 * WAVE) continue;
+        // masks and codes of rows k and k + 1, fetched from the lanes that hold them
+        const int mA = __shfl(k < WAVE ? mask[0] : mask[1], k & (WAVE - 1), WAVE);
+        const int cA = __shfl(k < WAVE ? ovc[0] : ovc[1], k & (WAVE - 1), WAVE);
+        int mB = full, cB = -1;
+        if (k1 < 2 * WAVE) {
+            mB = __shfl(k1 < WAVE ? mask[0] : mask[1], k1 & (WAVE - 1), WAVE);
+            cB = __shfl(k1 < WAVE ? ovc[0] : ovc[1], k1 & (WAVE - 1), WAVE);
+        }
+        if (ne == 2 && mB == full) continue;                                      // two exceptional rows that are not adjacent
         if (lane == 0) {
             int centre = 0;
             for (int j = 1; triple != 0 && j + 1 < Lmax && centre == 0; ++j) {
                 const int o = off_tab[A[j]];
                 if (off_tab[A[j - 1]] == o - 1 && off_tab[A[j + 1]] == o + 1) centre = j;
             }
-            desc[b] = BlkDesc{d.ra, (int32_t)((uint32_t)d.rb | UNI2), pA, Lmax | (centre << 8) | (k << 16) | (mk << 23) | (mk1 << 27)};
+            // rows that are regular in every slot A has keep the mask 0xff (slots >= Lmax are never folded)
+            const uint32_t mB8 = mB == full ? 0xffu : (uint32_t)mB;
+            const uint32_t rbw = UNI2 | SEAM2 | mB8 | ((uint32_t)(cA < 0 ? 0 : cA) << 8) | ((uint32_t)(cB < 0 ? 0 : cB) << 16) |
+                                 (cA >= 0 ? 1u << 24 : 0u) | (cB >= 0 ? 1u << 25 : 0u);
+            desc[b] = BlkDesc{d.ra, (int32_t)rbw, pA, Lmax | (centre << 8) | (k << 16) | (mA << 23)};
         }
     }
 }
@@ -511,7 +532,7 @@ __device__ __forceinline__ double wave_shift_down(double next_for_last_lane, dou
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 template <int UL, int SC, class AfterLoads>
-__device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair, uint64_t pat, int ulen, int seam, const char *xbytes,
+__device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair, uint64_t pat, int ulen, bool seam, int seam1, int seam2, const char *xbytes,
                                                    uint32_t r8, uint32_t ra8, int lane, AfterLoads &&after_loads,
                                                    double &acc0, double &acc1) {
     using T = double;
@@ -548,7 +569,7 @@ __device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair
         pl[C - 1] = left; ph[C - 1] = pl[C];
         pl[C + 1] = ph[C]; ph[C + 1] = right;
     }
-    if (seam == 0) {
+    if (!seam) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             if (UL == 0 ? t >= ulen : t >= UL) break;
@@ -556,29 +577,33 @@ __device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair
             acc1 = acc1 + ph[t] * av[t];
         }
     } else {
-        // seam block: local rows k and k + 1 lack slot ma / slot mb (-1: none) — their products are left out of the fold
-        const int k = seam & 127, ma = ((seam >> 7) & 15) - 1, mb = ((seam >> 11) & 15) - 1;
+        // seam block: local rows k and k + 1 fold only the slots of their masks, with their own value where they carry one
+        // (a row with a value of its own has exactly one slot)
+        const int k = seam1 & 127, maskA = (seam1 >> 7) & 255, maskB = seam2 & 255;
+        const T valA = s_pair[(seam2 >> 8) & 255].val, valB = s_pair[(seam2 >> 16) & 255].val;
+        const bool ovA = ((seam2 >> 24) & 1) != 0, ovB = ((seam2 >> 25) & 1) != 0;
         const bool a0 = 2 * lane == k, a1 = 2 * lane + 1 == k, b0 = 2 * lane == k + 1, b1 = 2 * lane + 1 == k + 1;
+        const int pm0 = a0 ? maskA : (b0 ? maskB : 255), pm1 = a1 ? maskA : (b1 ? maskB : 255);
+        const bool o0 = (a0 && ovA) || (b0 && ovB), o1 = (a1 && ovA) || (b1 && ovB);
+        const T v0 = a0 ? valA : valB, v1 = a1 ? valA : valB;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             if (UL == 0 ? t >= ulen : t >= UL) break;
-            const T n0 = acc0 + pl[t] * av[t], n1 = acc1 + ph[t] * av[t];
-            if (t == ma || t == mb) {                                   // (scalar) one of the two affected slots
-                acc0 = ((a0 && t == ma) || (b0 && t == mb)) ? acc0 : n0;
-                acc1 = ((a1 && t == ma) || (b1 && t == mb)) ? acc1 : n1;
-            } else { acc0 = n0; acc1 = n1; }
+            const T n0 = acc0 + pl[t] * (o0 ? v0 : av[t]), n1 = acc1 + ph[t] * (o1 ? v1 : av[t]);
+            acc0 = ((pm0 >> t) & 1) ? n0 : acc0;
+            acc1 = ((pm1 >> t) & 1) ? n1 : acc1;
         }
     }
 }
 template <class AfterLoads>
-__device__ __forceinline__ void full_uniform_dispatch(const PairEnt<double> *s_pair, uint64_t pat, int ulen, int sc, int seam, const char *xbytes,
+__device__ __forceinline__ void full_uniform_dispatch(const PairEnt<double> *s_pair, uint64_t pat, int ulen, int sc, bool seam, int seam1, int seam2, const char *xbytes,
                                                       uint32_t r8, uint32_t ra8, int lane, AfterLoads &&after_loads,
                                                       double &acc0, double &acc1) {
     // (scalar branches) the stencils: 7-point 3-D, 5-point 2-D, 3-point 1-D with sorted columns; anything else generic
-    if (ulen == 7 && sc == 3) full_uniform_block<7, 3>(s_pair, pat, ulen, seam, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
-    else if (ulen == 5 && sc == 2) full_uniform_block<5, 2>(s_pair, pat, ulen, seam, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
-    else if (ulen == 3 && sc == 1) full_uniform_block<3, 1>(s_pair, pat, ulen, seam, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
-    else full_uniform_block<0, 0>(s_pair, pat, ulen, seam, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
+    if (ulen == 7 && sc == 3) full_uniform_block<7, 3>(s_pair, pat, ulen, seam, seam1, seam2, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
+    else if (ulen == 5 && sc == 2) full_uniform_block<5, 2>(s_pair, pat, ulen, seam, seam1, seam2, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
+    else if (ulen == 3 && sc == 1) full_uniform_block<3, 1>(s_pair, pat, ulen, seam, seam1, seam2, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
+    else full_uniform_block<0, 0>(s_pair, pat, ulen, seam, seam1, seam2, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
 }
 
 
@@ -586,7 +611,7 @@ struct Blk2Loads {
     int ra, rb, pa, nn;      // descriptor of the 128-row block
     bool uni; int ulen;      // uniform block (every row = the first row's ulen codes)
     int tri;                 // ... and the slot of its column triple's centre (0: none)
-    int seam;                // ... and its seam rows (mark_uniform_kernel: row | slot + 1 << 7 | next row's slot + 1 << 11; 0: none)
+    bool is_seam; int seam1, seam2;   // ... or uniform but for one or two rows (mark_uniform_kernel's encoding: nn >> 16, rb's low bits)
     int a, b;                // row_ptr[i0], row_ptr[i0 + 1], i0 = min(ra + 2 lane, rb - 1)
     double u0, u1;           // dot operands of the lane's two rows
     u4v wc;                  // 16 code bytes
@@ -647,10 +672,12 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
     };
     auto issue = [&](const BlkDesc &d, Blk2Loads &L) {
         L.uni = ((uint32_t)d.rb & UNI2) != 0;                                   // scalar: all rows share one code sequence of d.nn codes
-        L.ra = d.ra; L.rb = (int)((uint32_t)d.rb & ~UNI2); L.pa = d.pa;
+        L.is_seam = L.uni && ((uint32_t)d.rb & SEAM2) != 0;                     // ... but for one or two of them
+        L.ra = d.ra; L.rb = L.is_seam ? d.ra + 2 * WAVE : (int)((uint32_t)d.rb & ~UNI2); L.pa = d.pa;
         L.ulen = L.uni ? (d.nn & 0xff) : 0;
         L.tri = L.uni ? ((d.nn >> 8) & 0xff) : 0;
-        L.seam = L.uni ? (d.nn >> 16) : 0;
+        L.seam1 = L.is_seam ? (d.nn >> 16) : 0;
+        L.seam2 = L.is_seam ? (int)((uint32_t)d.rb & 0x3ffffffu) : 0;
         L.nn = L.uni ? L.ulen * (L.rb - L.ra) : d.nn;
         const int r0 = L.ra + 2 * lane;
         L.a = 0; L.b = 0;
@@ -674,7 +701,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
     bool c_uni = false;
     uint64_t c_pat = 0;      // uniform block: its (at most 8) codes, first code in the low byte
     int c_tri = 0;           // ... and the centre slot of its column triple
-    int c_seam = 0;          // ... and its seam rows
+    bool c_seam = false;     // ... or uniform but for one or two rows:
+    int c_seam1 = 0, c_seam2 = 0;
     T c_u0 = 0.0, c_u1 = 0.0;
     auto stage = [&](const Blk2Loads &L) {
         const int shift = L.pa & 3;
@@ -685,7 +713,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
             const uint64_t hi = (uint64_t)__builtin_amdgcn_readfirstlane(L.wc.z);
             c_pat = shift ? (lo >> (8 * shift)) | (hi << (64 - 8 * shift)) : lo;
             const int r0 = L.ra + 2 * lane;
-            c_ra = L.ra; c_rb = L.rb; c_shift = shift; c_tri = L.tri; c_seam = L.seam;
+            c_ra = L.ra; c_rb = L.rb; c_shift = shift; c_tri = L.tri; c_seam = L.is_seam; c_seam1 = L.seam1; c_seam2 = L.seam2;
             c_s0 = 0; c_s1 = 0;
             c_len0 = r0 < L.rb ? L.ulen : 0;
             c_len1 = r0 + 1 < L.rb ? L.ulen : 0;
@@ -743,7 +771,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
 #pragma unroll
             for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; av[t] = 0.0; }
             if (c_rb - c_ra == 2 * WAVE) {
-                full_uniform_dispatch(s_pair, c_pat, ulen, c_tri, c_seam, xbytes, r8, (uint32_t)c_ra * 8u, lane, after_gathers, acc0, acc1);
+                full_uniform_dispatch(s_pair, c_pat, ulen, c_tri, c_seam, c_seam1, c_seam2, xbytes, r8, (uint32_t)c_ra * 8u, lane, after_gathers, acc0, acc1);
             } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
