@@ -91,8 +91,7 @@ static int launch_ew(sprs_ctx *c, size_t n, bool all_aligned, F f) {
     constexpr int PKW = pack_width<T>::value;
     const int pk = (all_aligned && PKW > 1) ? PKW : 1;
     int64_t work = ((int64_t)n / pk + BLOCK - 1) / BLOCK;
-    int g = grid_for(c);
-    if (work < g) g = (int)(work < 1 ? 1 : work);
+    const int g = balanced_grid(c, work);
     if (pk == PKW && PKW > 1)
         hipLaunchKernelGGL((ew_kernel<PKW, F>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, f);
     else
@@ -216,9 +215,7 @@ int reduce_partials_host(sprs_ctx *c, const T *part, int P, T *out, sprs_comm *c
 
 static int red_grid(sprs_ctx *c, size_t n, int pk) {
     int64_t work = ((int64_t)n / pk + BLOCK - 1) / BLOCK;
-    int g = grid_for(c);
-    if (work < g) g = (int)(work < 1 ? 1 : work);
-    return g;
+    return balanced_grid(c, work);
 }
 
 template <class T>

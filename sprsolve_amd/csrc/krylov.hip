@@ -371,9 +371,7 @@ template <class T>
 int KrylovBase<T>::ew_grid() const {
     constexpr int PKW = pack_width<T>::value;
     int64_t workb = ((int64_t)n / PKW + BLOCK - 1) / BLOCK;
-    int g = grid_for(ctx);
-    if (workb < g) g = (int)(workb < 1 ? 1 : workb);
-    return g;
+    return balanced_grid(ctx, workb);
 }
 
 // partial hand-off kernels for the distributed case: reduce up to two partial arrays into `red`
