@@ -84,9 +84,18 @@ template <class T, int PK>
 struct alignas(sizeof(T) * PK) Pack {
     T v[PK];
 };
-template <class T, int PK>
+template <class T, int PK, bool NT = false>
 __device__ __forceinline__ Pack<T, PK> ldp(const T *p, int64_t i) {
-    return *reinterpret_cast<const Pack<T, PK> *>(p + i * PK);
+    if constexpr (NT) {
+        constexpr int W = (int)(sizeof(T) * PK / 4);
+        typedef unsigned int uvec __attribute__((ext_vector_type(W)));
+        const uvec q = __builtin_nontemporal_load(reinterpret_cast<const uvec *>(p + i * PK));
+        Pack<T, PK> r;
+        __builtin_memcpy(&r, &q, sizeof(r));
+        return r;
+    } else {
+        return *reinterpret_cast<const Pack<T, PK> *>(p + i * PK);
+    }
 }
 template <class T, int PK>
 __device__ __forceinline__ void stp(T *p, int64_t i, const Pack<T, PK> &v) {

@@ -50,6 +50,8 @@ struct sprs_ctx {
     int spmv_period = 0;   // f64 pair codes: XCD-period schedule for matrices with a far band (3-D stencils), 1 = on.  Read at creation
     int spmv_triple = -1;  // f64 pair codes, uniform blocks: columns c - 1 and c + 1 read from column c's loads; 0 = off.  Read at creation
     int spmv_seam = -1;    // f64 pair codes: blocks that are uniform but for one or two adjacent rows lacking one slot run the uniform path; 0 = off.  Read at creation
+    int stream_nt = -1;    // fused recurrence kernels read their operands with non-temporal loads: -1 auto (by vector size), 0 / 1
+    int stream_nt_mask = 7; // ... in which of them: bit 0 K1 / MINRES kernels, bit 1 K3, bit 2 K5 (profiles/r02_tuning.md §20)
                            // and at launch.  Off by default: it cuts the SpMV's fabric reads by 58 % (x crosses the fabric once) and the
                            // kernel's time not at all (profiles/r02_tuning.md §7)
     int spmv_uniform = -1; // ... and blocks whose rows all repeat one code sequence read neither codes nor row_ptr; read at creation
@@ -247,6 +249,14 @@ inline int grid_for(const sprs_ctx *c) {
     if (g < 8) g = 8;
     if (g > MAX_GRID) g = MAX_GRID;
     return g & ~7;
+}
+
+// Non-temporal operand loads for the fused recurrence kernels: knob "stream_nt" (1 / 0), automatic (-1) from the size of
+// one vector — measured cross-over between 50 MB (vectors of a solve live in the 256 MiB Infinity Cache: -4 %) and
+// 100 MB (+9 %).
+inline bool stream_loads_nt(const sprs_ctx *c, size_t vector_bytes) {
+    if (c->stream_nt >= 0) return c->stream_nt != 0;
+    return vector_bytes >= (size_t)72 << 20;
 }
 
 // Grid of a grid-stride streaming pass over `work` tiles: no more workgroups than the context's grid, and as few as make

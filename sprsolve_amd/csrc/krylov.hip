@@ -29,21 +29,27 @@ namespace sprs {
 
 
 // ======================================================================= fused kernel skeleton
-template <int PK, class F>
+// NT: the vector operands are read with non-temporal loads.  At HBM sizes every operand is streamed once per pass and
+// evicted long before its next use; loads that do not allocate on the way leave the caches to the SpMV's gathers and run
+// 5-10 % faster in the mix with stores (profiles/r02_tuning.md §20).  Vectors that live in the Infinity Cache lose with it.
+template <int PK, bool NT, class F>
 __global__ __launch_bounds__(BLOCK) void fused_kernel(int64_t n, F f) {
     if (!f.prologue()) return;
-    SPRS_FOREACH_PACK(n, PK, i) f.template run<PK>(i);
+    SPRS_FOREACH_PACK(n, PK, i) f.template run<PK, NT>(i);
     if (PK > 1) {
         int64_t i = (n / PK) * PK + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-        if (i < n) f.template run<1>(i);
+        if (i < n) f.template run<1, NT>(i);
     }
     f.epilogue();
 }
 
 template <class T, class F>
-static int launch_fused(sprs_ctx *c, size_t n, int grid, F f) {
+static int launch_fused(sprs_ctx *c, size_t n, int grid, F f, int which = 0) {
     constexpr int PKW = pack_width<T>::value;
-    hipLaunchKernelGGL((fused_kernel<PKW, F>), dim3(grid), dim3(BLOCK), 0, c->stream, (int64_t)n, f);
+    if (stream_loads_nt(c, n * sizeof(T)) && ((c->stream_nt_mask >> which) & 1))
+        hipLaunchKernelGGL((fused_kernel<PKW, true, F>), dim3(grid), dim3(BLOCK), 0, c->stream, (int64_t)n, f);
+    else
+        hipLaunchKernelGGL((fused_kernel<PKW, false, F>), dim3(grid), dim3(BLOCK), 0, c->stream, (int64_t)n, f);
     SPRS_HIP_TRY(c, hipGetLastError());
     return SPRS_OK;
 }
@@ -92,11 +98,11 @@ struct BicgK1 {
         if (first_thread()) { S->rho = rho; S->r_norm = r_norm; S->beta = beta; }
         return true;
     }
-    template <int PK> __device__ __forceinline__ void run(int64_t i) const {
-        auto vv = ldp<T, PK>(v, i); auto pv = ldp<T, PK>(p, i); auto rv = ldp<T, PK>(r, i);
+    template <int PK, bool NT> __device__ __forceinline__ void run(int64_t i) const {
+        auto vv = ldp<T, PK, NT>(v, i); auto pv = ldp<T, PK, NT>(p, i); auto rv = ldp<T, PK, NT>(r, i);
         Pack<T, PK> yv;
         [[maybe_unused]] Pack<V, PK> dv;
-        if (PC) dv = ldp<V, PK>(dinv, i);
+        if (PC) dv = ldp<V, PK, NT>(dinv, i);
 #pragma unroll
         for (int e = 0; e < PK; ++e) {
             T t = sadd(smul(vv.v[e], a), smul(pv.v[e], beta));      // :155 axpby
@@ -131,11 +137,11 @@ struct BicgK3 {
         if (first_thread()) S->alpha = alpha;
         return true;
     }
-    template <int PK> __device__ __forceinline__ void run(int64_t i) const {
-        auto vv = ldp<T, PK>(v, i); auto rv = ldp<T, PK>(r, i);
+    template <int PK, bool NT> __device__ __forceinline__ void run(int64_t i) const {
+        auto vv = ldp<T, PK, NT>(v, i); auto rv = ldp<T, PK, NT>(r, i);
         Pack<T, PK> zv;
         [[maybe_unused]] Pack<V, PK> dv;
-        if (PC) dv = ldp<V, PK>(dinv, i);
+        if (PC) dv = ldp<V, PK, NT>(dinv, i);
 #pragma unroll
         for (int e = 0; e < PK; ++e) {
             rv.v[e] = sadd(rv.v[e], smul(vv.v[e], na));             // :172
@@ -168,11 +174,11 @@ struct BicgK5 {
         accN = 0.0; accR = szero<T>();
         return true;
     }
-    template <int PK> __device__ __forceinline__ void run(int64_t i) {
-        auto xv = ldp<T, PK>(x, i); auto yv = ldp<T, PK>(y, i); auto rv = ldp<T, PK>(r, i);
-        auto tv = ldp<T, PK>(t, i); auto qv = ldp<T, PK>(r0, i);
+    template <int PK, bool NT> __device__ __forceinline__ void run(int64_t i) {
+        auto xv = ldp<T, PK, NT>(x, i); auto yv = ldp<T, PK, NT>(y, i); auto rv = ldp<T, PK, NT>(r, i);
+        auto tv = ldp<T, PK, NT>(t, i); auto qv = ldp<T, PK, NT>(r0, i);
         [[maybe_unused]] Pack<T, PK> zv;
-        if (PC) zv = ldp<T, PK>(z, i);
+        if (PC) zv = ldp<T, PK, NT>(z, i);
 #pragma unroll
         for (int e = 0; e < PK; ++e) {
             T xx = sadd(xv.v[e], smul(yv.v[e], na));                // :188
@@ -216,11 +222,11 @@ struct MinresM2 {
         if (first_thread()) D->st[par].alpha = alpha;
         return true;
     }
-    template <int PK> __device__ __forceinline__ void run(int64_t i) {
-        auto nv = ldp<T, PK>(v_new, i); auto ov = ldp<T, PK>(v_old, i); auto cv = ldp<T, PK>(v, i);
+    template <int PK, bool NT> __device__ __forceinline__ void run(int64_t i) {
+        auto nv = ldp<T, PK, NT>(v_new, i); auto ov = ldp<T, PK, NT>(v_old, i); auto cv = ldp<T, PK, NT>(v, i);
         Pack<T, PK> wv;
         [[maybe_unused]] Pack<V, PK> dv;
-        if (PC) dv = ldp<V, PK>(dinv, i);
+        if (PC) dv = ldp<V, PK, NT>(dinv, i);
 #pragma unroll
         for (int e = 0; e < PK; ++e) {
             T t = sadd(nv.v[e], smul(ov.v[e], nb));                 // :117
@@ -289,12 +295,12 @@ struct MinresM3 {
         coef = smulr(smul(c_new, S.eta), S.beta_one);                                      // :162
         return true;
     }
-    template <int PK> __device__ __forceinline__ void run(int64_t i) const {
-        auto nv = ldp<T, PK>(v_new, i);
-        auto qv = ldp<T, PK>(q, i); auto po = ldp<T, PK>(p_old, i); auto poo = ldp<T, PK>(p_oold, i);
-        auto xv = ldp<T, PK>(x, i);
+    template <int PK, bool NT> __device__ __forceinline__ void run(int64_t i) const {
+        auto nv = ldp<T, PK, NT>(v_new, i);
+        auto qv = ldp<T, PK, NT>(q, i); auto po = ldp<T, PK, NT>(p_old, i); auto poo = ldp<T, PK, NT>(p_oold, i);
+        auto xv = ldp<T, PK, NT>(x, i);
         [[maybe_unused]] Pack<T, PK> wv;
-        if (PC) wv = ldp<T, PK>(w_new, i);
+        if (PC) wv = ldp<T, PK, NT>(w_new, i);
         Pack<T, PK> pv;
 #pragma unroll
         for (int e = 0; e < PK; ++e) {
@@ -602,16 +608,16 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
         return this->red1(partB, GS, 0, &qB);
     };
     auto K3 = [&](int check) -> int {
-        if (pc) return launch_fused<T>(c, n, G, BicgK3<T, V, true>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()});
-        return launch_fused<T>(c, n, G, BicgK3<T, V, false>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()});
+        if (pc) return launch_fused<T>(c, n, G, BicgK3<T, V, true>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()}, 1);
+        return launch_fused<T>(c, n, G, BicgK3<T, V, false>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()}, 1);
     };
     auto K4 = [&]() -> int {                                                                 // :104/:175 t = A s ; t.t, t.r
         SPRS_TRY(this->spmv(sz, t, 2, r, partTT, partTR, d_status));
         return this->red2(partTT, partTR, GS, 1, &qTT, &qTR);
     };
     auto K5 = [&]() -> int {
-        if (pc) SPRS_TRY(launch_fused<T>(c, n, G, BicgK5<T, true>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()}));
-        else SPRS_TRY(launch_fused<T>(c, n, G, BicgK5<T, false>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()}));
+        if (pc) SPRS_TRY(launch_fused<T>(c, n, G, BicgK5<T, true>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()}, 2));
+        else SPRS_TRY(launch_fused<T>(c, n, G, BicgK5<T, false>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()}, 2));
         return this->redDT(partN, partRho, G, 3, &qN, &qRho);
     };
     auto K1 = [&](int mode) -> int {
