@@ -97,9 +97,17 @@ __device__ __forceinline__ Pack<T, PK> ldp(const T *p, int64_t i) {
         return *reinterpret_cast<const Pack<T, PK> *>(p + i * PK);
     }
 }
-template <class T, int PK>
+template <class T, int PK, bool NT = false>
 __device__ __forceinline__ void stp(T *p, int64_t i, const Pack<T, PK> &v) {
-    *reinterpret_cast<Pack<T, PK> *>(p + i * PK) = v;
+    if constexpr (NT) {
+        constexpr int W = (int)(sizeof(T) * PK / 4);
+        typedef unsigned int uvec __attribute__((ext_vector_type(W)));
+        uvec q;
+        __builtin_memcpy(&q, &v, sizeof(q));
+        __builtin_nontemporal_store(q, reinterpret_cast<uvec *>(p + i * PK));
+    } else {
+        *reinterpret_cast<Pack<T, PK> *>(p + i * PK) = v;
+    }
 }
 
 template <class T> struct pack_width { static constexpr int value = 16 / sizeof(T); };

@@ -50,7 +50,7 @@ struct sprs_ctx {
     int spmv_period = 0;   // f64 pair codes: XCD-period schedule for matrices with a far band (3-D stencils), 1 = on.  Read at creation
     int spmv_triple = -1;  // f64 pair codes, uniform blocks: columns c - 1 and c + 1 read from column c's loads; 0 = off.  Read at creation
     int spmv_seam = -1;    // f64 pair codes: blocks that are uniform but for one or two adjacent rows lacking one slot run the uniform path; 0 = off.  Read at creation
-    int stream_nt = -1;    // fused recurrence kernels read their operands with non-temporal loads: -1 auto (by vector size), 0 / 1
+    int stream_nt = -1;    // fused recurrence kernels access their vectors with non-temporal loads / stores: -1 auto (by vector size), 0 / 1
     int stream_nt_mask = 7; // ... in which of them: bit 0 K1 / MINRES kernels, bit 1 K3, bit 2 K5 (profiles/r02_tuning.md §20)
                            // and at launch.  Off by default: it cuts the SpMV's fabric reads by 58 % (x crosses the fabric once) and the
                            // kernel's time not at all (profiles/r02_tuning.md §7)
@@ -251,12 +251,12 @@ inline int grid_for(const sprs_ctx *c) {
     return g & ~7;
 }
 
-// Non-temporal operand loads for the fused recurrence kernels: knob "stream_nt" (1 / 0), automatic (-1) from the size of
-// one vector — measured cross-over between 50 MB (vectors of a solve live in the 256 MiB Infinity Cache: -4 %) and
-// 100 MB (+9 %).
+// Non-temporal vector accesses (operand loads and result stores) in the fused recurrence kernels: knob "stream_nt"
+// (1 / 0), automatic (-1) from the size of one vector — measured cross-over between 50 MB (the vectors of a solve live
+// in the 256 MiB Infinity Cache: -1.4 %) and 64 MB (+1.2 %; 100-200 MB: +11 %), profiles/r02_tuning.md §20.
 inline bool stream_loads_nt(const sprs_ctx *c, size_t vector_bytes) {
     if (c->stream_nt >= 0) return c->stream_nt != 0;
-    return vector_bytes >= (size_t)72 << 20;
+    return vector_bytes >= (size_t)60 << 20;
 }
 
 // Grid of a grid-stride streaming pass over `work` tiles: no more workgroups than the context's grid, and as few as make

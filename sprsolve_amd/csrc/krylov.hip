@@ -29,9 +29,10 @@ namespace sprs {
 
 
 // ======================================================================= fused kernel skeleton
-// NT: the vector operands are read with non-temporal loads.  At HBM sizes every operand is streamed once per pass and
-// evicted long before its next use; loads that do not allocate on the way leave the caches to the SpMV's gathers and run
-// 5-10 % faster in the mix with stores (profiles/r02_tuning.md §20).  Vectors that live in the Infinity Cache lose with it.
+// NT: the vector operands are read and the results written with non-temporal accesses.  At HBM sizes every vector is
+// streamed once per pass and evicted long before its next use; accesses that do not allocate on the way leave the caches
+// to the SpMV's gathers and run faster in the read/write mix (profiles/r02_tuning.md §20).  Vectors that live in the
+// Infinity Cache lose with it.
 template <int PK, bool NT, class F>
 __global__ __launch_bounds__(BLOCK) void fused_kernel(int64_t n, F f) {
     if (!f.prologue()) return;
@@ -110,8 +111,8 @@ struct BicgK1 {
             pv.v[e] = t;
             if (PC) yv.v[e] = smulv(t, dv.v[e]);                    // :328
         }
-        stp<T, PK>(p, i, pv);
-        if (PC) stp<T, PK>(y, i, yv);
+        stp<T, PK, NT>(p, i, pv);
+        if (PC) stp<T, PK, NT>(y, i, yv);
     }
     __device__ __forceinline__ void epilogue() const {}
 };
@@ -147,8 +148,8 @@ struct BicgK3 {
             rv.v[e] = sadd(rv.v[e], smul(vv.v[e], na));             // :172
             if (PC) zv.v[e] = smulv(rv.v[e], dv.v[e]);              // :343
         }
-        stp<T, PK>(r, i, rv);
-        if (PC) stp<T, PK>(z, i, zv);
+        stp<T, PK, NT>(r, i, rv);
+        if (PC) stp<T, PK, NT>(z, i, zv);
     }
     __device__ __forceinline__ void epilogue() const {}
 };
@@ -189,8 +190,8 @@ struct BicgK5 {
             accN = accN + ssq(rr);
             accR = sadd(accR, smul(sconj(qv.v[e]), rr));
         }
-        stp<T, PK>(x, i, xv);
-        stp<T, PK>(r, i, rv);
+        stp<T, PK, NT>(x, i, xv);
+        stp<T, PK, NT>(r, i, rv);
     }
     __device__ __forceinline__ void epilogue() {
         __shared__ Real<T> smD[NWAVE];
@@ -239,8 +240,8 @@ struct MinresM2 {
                 accD = accD + ssq(t);                               // :120
             }
         }
-        stp<T, PK>(v_new, i, nv);
-        if (PC) stp<T, PK>(w_new, i, wv);
+        stp<T, PK, NT>(v_new, i, nv);
+        if (PC) stp<T, PK, NT>(w_new, i, wv);
     }
     __device__ __forceinline__ void epilogue() {
         __shared__ Real<T> smD[NWAVE];
@@ -313,10 +314,10 @@ struct MinresM3 {
             pv.v[e] = t;
             xv.v[e] = sadd(xv.v[e], smul(t, coef));                 // :162
         }
-        stp<T, PK>(v_new, i, nv);
-        if (PC) stp<T, PK>(w_new, i, wv);
-        stp<T, PK>(p, i, pv);
-        stp<T, PK>(x, i, xv);
+        stp<T, PK, NT>(v_new, i, nv);
+        if (PC) stp<T, PK, NT>(w_new, i, wv);
+        stp<T, PK, NT>(p, i, pv);
+        stp<T, PK, NT>(x, i, xv);
     }
     __device__ __forceinline__ void epilogue() const {
         if (!first_thread()) return;
