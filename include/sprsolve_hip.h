@@ -71,8 +71,9 @@ int sprs_version(void);
  *   "grid"          workgroups of the streaming (BLAS-1 / fused recurrence) kernels, 8..4096, multiple of 8
  *   "spmv_grid"     workgroups of the SpMV kernels (-1: 4 per CU)
  *   "poll"          iterations between two host looks at the device-side status word (>= 1)
- *   "stream_nt"     fused recurrence kernels read and write their vectors with non-temporal accesses: -1 automatic
- *                   (vectors of 60 MB and more), 0 / 1; "stream_nt_mask": in which of them (bit 0 K1, 1 K3, 2 K5)
+ *   "stream_nt"     fused recurrence kernels read and write their vectors, and the pair-code SpMV writes y, with
+ *                   non-temporal accesses: -1 automatic (vectors of 72 MB and more), 0 / 1;
+ *                   "stream_nt_mask": in which of the fused kernels (bit 0 K1, 1 K3, 2 K5)
  *   "xcd_chunk"     1: one contiguous chunk of row blocks per XCD (-1: automatic — cache-resident matrices only)
  *   "spmv_dict"     SpMV stream: -1 auto / 0 plain CSR / 1 offset codes / 2 (offset, value) pair codes
  *                   (sprs_csr_stream_format reports what a handle got)                                   (creation)

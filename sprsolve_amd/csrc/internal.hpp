@@ -251,12 +251,13 @@ inline int grid_for(const sprs_ctx *c) {
     return g & ~7;
 }
 
-// Non-temporal vector accesses (operand loads and result stores) in the fused recurrence kernels: knob "stream_nt"
-// (1 / 0), automatic (-1) from the size of one vector — measured cross-over between 50 MB (the vectors of a solve live
-// in the 256 MiB Infinity Cache: -1.4 %) and 64 MB (+1.2 %; 100-200 MB: +11 %), profiles/r02_tuning.md §20.
+// Non-temporal vector accesses — operand loads and result stores of the fused recurrence kernels, the y stores of the
+// pair-code SpMV: knob "stream_nt" (1 / 0), automatic (-1) from the size of one vector.  Measured cross-over: 64 MB
+// (-0.9 %; at 50 MB the vectors of a solve live in the 256 MiB Infinity Cache: -3 %) to 80 MB (+3.6 %; 100-200 MB: +11 %),
+// profiles/r02_tuning.md §20.
 inline bool stream_loads_nt(const sprs_ctx *c, size_t vector_bytes) {
     if (c->stream_nt >= 0) return c->stream_nt != 0;
-    return vector_bytes >= (size_t)60 << 20;
+    return vector_bytes >= (size_t)72 << 20;
 }
 
 // Grid of a grid-stride streaming pass over `work` tiles: no more workgroups than the context's grid, and as few as make

@@ -618,7 +618,8 @@ struct Blk2Loads {
     int di;                  // ... and the b128 slot they go to
 };
 
-template <int DOT>
+// YNT: y is written with non-temporal stores (HBM-sized vectors: the result is not read again before it has been evicted)
+template <int DOT, bool YNT>
 __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_chunk, const BlkDesc *__restrict__ desc,
                                                            const int32_t *__restrict__ order,
                                                            const int32_t *__restrict__ row_ptr,
@@ -835,7 +836,14 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
         }
         }
         if (r0 + 1 < c_rb) {
-            *reinterpret_cast<D2 *>(reinterpret_cast<char *>(y) + r8) = D2{acc0, acc1};
+            if constexpr (YNT) {
+                const D2 yy{acc0, acc1};
+                u4v q;
+                __builtin_memcpy(&q, &yy, 16);
+                __builtin_nontemporal_store(q, reinterpret_cast<u4v *>(reinterpret_cast<char *>(y) + r8));
+            } else {
+                *reinterpret_cast<D2 *>(reinterpret_cast<char *>(y) + r8) = D2{acc0, acc1};
+            }
             if (DOT == 1) { d0 = d0 + c_u0 * acc0; d0 = d0 + c_u1 * acc1; }
             if (DOT == 2) { d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * c_u0; d0 = d0 + acc1 * acc1; d1 = d1 + acc1 * c_u1; }
         } else if (r0 < c_rb) {
@@ -1143,9 +1151,13 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
             const int gw = g;     // same grid as the 64-row kernel: the consumers reduce exactly spmv_num_partials(A) partials
             const BlkDesc *wd = reinterpret_cast<const BlkDesc *>(D->wide_desc);
             const double *pvd = reinterpret_cast<const double *>(D->pair_val);
-#define SPRS_WSPMV(DM) SPRS_LAUNCH_SPMV(c, (spmv_pair2_kernel<DM>), gw, count_w, xcd_chunk, wd, order_w, \
+#define SPRS_WSPMV(DM, YN) SPRS_LAUNCH_SPMV(c, (spmv_pair2_kernel<DM, YN>), gw, count_w, xcd_chunk, wd, order_w, \
                                           A->row_ptr, D->pair_code, D->pair_off, pvd, x, y, u, part0, part1, status, (int)A->nrows, (int)A->ncols)
-            if (dot_mode == 0) SPRS_WSPMV(0); else if (dot_mode == 1) SPRS_WSPMV(1); else SPRS_WSPMV(2);
+            if (stream_loads_nt(c, (size_t)A->nrows * sizeof(T))) {          // HBM-sized result: non-temporal y stores
+                if (dot_mode == 0) SPRS_WSPMV(0, true); else if (dot_mode == 1) SPRS_WSPMV(1, true); else SPRS_WSPMV(2, true);
+            } else {
+                if (dot_mode == 0) SPRS_WSPMV(0, false); else if (dot_mode == 1) SPRS_WSPMV(1, false); else SPRS_WSPMV(2, false);
+            }
 #undef SPRS_WSPMV
             SPRS_HIP_TRY(c, hipGetLastError());
             return SPRS_OK;
