@@ -864,3 +864,40 @@ def test_randomised_solver_parity_short():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:]
     assert "0 hard mismatches" in p.stdout
+
+
+def test_non_temporal_accesses_are_a_pure_cache_hint(oracle):
+    """Knob stream_nt: at HBM sizes the fused recurrence kernels read and write their vectors, and the pair-code SpMV
+    writes y, with non-temporal accesses (automatic from 72 MB per vector; forced here on small systems so that those
+    kernel instantiations run in the suite).  Same values, same order: iteration counts, residuals, x and y are
+    bit-identical with the hint on and off — BiCGStab plain and Jacobi, MINRES, CSMINRES."""
+    import sprsolve_amd as sa
+    from sprsolve_amd import gen
+    ctx = sa.default_ctx(0)
+    bits = lambda a: np.ascontiguousarray(a).view(np.uint8)
+    ip, ix, d, rhs = gen.poisson3d(150, 12, 9)
+    n = rhs.size
+    sp, sx, sd, srhs = gen.symmetric_banded(20011, hbw=4)
+    cp_, cx_, cd_c, crhs, _ = gen.complex_symmetric_grid(40, 60)   # tests/test_complex_solve2.rs:35-96
+    nc = crhs.size
+    out = {}
+    try:
+        for nt in (0, 1):
+            ctx.set("stream_nt", nt)
+            A = sa.HipCsr.new((n, n), ip, ix, d)
+            xin = np.linspace(-1.0, 1.0, n) ** 3
+            y = np.zeros(n); dot = A.mul_vec_dot(xin, y)
+            s = sa.BiCGStab.new(A, n); x1 = np.zeros(n); r1 = s.solve(rhs, x1, 3000, 1e-10)
+            P = sa.DiagPrecond.new(np.full(n, 6.0)); x2 = np.zeros(n); r2 = s.precond_solve(P, rhs, x2, 3000, 1e-10)
+            B = sa.HipCsr.new((20011, 20011), sp, sx, sd)
+            m = sa.MinRes.new(B, 20011); x3 = np.zeros(20011); r3 = m.solve(srhs, x3, 3000, 1e-10)
+            Cm = sa.HipCsr.new((nc, nc), cp_, cx_, cd_c)
+            cs = sa.CSMinRes.new(Cm, nc); x4 = np.zeros(nc, dtype=np.complex128); r4 = cs.solve(crhs, x4, 5000, 1e-9)
+            out[nt] = (dot, y, r1, x1, r2, x2, r3, x3, r4, x4)
+    finally:
+        ctx.set("stream_nt", -1)
+    a, b = out[0], out[1]
+    assert a[0] == b[0] and a[2] == b[2] and a[4] == b[4] and a[6] == b[6] and a[8] == b[8]
+    for k in (1, 3, 5, 7, 9):
+        assert np.array_equal(bits(a[k]), bits(b[k])), k
+    assert np.array_equal(bits(a[1]), bits(oracle.spmv(ip, ix, d, np.linspace(-1.0, 1.0, n) ** 3)))
