@@ -83,8 +83,9 @@ int sprs_version(void);
  *   "spmv_seam"     ... and so are blocks that are uniform but for one row, or two adjacent ones, holding only
  *                   part of the pattern or one entry of their own (line seams of truncated / Dirichlet grids) (creation)
  *   "spmv_eqrows"   plain CSR: blocks of equal-length rows do not read row_ptr                           (creation)
- *   "spmv_period"   1: XCD-period walk of the compressed streams' blocks for matrices with a far band;
- *                   default 0 (measured: fabric traffic -58 %, time unchanged)                           (creation)
+ *   "spmv_period"   XCD-period walk of the compressed streams' blocks for matrices with a far band (rows r and
+ *                   r +- band on one XCD): -1 automatic = the f64 pair-code stream (cfg 5: SpMV -2.3 %),
+ *                   1 = the offset-code stream too (measured slower), 0 = off                            (creation)
  *   "spmv_nt"       1: non-temporal loads of the plain stream; "spmv_strip": experimental walks of the plain stream
  *   "halo_overlap"  distributed SpMV: 1 (default) multiplies the interior rows while the halo travels
  *   "gs_graph"      1: Gauss-Seidel replays a sweep's level launches from a hipGraph (default 0)

@@ -99,7 +99,7 @@ while time.time() < t_end:
     count += 1
 for k in ("spmv_dict", "spmv_wide", "spmv_uniform", "spmv_eqrows"):
     ctx.set(k, -1)
-ctx.set("spmv_period", 0)
+ctx.set("spmv_period", -1)
 ctx.set("spmv_triple", -1)
 ctx.set("spmv_seam", -1)
 print("fuzz ok: %d matrices, %d (matrix, knob) combinations, all y bit-identical to the reference fold" % (count, combos))

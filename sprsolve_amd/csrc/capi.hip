@@ -108,7 +108,7 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     else if (k == "spmv_dict") { if (value < -1 || value > 2) return SPRS_INVALID_ARGUMENT; c->spmv_dict = (int)value; }
     else if (k == "spmv_wide") c->spmv_wide = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_uniform") c->spmv_uniform = value < 0 ? -1 : (value ? 1 : 0);
-    else if (k == "spmv_period") c->spmv_period = value > 0 ? 1 : 0;
+    else if (k == "spmv_period") c->spmv_period = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_triple") c->spmv_triple = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_seam") c->spmv_seam = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "stream_nt") c->stream_nt = value < 0 ? -1 : (value ? 1 : 0);

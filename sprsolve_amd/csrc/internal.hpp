@@ -47,7 +47,7 @@ struct sprs_ctx {
     int spmv_dict = -1;
     int spmv_wide = -1;   // f64 pair codes: two rows per lane (16-byte gathers); -1 / 1 on, 0 off
     int spmv_eqrows = -1; // plain-CSR stream: blocks of equal-length rows take their extents from the descriptor (no row_ptr read); read at creation
-    int spmv_period = 0;   // f64 pair codes: XCD-period schedule for matrices with a far band (3-D stencils), 1 = on.  Read at creation
+    int spmv_period = -1;  // XCD-period walk for matrices with a far band (3-D stencils): -1 automatic = the f64 pair-code stream only, 1 = the offset-code stream too, 0 = off.  Read at creation
     int spmv_triple = -1;  // f64 pair codes, uniform blocks: columns c - 1 and c + 1 read from column c's loads; 0 = off.  Read at creation
     int spmv_seam = -1;    // f64 pair codes: blocks that are uniform but for one or two adjacent rows lacking one slot run the uniform path; 0 = off.  Read at creation
     int stream_nt = -1;    // fused recurrence kernels access their vectors with non-temporal loads / stores: -1 auto (by vector size), 0 / 1

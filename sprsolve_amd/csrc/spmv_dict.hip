@@ -1075,7 +1075,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
                 int64_t P = 0;
                 for (const auto &o : offs) P = std::max<int64_t>(P, std::llabs((long long)o.first));
                 const int64_t G = P / 8;
-                if (c->spmv_period > 0 && G >= 16 * 128 && P * 4 <= A->nrows && nw >= 8 * NWAVE * 8) {
+                if (c->spmv_period != 0 && G >= 16 * 128 && P * 4 <= A->nrows && nw >= 8 * NWAVE * 8) {      // automatic (-1): on
                     const std::vector<int32_t> ord = xcd_period_order(nw, G, [&](int j) { return (int64_t)wd[(size_t)j].ra; });
                     DICT_TRY2(hipMalloc((void **)&D->wide_order, sizeof(int32_t) * (size_t)nw));
                     DICT_TRY2(hipMemcpyAsync(D->wide_order, ord.data(), sizeof(int32_t) * (size_t)nw, hipMemcpyHostToDevice, c->stream));
@@ -1144,7 +1144,7 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
         // whose split is made on pairs of 64-row blocks for this purpose (dist.hip)
         const int32_t *order_w = nullptr;
         int count_w = -1;
-        if (order == nullptr && count == A->n_rowblk) { count_w = D->n_wide; order_w = c->spmv_period > 0 ? D->wide_order : nullptr; }
+        if (order == nullptr && count == A->n_rowblk) { count_w = D->n_wide; order_w = c->spmv_period != 0 ? D->wide_order : nullptr; }
         else if (A->dist && A->dist->order_int_w && order == A->dist->order_int && count == A->dist->n_int) { order_w = A->dist->order_int_w; count_w = A->dist->n_int_w; }
         else if (A->dist && A->dist->order_bnd_w && order == A->dist->order_bnd && count == A->dist->n_bnd) { order_w = A->dist->order_bnd_w; count_w = A->dist->n_bnd_w; }
         if (pair && D->wide_desc && c->spmv_wide != 0 && count_w >= 0 && A->nrows >= 2 && A->ncols >= 2) {

@@ -627,5 +627,5 @@ def test_xcd_period_schedule_is_a_pure_reordering(sa, oracle):
         assert abs(out[0, 1][0] - out[1, 1][0]) <= max(3, out[0, 1][0] // 10)
         assert out[0, 1] == out[0, 0] and out[1, 1] == out[1, 0]        # the triple shortcut changes timing only
     finally:
-        ctx.set("spmv_period", 0)
+        ctx.set("spmv_period", -1)
         ctx.set("spmv_triple", -1)
