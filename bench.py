@@ -389,14 +389,35 @@ def bench100(args):
                                           "78 KB of matrix: pure launch latency (5 launches per iteration)")
     except Exception as e:     # the CPU line stands on its own
         out["gpu_same_config"] = dict(error=str(e))
-    print(json.dumps(out))
+    emit(json.dumps(out))
 
 
 # ------------------------------------------------------------------------------------------ main
+_JSON_OUT = None
+
+
+def protect_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner on
+    file descriptor 1 when its first communicator is created): from here on descriptor 1 points at stderr and the JSON
+    line goes to a private duplicate of the original stdout."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    out = _JSON_OUT if _JSON_OUT is not None else sys.stdout
+    out.write(line + "\n")
+    out.flush()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    protect_stdout()
     if args.workload == "bench100":
         return bench100(args)
     import torch   # first: libsprsolve_hip.so then shares torch's HIP runtime (same soname)
@@ -643,7 +664,7 @@ def main():
     if also:
         out["also"] = also
     if rank == 0:
-        print(json.dumps(out))
+        emit(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

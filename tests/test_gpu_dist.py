@@ -210,3 +210,25 @@ def test_plan_builder_with_the_real_rccl(env, oracle, exchange):
     with pytest.raises(ValueError):
         sdist.DistCsr.from_global(env["comm"], np.array([0, n], np.int64), int(ip[-1]), torch.from_numpy(ip).to(dev),
                                   torch.from_numpy(bad).to(dev), torch.from_numpy(d).to(dev), exchange=exchange)
+
+
+def test_bench_stdout_is_one_json_line_with_the_real_rccl():
+    """bench.py's contract is ONE JSON line on stdout.  RCCL prints a version banner on file descriptor 1 when its first
+    communicator is created; bench.py points descriptor 1 at stderr for the run and writes its line to a duplicate of
+    the original.  `--force-dist` takes the RCCL path with one rank (the real library, as the driver's N > 1 runs do)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SPRS_RCCL_LIB"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--grid", "64x48x32", "--steps", "6",
+                        "--warmup", "2", "--no-cpu-baseline", "--no-also"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=420)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1, p.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["rccl_ranks"] == 1 and d["converge_check"]["max_abs_err_vs_exact"] < 1e-5
