@@ -75,6 +75,9 @@ int sprs_version(void);
  *                   non-temporal accesses: -1 automatic (vectors of 72 MB and more), 0 / 1;
  *                   "stream_nt_mask": in which of the fused kernels (bit 0 K1, 1 K3, 2 K5)
  *   "xcd_chunk"     1: one contiguous chunk of row blocks per XCD (-1: automatic — cache-resident matrices only)
+ *   "ew_chunk"      fused recurrence kernels walk one contiguous eighth of the vectors per XCD, the eighth whose rows
+ *                   that XCD multiplies: -1 automatic (cache-resident matrices whose far band is at most 1/32 of
+ *                   the rows), 0 / 1
  *   "spmv_dict"     SpMV stream: -1 auto / 0 plain CSR / 1 offset codes / 2 (offset, value) pair codes
  *                   (sprs_csr_stream_format reports what a handle got)                                   (creation)
  *   "spmv_wide"     f64 pair codes: two rows per lane, 128-row blocks (-1 / 1 on, 0 off)

@@ -111,6 +111,7 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     else if (k == "spmv_period") c->spmv_period = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_triple") c->spmv_triple = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_seam") c->spmv_seam = value < 0 ? -1 : (value ? 1 : 0);
+    else if (k == "ew_chunk") c->ew_chunk = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "stream_nt") c->stream_nt = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "stream_nt_mask") c->stream_nt_mask = (int)(value & 7);
     else if (k == "spmv_eqrows") c->spmv_eqrows = value < 0 ? -1 : (value ? 1 : 0);
@@ -134,6 +135,7 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     if (k == "spmv_period") return c->spmv_period;
     if (k == "spmv_triple") return c->spmv_triple;
     if (k == "spmv_seam") return c->spmv_seam;
+    if (k == "ew_chunk") return c->ew_chunk;
     if (k == "stream_nt") return c->stream_nt;
     if (k == "stream_nt_mask") return c->stream_nt_mask;
     if (k == "spmv_eqrows") return c->spmv_eqrows;

@@ -50,6 +50,7 @@ struct sprs_ctx {
     int spmv_period = -1;  // XCD-period walk for matrices with a far band (3-D stencils): -1 automatic = the f64 pair-code stream only, 1 = the offset-code stream too, 0 = off.  Read at creation
     int spmv_triple = -1;  // f64 pair codes, uniform blocks: columns c - 1 and c + 1 read from column c's loads; 0 = off.  Read at creation
     int spmv_seam = -1;    // f64 pair codes: blocks that are uniform but for one or two adjacent rows lacking one slot run the uniform path; 0 = off.  Read at creation
+    int ew_chunk = -1;     // fused recurrence kernels walk one contiguous eighth of the vectors per XCD: -1 automatic (fused_chunked), 0 / 1
     int stream_nt = -1;    // fused recurrence kernels access their vectors with non-temporal loads / stores: -1 auto (by vector size), 0 / 1
     int stream_nt_mask = 7; // ... in which of them: bit 0 K1 / MINRES kernels, bit 1 K3, bit 2 K5 (profiles/r02_tuning.md §20)
                            // and at launch.  Off by default: it cuts the SpMV's fabric reads by 58 % (x crosses the fabric once) and the
@@ -152,6 +153,7 @@ struct sprs_dict {
     int32_t *wide_order = nullptr; // device: XCD-period schedule of the 128-row blocks (null = natural order)
     int32_t *off_order = nullptr;  // device: the same schedule for the 64-row blocks of the offset-code stream
     int64_t period = 0;            // the far band it folds over (rows)
+    int64_t max_off = -1;          // largest |col - row| of the matrix (-1: unknown)
     void *off_desc = nullptr;      // device: copy of blk_desc for the offset-code stream with the uniform blocks flagged (bit 30, nn = row length)
     int n_off_uniform = 0;
 };
@@ -214,6 +216,9 @@ int spmv_subset_grid(const sprs_csr *A, int count);
 int build_dict(sprs_csr *A, bool has_vector_blocks, const std::vector<int32_t> &blk, const int32_t *host_row_ptr);
 void free_dict(sprs_csr *A);
 int dict_mode(const sprs_csr *A);                      // 0 plain, 1 offsets, 2 offsets + values: what launch_spmv will use
+// Should the fused recurrence kernels of a solve on A give every XCD one contiguous eighth of the vectors (spmv.hip)?
+bool fused_chunked(const sprs_csr *A);
+
 template <class T>
 int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int count, int g, int xcd_chunk, const T *x, T *y,
                      int dot_mode, const T *u, T *part0, T *part1, const int *status, bool conj_x);

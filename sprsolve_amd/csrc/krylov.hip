@@ -34,9 +34,18 @@ namespace sprs {
 // to the SpMV's gathers and run faster in the read/write mix (profiles/r02_tuning.md §20).  Vectors that live in the
 // Infinity Cache lose with it.
 template <int PK, bool NT, class F>
-__global__ __launch_bounds__(BLOCK) void fused_kernel(int64_t n, F f) {
+__global__ __launch_bounds__(BLOCK) void fused_kernel(int64_t n, F f, int chunked) {
     if (!f.prologue()) return;
-    SPRS_FOREACH_PACK(n, PK, i) f.template run<PK, NT>(i);
+    if (chunked) {
+        // one contiguous eighth of the vectors per XCD (workgroup id mod 8), the same eighth in every kernel and the one
+        // whose rows that XCD multiplies in the SpMV (xcd_chunk): what a kernel writes is read from the same L2
+        const int64_t np = n / PK, chunk = ((np + 7) / 8 + BLOCK - 1) / BLOCK * BLOCK;
+        const int xcd = blockIdx.x & 7;
+        const int64_t end = min(np, (int64_t)(xcd + 1) * chunk), st = (int64_t)(gridDim.x >> 3) * BLOCK;
+        for (int64_t i = xcd * chunk + (int64_t)(blockIdx.x >> 3) * BLOCK + threadIdx.x; i < end; i += st) f.template run<PK, NT>(i);
+    } else {
+        SPRS_FOREACH_PACK(n, PK, i) f.template run<PK, NT>(i);
+    }
     if (PK > 1) {
         int64_t i = (n / PK) * PK + (int64_t)blockIdx.x * BLOCK + threadIdx.x;
         if (i < n) f.template run<1, NT>(i);
@@ -45,12 +54,13 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(int64_t n, F f) {
 }
 
 template <class T, class F>
-static int launch_fused(sprs_ctx *c, size_t n, int grid, F f, int which = 0) {
+static int launch_fused(sprs_ctx *c, size_t n, int grid, int chunked_walk, F f, int which = 0) {
     constexpr int PKW = pack_width<T>::value;
+    const int chunked = (chunked_walk && grid % 8 == 0 && grid >= 8) ? 1 : 0;
     if (stream_loads_nt(c, n * sizeof(T)) && ((c->stream_nt_mask >> which) & 1))
-        hipLaunchKernelGGL((fused_kernel<PKW, true, F>), dim3(grid), dim3(BLOCK), 0, c->stream, (int64_t)n, f);
+        hipLaunchKernelGGL((fused_kernel<PKW, true, F>), dim3(grid), dim3(BLOCK), 0, c->stream, (int64_t)n, f, chunked);
     else
-        hipLaunchKernelGGL((fused_kernel<PKW, false, F>), dim3(grid), dim3(BLOCK), 0, c->stream, (int64_t)n, f);
+        hipLaunchKernelGGL((fused_kernel<PKW, false, F>), dim3(grid), dim3(BLOCK), 0, c->stream, (int64_t)n, f, chunked);
     SPRS_HIP_TRY(c, hipGetLastError());
     return SPRS_OK;
 }
@@ -598,6 +608,7 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
     const int *d_status = &d_state->status;
 
     const int G = this->ew_grid();
+    const int cw = fused_chunked(this->A) ? 1 : 0;      // XCD-chunked walk of the vector kernels (spmv.hip)
     const int GS = spmv_num_partials(this->A);
     Real<T> *partN = this->dslot(0);
     T *partRho = this->pslot(0), *partB = this->pslot(1), *partTT = this->pslot(2), *partTR = this->pslot(3);
@@ -609,21 +620,21 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
         return this->red1(partB, GS, 0, &qB);
     };
     auto K3 = [&](int check) -> int {
-        if (pc) return launch_fused<T>(c, n, G, BicgK3<T, V, true>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()}, 1);
-        return launch_fused<T>(c, n, G, BicgK3<T, V, false>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()}, 1);
+        if (pc) return launch_fused<T>(c, n, G, cw, BicgK3<T, V, true>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()}, 1);
+        return launch_fused<T>(c, n, G, cw, BicgK3<T, V, false>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()}, 1);
     };
     auto K4 = [&]() -> int {                                                                 // :104/:175 t = A s ; t.t, t.r
         SPRS_TRY(this->spmv(sz, t, 2, r, partTT, partTR, d_status));
         return this->red2(partTT, partTR, GS, 1, &qTT, &qTR);
     };
     auto K5 = [&]() -> int {
-        if (pc) SPRS_TRY(launch_fused<T>(c, n, G, BicgK5<T, true>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()}, 2));
-        else SPRS_TRY(launch_fused<T>(c, n, G, BicgK5<T, false>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()}, 2));
+        if (pc) SPRS_TRY(launch_fused<T>(c, n, G, cw, BicgK5<T, true>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()}, 2));
+        else SPRS_TRY(launch_fused<T>(c, n, G, cw, BicgK5<T, false>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()}, 2));
         return this->redDT(partN, partRho, G, 3, &qN, &qRho);
     };
     auto K1 = [&](int mode) -> int {
-        if (pc) return launch_fused<T>(c, n, G, BicgK1<T, V, true>{d_state, qN.p, qRho.p, qN.P, mode, v, r, p, dinv, y, T(), T()});
-        return launch_fused<T>(c, n, G, BicgK1<T, V, false>{d_state, qN.p, qRho.p, qN.P, mode, v, r, p, dinv, y, T(), T()});
+        if (pc) return launch_fused<T>(c, n, G, cw, BicgK1<T, V, true>{d_state, qN.p, qRho.p, qN.P, mode, v, r, p, dinv, y, T(), T()});
+        return launch_fused<T>(c, n, G, cw, BicgK1<T, V, false>{d_state, qN.p, qRho.p, qN.P, mode, v, r, p, dinv, y, T(), T()});
     };
     auto fetch = [&]() -> int {
         SPRS_HIP_TRY(c, hipMemcpyAsync(&H, d_state, sizeof(H), hipMemcpyDeviceToHost, c->stream));
@@ -885,6 +896,7 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> t
     const int *d_status = &d_state->status;
 
     const int G = this->ew_grid();
+    const int cw = fused_chunked(this->A) ? 1 : 0;      // XCD-chunked walk of the vector kernels (spmv.hip)
     const int GS = spmv_num_partials(this->A);
     T *partAlpha = this->pslot(0), *partBeta2 = this->pslot(1);
     Real<T> *partBeta = this->dslot(0);
@@ -911,15 +923,15 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> t
             typename KrylovBase<T>::PartD qBt{partBeta, G};
             SPRS_TRY(this->red1(partAlpha, GS, 0, &qA));
             if (pc) {
-                SPRS_TRY(launch_fused<T>(c, n, G, MinresM2<T, V, true>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, T(), T(), 0.0, T()}));
+                SPRS_TRY(launch_fused<T>(c, n, G, cw, MinresM2<T, V, true>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, T(), T(), 0.0, T()}));
                 SPRS_TRY(this->red1(partBeta2, G, 1, &qB2));
             } else {
-                SPRS_TRY(launch_fused<T>(c, n, G, MinresM2<T, V, false>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, T(), T(), 0.0, T()}));
+                SPRS_TRY(launch_fused<T>(c, n, G, cw, MinresM2<T, V, false>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, T(), T(), 0.0, T()}));
                 SPRS_TRY(this->redD1(partBeta, G, 1, &qBt));
             }
             { T *tp = p_oold; p_oold = p_old; p_old = p; p = tp; }           // :151-154
 #define SPRS_M3(PCF, SAF)                                                                                        \
-    launch_fused<T>(c, n, G, MinresM3<T, PCF, SAF>{d_state, par, (long long)its, qBt.p, qB2.p, pc ? qB2.P : qBt.P, v_new,  \
+    launch_fused<T>(c, n, G, cw, MinresM3<T, PCF, SAF>{d_state, par, (long long)its, qBt.p, qB2.p, pc ? qB2.P : qBt.P, v_new,  \
                                                    w_new, q, p_old, p_oold, p, x, 0.0, 0.0, 0.0, 0.0, T(), T(),  \
                                                    T(), T()})
             if (pc) SPRS_TRY(SPRS_M3(true, false));

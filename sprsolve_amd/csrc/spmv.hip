@@ -407,6 +407,18 @@ static inline int grid_for_blocks(const sprs_csr *A, int count) {
 static inline int spmv_grid(const sprs_csr *A) { return grid_for_blocks(A, A->n_rowblk); }
 int spmv_subset_grid(const sprs_csr *A, int count) { return grid_for_blocks(A, count); }
 
+// The fused recurrence kernels deal their tiles round-robin over the workgroups, i.e. over the XCDs.  Where the SpMV
+// gives every XCD one contiguous eighth of the rows (cache-resident matrices, xcd_chunk) and nearly all of a row's columns
+// lie inside that eighth (far band <= 1/4 of it), the vector kernels take the same eighths: what K1 writes is gathered by
+// the SpMV from the same XCD's L2 instead of crossing the fabric (cfg 2: +4.5 %, cfg 3 / 4: +1-2 %; a 500x500x4 grid,
+// whose plane neighbours live two XCDs away, loses 6 % with it — profiles/r02_tuning.md §22).
+bool fused_chunked(const sprs_csr *A) {
+    const sprs_ctx *c = A->ctx;
+    if (c->ew_chunk >= 0) return c->ew_chunk != 0;
+    if (A->dist || A->blk_order || c->xcd_chunk == 0 || !is_cache_resident(A)) return false;
+    return A->dict && A->dict->max_off >= 0 && A->dict->max_off * 32 <= (int64_t)A->nrows;
+}
+
 template <class T>
 static int launch_spmv_impl(const sprs_csr *A, const int32_t *order, int count, int g, const T *x, T *y, int dot_mode,
                             const T *u, T *part0, T *part1, const int *status, bool conj_x) {

@@ -975,6 +975,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
         DICT_TRY2(hipMemsetAsync(val_code, 0, nb, c->stream));
     }
     D->n_off = (int)offs.size(); D->n_val = use_vals ? (int)vals.size() : 0;
+    for (const auto &o : offs) D->max_off = std::max<int64_t>(D->max_off, std::llabs((long long)o.first));
     int *bad = counts + 3;
     if (use_vals)
         hipLaunchKernelGGL((dict_encode_kernel<T, VALS>), dim3(g), dim3(BLOCK), 0, c->stream, n, A->row_ptr, A->col_idx, val, off_h,
