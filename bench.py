@@ -25,12 +25,19 @@ Workload (config.workload):
   * `--workload bench100`: BASELINE cfg 1, the reference's own bench (benches/bicgstab.rs:14-37):
     CPU restatement at 4 threads and all cores, fixed iteration count; the GPU number beside it if a GPU is there.
 
-roofline (every fraction is <= 1 by construction): `achieved` = the bytes the TIMED kernel's stream has to move
-(`format_bytes_per_launch`: x and y once, row_ptr, and what the stream stores per nnz) / its mean launch time,
-HIP events on the solver's stream inside the timed solve.  SURVEY §8d's CSR formula nnz*12 + (n+1)*4 + 2*n*8 applies
-to the plain-CSR kernel only and is reported for that kernel (`roofline_plain_csr`, measured in the same run on the
-same matrix); for a compressed stream the same time against the CSR bytes is `csr_equivalent_GBs` — a speed-up
-figure, not a roofline fraction.
+roofline: `achieved` = the bytes the TIMED kernel reads and writes per launch / its mean launch time (HIP events on the
+solver's stream inside the timed solve; rocprofv3's per-kernel averages agree, profiles/).  "Reads and writes" is literal
+(`bytes_moved_per_launch`): x and y once, the dot operand where it is not the input vector (K2's r0), the stream's
+per-nnz bytes, and row_ptr / code bytes ONLY of the blocks that read them (uniform blocks of the compressed streams and
+equal-length blocks of the plain stream take their extents from the descriptor).  The format's size
+(`format_bytes_per_launch`) and SURVEY §8d's CSR formula (`csr_equivalent_GBs`, a speed-up figure) are named extras,
+never the fraction.  BASELINE's "CSR SpMV GB/s (% HBM roofline)" is the plain-CSR kernel's line: `roofline_plain_csr`
+(and the top-level `roofline` under `--stream csr`).
+
+Timing: W untimed warm-up iterations, then EXACTLY K timed ones between barrier + device synchronisation (max over ranks):
+`timed_region`.  With K < 100 that region is mostly the solve's set-up (one SpMV, one axpy, two norms, the unrolled first
+iteration), so a second region of K_hi = K + 100 iterations is timed the same way and `ms_per_step` / `value` are the
+MARGINAL rate (K_hi - K) / (T(K_hi) - T(K)); both regions are in the line.
 """
 import argparse
 import json
@@ -115,54 +122,76 @@ def spmv_bytes(n, nnz, s):
 
 
 def stream_info(A, n, nnz, s):
-    """What the SpMV of handle A actually streams (csrc/spmv_dict.hip) and the bytes that format needs per launch
-    (x and y counted once, like spmv_bytes): plain CSR nnz*(s+4); offset codes nnz*(s+1); pair codes nnz*1."""
+    """What the SpMV of handle A streams (csrc/spmv.hip, csrc/spmv_dict.hip): the format's size per launch (x and y
+    counted once, like spmv_bytes: plain CSR nnz*(s+4); offset codes nnz*(s+1); pair codes nnz*1, + row_ptr) and the
+    bytes a launch actually READS AND WRITES (`bytes_moved_per_launch`, the dot operand excluded — roofline_of adds it):
+    blocks that take their row extents / code pattern from the descriptor read neither row_ptr nor code bytes."""
     mode, n_off, n_pair = A.stream_format()
     per_nnz = {0: s + 4, 1: s + 1, 2: 1}[mode]
-    info = dict(stream=STREAM_NAMES[mode], mode=mode, distinct_offsets=n_off, distinct_pairs=n_pair,
-                bytes_per_nnz=per_nnz, format_bytes_per_launch=nnz * per_nnz + (n + 1) * 4 + 2 * n * s)
-    if mode != 0:
-        # uniform blocks (all rows repeat one code sequence) are multiplied without their code bytes and without row_ptr:
-        # what the kernel has to READ is less than the format's size (blocks are equal-sized to within the last one)
-        nb, nu = A.wide_blocks()
-        uf = nu / nb if nb else 0.0
-        info.update(row_blocks=nb, uniform_blocks=nu,
-                    compulsory_bytes_per_launch=int(nnz * (per_nnz - 1) + (1.0 - uf) * (nnz + (n + 1) * 4) + 2 * n * s))
-    return info
+    nb, nu = A.wide_blocks()          # blocks the kernel walks / blocks that read no row_ptr (and no code bytes)
+    uf = nu / nb if nb else 0.0
+    code_b = 0 if mode == 0 else 1
+    moved = int(nnz * (per_nnz - code_b) + (1.0 - uf) * (nnz * code_b + (n + 1) * 4) + 2 * n * s)
+    return dict(stream=STREAM_NAMES[mode], mode=mode, distinct_offsets=n_off, distinct_pairs=n_pair,
+                bytes_per_nnz=per_nnz, format_bytes_per_launch=nnz * per_nnz + (n + 1) * 4 + 2 * n * s,
+                row_blocks=nb, descriptor_only_blocks=nu, bytes_moved_per_launch=moved)
 
 
-def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8):
-    """The roofline object of one measured SpMV kernel: fraction of the HBM peak on the bytes ITS stream must move."""
-    fb = sinfo["format_bytes_per_launch"]
-    r = dict(bound="hbm", kernel=KERNEL_NAMES[sinfo["mode"]], achieved=fb / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-             frac=fb / t_spmv / 1e9 / HBM_PEAK_GBS, traffic=None, stream=sinfo["stream"], bytes_per_nnz=sinfo["bytes_per_nnz"],
-             format_bytes_per_launch=fb, algorithmic_bytes_per_launch=fb, avg_launch_us=t_spmv * 1e6, launches=launches)
-    if "compulsory_bytes_per_launch" in sinfo:
-        r["compulsory_bytes_per_launch"] = sinfo["compulsory_bytes_per_launch"]
-        r["frac_compulsory"] = sinfo["compulsory_bytes_per_launch"] / t_spmv / 1e9 / HBM_PEAK_GBS
-        r["compulsory_note"] = ("format bytes minus the code bytes and row_ptr of the uniform blocks (%d of %d), which the kernel "
-                                "does not read" % (sinfo["uniform_blocks"], sinfo["row_blocks"]))
+def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8, dot_launches=0):
+    """The roofline object of one measured SpMV kernel: fraction of the HBM peak on the bytes it READS AND WRITES.
+    dot_launches: how many of the `launches` read a dot operand that is not their input vector (n*s bytes each)."""
+    moved = sinfo["bytes_moved_per_launch"] + (n * s * dot_launches / launches if launches else 0.0)
+    r = dict(bound="hbm", kernel=KERNEL_NAMES[sinfo["mode"]], achieved=moved / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+             frac=moved / t_spmv / 1e9 / HBM_PEAK_GBS, traffic=None, stream=sinfo["stream"], bytes_per_nnz=sinfo["bytes_per_nnz"],
+             algorithmic_bytes_per_launch=moved, bytes_moved_per_launch=moved,
+             bytes_note=("mean over the %d timed launches of what a launch reads and writes: x, y, the stream (%d B/nnz), row_ptr%s of the "
+                         "%d of %d blocks that read them, and the dot operand of the %d launches whose operand is not their input "
+                         "vector" % (launches, sinfo["bytes_per_nnz"], " and code bytes" if sinfo["mode"] else "",
+                                     sinfo["row_blocks"] - sinfo["descriptor_only_blocks"], sinfo["row_blocks"], dot_launches)),
+             format_bytes_per_launch=sinfo["format_bytes_per_launch"],
+             frac_format_bytes=sinfo["format_bytes_per_launch"] / t_spmv / 1e9 / HBM_PEAK_GBS,
+             avg_launch_us=t_spmv * 1e6, launches=launches)
     if sinfo["mode"] != 0:
+        r["frac_format_bytes_note"] = "the format's size / time: counts code bytes and row_ptr the kernel does not read; NOT the roofline fraction"
         r["csr_equivalent_GBs"] = spmv_bytes(n, nnz, s) / t_spmv / 1e9
         r["csr_equivalent_note"] = ("the same launch time against SURVEY §8d's CSR bytes nnz*12 + (n+1)*4 + 2*n*8: what a plain-CSR "
                                     "kernel would have to sustain to be as fast; a speed-up figure, NOT a roofline fraction "
                                     "(the stream is lossless, y bit-identical; the plain-CSR kernel's own fraction is roofline_plain_csr)")
+    else:
+        r["survey_8d_bytes"] = spmv_bytes(n, nnz, s)
+        r["frac_survey_8d"] = spmv_bytes(n, nnz, s) / t_spmv / 1e9 / HBM_PEAK_GBS
     return r
+
+
+def csrc_digest():
+    """sha256 over the kernel sources: a PMC summary taken with other sources is stale (there is no .git on the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "sprsolve_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode()); h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(key):
     """HBM-side bytes per SpMV launch from the committed rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE passes
-    of this bench command, gfx950 x2 FETCH correction) — measured off-line, so it goes stale when the kernel changes:
-    the file records the commit it was taken at."""
-    for name in ("r02_pmc_summary.json",):
+    of this bench command, gfx950 x2 FETCH correction) — measured off-line, so it goes stale when the kernels change:
+    the summary records the digest of csrc/ it was taken with, and the note says whether that is still the code running."""
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
                 ent = json.load(f).get(key, {})
             pm = ent.get("spmv_in_solve")
             if pm:
-                return pm["traffic_bytes"], "profiles/%s[%s] (taken at commit %s): %s" % (name, key, ent.get("commit"), pm["note"])
-    return None, "no PMC summary found"
+                dig = ent.get("csrc_digest")
+                stale = dig != csrc_digest()
+                return pm["traffic_bytes"], ("profiles/%s[%s] (commit %s, csrc digest %s; %s): %s"
+                                             % (name, key, ent.get("commit"), dig,
+                                                "STALE — csrc/ has changed since" if stale else "current sources", pm["note"])), stale
+    return None, "no PMC summary found", None
 
 
 def stream_ceiling(torch, ctx, n, reps=20):
@@ -235,6 +264,38 @@ def time_solve(torch, dist, solver, precond, rhs, x, steps, warmup, world, profi
     prof = solver.profile()
     solver.set_profile(False)
     return dt, prof
+
+
+def time_marginal(torch, dist, solver, precond, rhs, x, steps, warmup, world, profile=True):
+    """The contract's region (W warm-up, exactly K timed iterations) and, when K < 100, a second region of K + 100
+    iterations: ms per step from the marginal rate, so that the solve's set-up (an SpMV, an axpy, two blocking norms, the
+    unrolled first iteration) does not pass for iteration time.  Returns (ms_per_step, seconds of the K-step region,
+    SpMV profile of the longest region, timing record for the JSON line)."""
+    dt, prof = time_solve(torch, dist, solver, precond, rhs, x, steps, warmup, world, profile)
+    rec = dict(timed_region=dict(steps=steps, seconds=dt, ms_per_step_with_setup=dt / steps * 1e3), ms_per_step_from="timed_region")
+    ms = dt / steps * 1e3
+    if steps < 100:
+        k_hi = steps + 100
+        dt_hi, prof_hi = time_solve(torch, dist, solver, precond, rhs, x, k_hi, 0, world, profile)
+        rec["second_region"] = dict(steps=k_hi, seconds=dt_hi, ms_per_step_with_setup=dt_hi / k_hi * 1e3)
+        if dt_hi > dt:
+            ms = (dt_hi - dt) / (k_hi - steps) * 1e3
+            rec["ms_per_step_from"] = "marginal: (T(%d) - T(%d)) / %d iterations" % (k_hi, steps, k_hi - steps)
+        else:
+            ms = dt_hi / k_hi * 1e3
+            rec["ms_per_step_from"] = "second_region (the marginal difference was not positive)"
+        prof = prof_hi
+    return ms, dt, prof, rec
+
+
+def timed_create(torch, make):
+    """Handle creation (row blocks, dictionary collection + encoding, uniform / seam marking, schedules): wall time of the
+    blocking call with the device idle before and after."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    A = make()
+    torch.cuda.synchronize()
+    return A, (time.perf_counter() - t0) * 1e3
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
@@ -456,12 +517,12 @@ def main():
         R = 1000
         ip, ix, dv, rhs, diag = gen_torch.grid_laplacian_dirichlet(R, R, device=dev)
         n, nnz = R * R, int(ip[-1].item())
-        A = sa.HipCsr.from_device((n, n), nnz, ip, ix, dv, adopt=True, ctx=ctx)
+        A, create_ms = timed_create(torch, lambda: sa.HipCsr.from_device((n, n), nnz, ip, ix, dv, adopt=True, ctx=ctx))
         P = sa.DiagPrecond.new(diag.cpu().numpy(), ctx=ctx)
         s = sa.BiCGStab.new(A, n)
         x = torch.zeros(n, dtype=torch.float64, device=dev)
-        dt, _ = time_solve(torch, dist, s, P, rhs, x, steps, warmup, 1, profile=False)
-        _, prof = time_solve(torch, dist, s, P, rhs, x, steps, 0, 1, profile=True)    # separate pass: per-launch SpMV time
+        ms, dt, _, trec = time_marginal(torch, dist, s, P, rhs, x, steps, warmup, 1, profile=False)
+        _, prof = time_solve(torch, dist, s, P, rhs, x, max(steps, 100), 0, 1, profile=True)    # separate pass: per-launch SpMV time
         # correctness of the same objects: converge to the known solution i+j
         x.zero_()
         its, res = s.precond_solve(P, rhs, x, 20000, 1e-8)
@@ -482,12 +543,12 @@ def main():
         ms_alone = A.time_mul_vec(rhs, y, reps=200)
         t_spmv = prof["spmv_ms_total"] / max(prof["spmv_launches"], 1) * 1e-3
         return dict(workload="cfg2: 1000x1000 2-D 5-point Poisson (Dirichlet rows), n=1e6, nnz=4984016, BiCGStab + Jacobi",
-                    value=steps / dt, ms_per_step=dt / steps * 1e3, n=n, nnz=nnz, spmv_stream=sinfo["stream"],
+                    value=1e3 / ms, ms_per_step=ms, timing=trec, create_ms=create_ms, n=n, nnz=nnz, spmv_stream=sinfo["stream"],
                     pcie_inclusive_it_s=steps / pcie_dt,
                     spmv_us_in_solve=t_spmv * 1e6, spmv_us_back_to_back=ms_alone * 1e3,
                     spmv_csr_equivalent_GBs_in_solve=bs / t_spmv / 1e9, spmv_csr_equivalent_GBs_back_to_back=bs / (ms_alone * 1e-3) / 1e9,
                     spmv_bytes=bs, iter_bytes_reference_oplist=2 * bs + 26 * n * 8 + 2 * n * 24,
-                    effective_GBs=(2 * bs + 26 * n * 8 + 2 * n * 24) * steps / dt / 1e9,
+                    effective_GBs=(2 * bs + 26 * n * 8 + 2 * n * 24) / (ms * 1e-3) / 1e9,
                     converge_check=dict(tol=1e-8, iters=its, rel_res=res, max_abs_err_vs_exact=err),
                     note="working set (~140 MB) fits the 256 MiB Infinity Cache: GB/s here is not an HBM figure"), t_spmv, bs, sinfo, prof
 
@@ -501,11 +562,12 @@ def main():
             if rank == 0 and not args.no_cpu_baseline:
                 # host copy for the CPU leg, taken before the arrays are adopted (the baseline runs last)
                 cpu_arrays = (ip.cpu().numpy(), ix.cpu().numpy(), dv.cpu().numpy(), rhs.cpu().numpy())
-            A = sa.HipCsr.from_device((n, n), nnz, ip, ix, dv, adopt=True, ctx=ctx)
+            A, create_ms = timed_create(torch, lambda: sa.HipCsr.from_device((n, n), nnz, ip, ix, dv, adopt=True, ctx=ctx))
             s = sa.BiCGStab.new(A, n)
             x = torch.zeros(n, dtype=torch.float64, device=dev)
-            dt, prof = time_solve(torch, dist, s, None, rhs, x, args.steps, args.warmup, 1)
+            ms_step, dt, prof, trec = time_marginal(torch, dist, s, None, rhs, x, args.steps, args.warmup, 1)
             t_spmv = prof["spmv_ms_total"] / max(prof["spmv_launches"], 1) * 1e-3
+            dot_l = (prof["spmv_launches"] - 1) // 2          # K2 reads r0 beside its input; K4's operand is its input; the set-up SpMV has none
             bs = spmv_bytes(n, nnz, 8)
             # correctness on the very same objects: the exact solution is all ones
             x.zero_()
@@ -521,74 +583,81 @@ def main():
                 k_csr = max(args.steps // 2, 10)
                 if sinfo["mode"] != 0:
                     ctx.set("spmv_dict", 0)
-                    t_csr, p_csr = time_solve(torch, dist, s, None, rhs, x, k_csr, min(args.warmup, 5), 1)
+                    ms_csr, t_csr, p_csr, trec_csr = time_marginal(torch, dist, s, None, rhs, x, k_csr, min(args.warmup, 5), 1)
+                    csr_info = stream_info(A, n, nnz, 8)         # under the knob: the plain stream's blocks
                     ctx.set("spmv_dict", STREAM_KNOB[args.stream])
                 else:
-                    t_csr, p_csr, k_csr = dt, prof, args.steps
+                    ms_csr, t_csr, p_csr, trec_csr, k_csr, csr_info = ms_step, dt, prof, trec, args.steps, sinfo
                 tl = p_csr["spmv_ms_total"] / max(p_csr["spmv_launches"], 1) * 1e-3
-                csr_info = dict(stream="csr", mode=0, bytes_per_nnz=12, format_bytes_per_launch=bs)
-                roof_csr = roofline_of(csr_info, tl, p_csr["spmv_launches"], n, nnz)
-                roof_csr["traffic"], roof_csr["traffic_note"] = pmc_traffic("cfg5_csr")
+                roof_csr = roofline_of(csr_info, tl, p_csr["spmv_launches"], n, nnz, 8, (p_csr["spmv_launches"] - 1) // 2)
+                roof_csr["traffic"], roof_csr["traffic_note"], roof_csr["traffic_stale"] = pmc_traffic("cfg5_csr")
                 if roof_csr["traffic"]:
-                    roof_csr["traffic_over_algorithmic"] = roof_csr["traffic"] / bs
+                    roof_csr["traffic_over_bytes_moved"] = roof_csr["traffic"] / roof_csr["bytes_moved_per_launch"]
                 also["cfg5_plain_csr_stream"] = dict(
-                    value=k_csr / t_csr, unit="iterations/s", ms_per_step=t_csr / k_csr * 1e3, steps=k_csr,
-                    spmv_us_in_solve=tl * 1e6, spmv_GBs=bs / tl / 1e9, spmv_frac_of_hbm_peak=bs / tl / 1e9 / HBM_PEAK_GBS,
-                    note="spmv_kernel<double> on (col_idx, val); same matrix, same vectors, same iterates")
+                    value=1e3 / ms_csr, unit="iterations/s", ms_per_step=ms_csr, steps=k_csr, timing=trec_csr,
+                    spmv_us_in_solve=tl * 1e6, spmv_GBs=roof_csr["achieved"], spmv_frac_of_hbm_peak=roof_csr["frac"],
+                    spmv_frac_survey_8d=roof_csr["frac_survey_8d"],
+                    note="spmv_kernel<double> on (col_idx, val); same matrix, same vectors, same iterates; the fraction is on the bytes "
+                         "the launches read and write (roofline_plain_csr.bytes_note), SURVEY §8d's formula beside it")
             if not args.no_also and args.values == "poisson":
                 # variable coefficients on the same pattern: no value dictionary => one-byte offset codes + values, 9 B/nnz
                 del s, A
                 x = None
                 torch.cuda.empty_cache()
                 ipr, ixr, dvr, rhsr = gen_torch.poisson3d(nx, ny, nz, device=dev, values="random")
-                Ar = sa.HipCsr.from_device((n, n), nnz, ipr, ixr, dvr, adopt=True, ctx=ctx)
+                Ar, create_ms_r = timed_create(torch, lambda: sa.HipCsr.from_device((n, n), nnz, ipr, ixr, dvr, adopt=True, ctx=ctx))
                 sr = sa.BiCGStab.new(Ar, n)
                 xr = torch.zeros(n, dtype=torch.float64, device=dev)
                 k_r = max(args.steps // 2, 10)
-                t_r, p_r = time_solve(torch, dist, sr, None, rhsr, xr, k_r, min(args.warmup, 5), 1)
+                ms_r, t_r, p_r, trec_r = time_marginal(torch, dist, sr, None, rhsr, xr, k_r, min(args.warmup, 5), 1)
                 tlr = p_r["spmv_ms_total"] / max(p_r["spmv_launches"], 1) * 1e-3
                 sinfo_r = stream_info(Ar, n, nnz, 8)
                 xr.zero_()
                 its_r, res_r = sr.solve(rhsr, xr, 5000, 1e-8)
                 err_r = float((xr - 1.0).abs().max().item())
-                rr = roofline_of(sinfo_r, tlr, p_r["spmv_launches"], n, nnz)
+                rr = roofline_of(sinfo_r, tlr, p_r["spmv_launches"], n, nnz, 8, (p_r["spmv_launches"] - 1) // 2)
                 if (nx, ny, nz) == (500, 500, 200) and sinfo_r["mode"] == 1:
-                    rr["traffic"], rr["traffic_note"] = pmc_traffic("cfg5_random")
+                    rr["traffic"], rr["traffic_note"], rr["traffic_stale"] = pmc_traffic("cfg5_random")
                 also["cfg5_random_values"] = dict(
                     workload="the cfg-5 pattern (500x500x200 7-point) with off-diagonals U(-1,1) and diagonal 1 + sum|row off-diagonals| "
                              "(splitmix64 by nnz position), rhs = A*1, BiCGStab tol=0 fixed %d iterations" % k_r,
-                    value=k_r / t_r, unit="iterations/s", ms_per_step=t_r / k_r * 1e3, steps=k_r, spmv_stream=sinfo_r,
-                    roofline=rr, converge_check=dict(tol=1e-8, iters=its_r, rel_res=res_r, max_abs_err_vs_exact=err_r))
+                    value=1e3 / ms_r, unit="iterations/s", ms_per_step=ms_r, steps=k_r, timing=trec_r, create_ms=create_ms_r,
+                    spmv_stream=sinfo_r, roofline=rr,
+                    converge_check=dict(tol=1e-8, iters=its_r, rel_res=res_r, max_abs_err_vs_exact=err_r))
                 del sr, Ar, xr, ipr, ixr, dvr, rhsr
                 torch.cuda.empty_cache()
         else:
             from sprsolve_amd import dist as sdist
-            res_ = sdist.bench_poisson3d(torch, dist, ctx, rank, world, nx, ny, nz, args.steps, args.warmup, time_solve,
+            res_ = sdist.bench_poisson3d(torch, dist, ctx, rank, world, nx, ny, nz, args.steps, args.warmup, time_marginal,
                                          exchange=args.exchange)
             dt, prof, t_spmv, bs, check, n_glob, nnz_glob, sinfo = res_[:8]
             dist_info = res_[8] if len(res_) > 8 else {}
+            ms_step, trec, create_ms = dist_info.pop("ms_per_step"), dist_info.pop("timing"), dist_info.pop("create_ms")
+            dot_l = (prof["spmv_launches"] - 1) // 2
             roof_csr = None
         it_bytes = 2 * spmv_bytes(n_glob, nnz_glob, 8) + 26 * n_glob * 8
         n_rank = sinfo.get("rows", n_glob)
         nnz_rank = sinfo.get("nnz", nnz_glob)
-        roof = roofline_of(sinfo, t_spmv, prof["spmv_launches"], n_rank, nnz_rank)
-        if world == 1 and (nx, ny, nz) == (500, 500, 200):
-            roof["traffic"], roof["traffic_note"] = pmc_traffic({0: "cfg5_csr", 1: "cfg5_random", 2: "cfg5_pair"}[sinfo["mode"]])
-        roof["note"] = ("per rank; `achieved` / `frac` = the bytes this kernel's stream must move (x, y once; row_ptr; %d B per nnz) / mean "
-                        "launch time (HIP events on the solver's stream, inside the timed solve)" % sinfo["bytes_per_nnz"]
-                        + ("; the kernel is bound by the CUs' vector-memory issue and gather latency, not by HBM (DESIGN.md §3)" if sinfo["mode"] == 2 else "")
+        roof = roofline_of(sinfo, t_spmv, prof["spmv_launches"], n_rank, nnz_rank, 8, dot_l)
+        if world == 1 and (nx, ny, nz) == (500, 500, 200) and not args.force_dist:
+            key = {0: "cfg5_csr", 1: "cfg5_random", 2: "cfg5_pair"}[sinfo["mode"]]
+            roof["traffic"], roof["traffic_note"], roof["traffic_stale"] = pmc_traffic(key)
+        roof["note"] = ("per rank; `achieved` / `frac` = the bytes a launch reads and writes (bytes_note) / mean launch time (HIP events on the "
+                        "solver's stream, inside the timed solve)"
+                        + ("; this kernel is bound by the CUs' vector-memory path and gather latency, not by HBM (DESIGN.md §3): its fraction says "
+                           "how little of the HBM bandwidth it needs, BASELINE's CSR figure is roofline_plain_csr" if sinfo["mode"] == 2 else "")
                         + ("; N>1: the bracketed time includes the wait for the halo exchange of the boundary rows" if world > 1 else ""))
         out = dict(metric="BiCGStab iterations/s (f64, 50M-row 7-point 3-D Poisson) + CSR SpMV GB/s vs HBM roofline",
-                   value=args.steps / dt, unit="iterations/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None,
-                   dtype="f64", data="synthetic",
+                   value=1e3 / ms_step, unit="iterations/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=ms_step, higher_is_better=True, scaling="strong", vs_baseline=None,
+                   dtype="f64", data="synthetic", timing=trec, create_ms=create_ms,
                    config=dict(workload="cfg5: %dx%dx%d 7-point 3-D Poisson%s, n=%d, nnz=%d, BiCGStab (no preconditioner), "
                                         "tol=0 fixed %d iterations" % (nx, ny, nz, " (random values)" if args.values == "random" else "",
                                                                        n_glob, nnz_glob, args.steps),
                                rows=n_glob, nnz=nnz_glob, index_type="i32", partition="z-slabs x%d" % world,
                                spmv_stream=sinfo,
                                bytes_per_iteration_reference_oplist=it_bytes),
-                   effective_GBs_reference_oplist=it_bytes * args.steps / dt / 1e9,
+                   effective_GBs_reference_oplist=it_bytes / (ms_step * 1e-3) / 1e9,
                    roofline=roof, converge_check=check)
         if roof_csr is not None:
             out["roofline_plain_csr"] = roof_csr
@@ -615,12 +684,12 @@ def main():
         if world != 1:
             raise SystemExit("poisson2d is a single-GPU workload (cfg 2)")
         r2, t_spmv, bs, sinfo, prof = bench_poisson2d(args.steps, args.warmup)
-        roof = roofline_of(sinfo, t_spmv, prof["spmv_launches"], 10**6, r2["nnz"])
+        roof = roofline_of(sinfo, t_spmv, prof["spmv_launches"], 10**6, r2["nnz"], 8, prof["spmv_launches"] - 1)   # Jacobi: both operands differ from the inputs
         roof["note"] = "cache-resident working set (fits the 256 MiB Infinity Cache): not an HBM figure; see detail.note"
         out = dict(metric="BiCGStab iterations/s (f64, 1M-row 2-D Poisson + Jacobi) + CSR SpMV GB/s",
                    value=r2["value"], unit="iterations/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
                    ms_per_step=r2["ms_per_step"], higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64",
-                   data="synthetic", config=dict(workload=r2["workload"]), roofline=roof, detail=r2)
+                   data="synthetic", config=dict(workload=r2["workload"]), timing=r2["timing"], create_ms=r2["create_ms"], roofline=roof, detail=r2)
         if not args.no_cpu_baseline:
             from oracle import oracle as orc
             from sprsolve_amd import gen
@@ -640,21 +709,21 @@ def main():
             ip, ix, dv, rhs, _ = gen.complex_symmetric_grid(500, 1000)
             n = 500000
             solver_cls, label, sbytes, ofn = sa.CSMinRes, "cfg4: complex-symmetric 500x1000 grid, n=5e5, nnz=2497000, CSMINRES", 16, orc.csminres
-        A = sa.HipCsr.new((n, n), ip, ix, dv, ctx=ctx)
+        A, create_ms = timed_create(torch, lambda: sa.HipCsr.new((n, n), ip, ix, dv, ctx=ctx))    # includes the H2D copy of the arrays
         s = solver_cls.new(A, n)
         tdt = torch.float64 if sbytes == 8 else torch.complex128
         drhs = torch.from_numpy(rhs).to(dev)
         x = torch.zeros(n, dtype=tdt, device=dev)
-        dt, prof = time_solve(torch, dist, s, None, drhs, x, args.steps, args.warmup, 1)
+        ms_step, dt, prof, trec = time_marginal(torch, dist, s, None, drhs, x, args.steps, args.warmup, 1)
         t_spmv = prof["spmv_ms_total"] / max(prof["spmv_launches"], 1) * 1e-3
         sinfo = stream_info(A, n, int(ip[-1]), sbytes)
-        roof = roofline_of(sinfo, t_spmv, prof["spmv_launches"], n, int(ip[-1]), sbytes)
+        roof = roofline_of(sinfo, t_spmv, prof["spmv_launches"], n, int(ip[-1]), sbytes, 0)    # the Lanczos dot operand IS the input vector
         roof["kernel"] = roof["kernel"].replace("double", "double" if sbytes == 8 else "cplx")
         roof["note"] = "cache-resident working set (fits the 256 MiB Infinity Cache): the fraction is against the HBM peak all the same"
-        out = dict(metric="%s iterations/s + CSR SpMV GB/s" % solver_cls.__name__, value=args.steps / dt, unit="iterations/s",
-                   n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
-                   scaling="strong", vs_baseline=None, dtype="f64" if sbytes == 8 else "c64", data="synthetic",
-                   config=dict(workload=label, spmv_stream=sinfo), roofline=roof)
+        out = dict(metric="%s iterations/s + CSR SpMV GB/s" % solver_cls.__name__, value=1e3 / ms_step, unit="iterations/s",
+                   n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True,
+                   scaling="strong", vs_baseline=None, dtype="f64" if sbytes == 8 else "c64", data="synthetic", timing=trec,
+                   create_ms=create_ms, config=dict(workload=label, spmv_stream=sinfo), roofline=roof)
         if not args.no_cpu_baseline:
             if args.workload == "banded":
                 out["cpu_baseline"] = cpu_baseline(ofn, ip, ix, dv, rhs, None, args.cpu_seconds, "the full cfg-3 system")

@@ -72,8 +72,7 @@ int sprs_version(void);
  *   "spmv_grid"     workgroups of the SpMV kernels (-1: 4 per CU)
  *   "poll"          iterations between two host looks at the device-side status word (>= 1)
  *   "stream_nt"     fused recurrence kernels read and write their vectors, and the pair-code SpMV writes y, with
- *                   non-temporal accesses: -1 automatic (vectors of 72 MB and more), 0 / 1;
- *                   "stream_nt_mask": in which of the fused kernels (bit 0 K1, 1 K3, 2 K5)
+ *                   non-temporal accesses: -1 automatic (vectors of 72 MB and more), 0 / 1
  *   "xcd_chunk"     1: one contiguous chunk of row blocks per XCD (-1: automatic — cache-resident matrices only)
  *   "ew_chunk"      fused recurrence kernels walk one contiguous eighth of the vectors per XCD, the eighth whose rows
  *                   that XCD multiplies: -1 automatic (cache-resident matrices whose far band is at most 1/32 of
@@ -89,7 +88,6 @@ int sprs_version(void);
  *   "spmv_period"   XCD-period walk of the compressed streams' blocks for matrices with a far band (rows r and
  *                   r +- band on one XCD): -1 automatic = the f64 pair-code stream (cfg 5: SpMV -2.3 %),
  *                   1 = the offset-code stream too (measured slower), 0 = off                            (creation)
- *   "spmv_nt"       1: non-temporal loads of the plain stream; "spmv_strip": experimental walks of the plain stream
  *   "halo_overlap"  distributed SpMV: 1 (default) multiplies the interior rows while the halo travels
  *   "gs_graph"      1: Gauss-Seidel replays a sweep's level launches from a hipGraph (default 0)
  * sprs_ctx_get also answers "num_cu" and "device".  Unknown key: SPRS_INVALID_ARGUMENT / -1. */
@@ -137,8 +135,9 @@ int64_t sprs_csr_nnz(const sprs_csr *A);
 int sprs_csr_stream_format(const sprs_csr *A, int *n_offsets, int *n_pairs);
 /* Diagnostics of the compressed streams: the number of row blocks the SpMV of this handle walks (128-row blocks of
  * the f64 pair-code stream, 64-row blocks of the offset-code stream) and how many of them are "uniform" (all rows
- * repeat one code sequence: multiplied from a scalar pattern, no code bytes and no row_ptr read).  0 / 0 for the
- * plain stream.  Copies the descriptors to the host: not for hot paths. */
+ * repeat one code sequence: multiplied from a scalar pattern, no code bytes and no row_ptr read).  Plain stream: its
+ * 64-row blocks and how many of them hold rows of equal length (row extents from the descriptor, no row_ptr read).
+ * Copies the descriptors to the host: not for hot paths. */
 int sprs_csr_wide_blocks(const sprs_csr *A, int64_t *n_blocks, int64_t *n_uniform);
 
 /* MatVecMul::mul_vec / mul_vec_dot (mat.rs:49-64): host slices, checked — returns
@@ -350,6 +349,9 @@ int sprs_comm_create(sprs_ctx *ctx, int world, int rank, const void *id128, sprs
 int sprs_comm_destroy(sprs_comm *comm);
 int sprs_comm_count(const sprs_comm *comm, int *count_out); /* ncclCommCount: the number of ranks RCCL itself reports */
 int sprs_comm_allreduce_sum_f64(sprs_comm *comm, double *dev, size_t count); /* in place; blocking */
+/* mean time of `reps` back-to-back in-place all-reduces of `count` doubles on the context's stream (HIP events): the
+ * price of one dot-product hand-off of a distributed solve on this communicator; collective */
+int sprs_comm_allreduce_timed_f64(sprs_comm *comm, double *dev, size_t count, int reps, double *us_out);
 /* peer_rank[n_peers]; send_off/recv_off[n_peers+1] are element offsets; send_idx_dev[send_off[n_peers]]
  * (device, i32) lists the local entries to pack for each peer; entries from peer p land at
  * x_ext[n_local + recv_off[p] ...].  recv_off[n_peers] == n_ext - n_local. */

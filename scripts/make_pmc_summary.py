@@ -3,7 +3,7 @@
 
   usage: python scripts/make_pmc_summary.py <fetch_dir> <write_dir> <key> [summary.json]
 
-Adds / replaces the entry <key> of profiles/r02_pmc_summary.json with, per kernel: launches, median
+Adds / replaces the entry <key> of profiles/r03_pmc_summary.json with, per kernel: launches, median
 FETCH_SIZE / WRITE_SIZE (KiB per dispatch), average duration, and for the dominant SpMV kernel the
 corrected traffic: 2 * FETCH_SIZE (gfx950 counts 128-B fabric requests at 64 B; calibrated 0.510 / 0.509,
 see "calibration" in the same file) + WRITE_SIZE."""
@@ -50,7 +50,7 @@ def short(name):
 def main():
     fetch_dir, write_dir, key = sys.argv[1:4]
     out_path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                                     "profiles", "r02_pmc_summary.json")
+                                                                     "profiles", "r03_pmc_summary.json")
     fe, wr, du = read_counter(fetch_dir, "FETCH_SIZE"), read_counter(write_dir, "WRITE_SIZE"), read_durations(fetch_dir)
     kernels = {}
     for k in sorted(set(fe) | set(wr)):
@@ -80,6 +80,9 @@ def main():
                                                   stderr=subprocess.DEVNULL, text=True).strip()
     except Exception:       # the GPU box has no .git: the commit is filled in when the summary is copied into profiles/
         entry["commit"] = None
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_digest          # what bench.py compares with to flag a stale `roofline.traffic`
+    entry["csrc_digest"] = csrc_digest()
     summary[key] = entry
     json.dump(summary, open(out_path, "w"), indent=1)
     print(json.dumps(entry.get("spmv_in_solve", {}), indent=1))

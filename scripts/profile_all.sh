@@ -1,4 +1,4 @@
-# Profiles of record for round 2 (run on the GPU box): kernel-trace stats + FETCH/WRITE PMC passes per workload.
+# Profiles of record (rounds 2, 3) (run on the GPU box): kernel-trace stats + FETCH/WRITE PMC passes per workload.
 #   usage: bash scripts/profile_all.sh   -> gpurun_out/{kernel_stats_*.csv, pmc_summary_*.json, prof_*_stats.json}
 set -e
 bash scripts/profile_bench.sh cfg5_pair

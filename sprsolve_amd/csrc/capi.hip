@@ -103,8 +103,6 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     if (k == "grid") { if (value < 8 || value > MAX_GRID) return SPRS_INVALID_ARGUMENT; c->grid = (int)(value & ~7); }
     else if (k == "spmv_grid") { if (value > MAX_GRID / 2 || (value >= 0 && value < 8)) return SPRS_INVALID_ARGUMENT; c->spmv_grid = value < 0 ? -1 : (int)(value & ~7); }
     else if (k == "xcd_chunk") c->xcd_chunk = value < 0 ? -1 : (value ? 1 : 0);
-    else if (k == "spmv_nt") c->spmv_nt = value < 0 ? -1 : (value ? 1 : 0);
-    else if (k == "spmv_strip") c->spmv_strip = (int)value;
     else if (k == "spmv_dict") { if (value < -1 || value > 2) return SPRS_INVALID_ARGUMENT; c->spmv_dict = (int)value; }
     else if (k == "spmv_wide") c->spmv_wide = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_uniform") c->spmv_uniform = value < 0 ? -1 : (value ? 1 : 0);
@@ -113,7 +111,6 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     else if (k == "spmv_seam") c->spmv_seam = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "ew_chunk") c->ew_chunk = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "stream_nt") c->stream_nt = value < 0 ? -1 : (value ? 1 : 0);
-    else if (k == "stream_nt_mask") c->stream_nt_mask = (int)(value & 7);
     else if (k == "spmv_eqrows") c->spmv_eqrows = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "halo_overlap") c->halo_overlap = value ? 1 : 0;
     else if (k == "gs_graph") c->gs_graph = value ? 1 : 0;
@@ -127,8 +124,6 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     if (k == "grid") return c->grid;
     if (k == "xcd_chunk") return c->xcd_chunk;
     if (k == "spmv_grid") return c->spmv_grid;
-    if (k == "spmv_nt") return c->spmv_nt;
-    if (k == "spmv_strip") return c->spmv_strip;
     if (k == "spmv_dict") return c->spmv_dict;
     if (k == "spmv_wide") return c->spmv_wide;
     if (k == "spmv_uniform") return c->spmv_uniform;
@@ -137,7 +132,6 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     if (k == "spmv_seam") return c->spmv_seam;
     if (k == "ew_chunk") return c->ew_chunk;
     if (k == "stream_nt") return c->stream_nt;
-    if (k == "stream_nt_mask") return c->stream_nt_mask;
     if (k == "spmv_eqrows") return c->spmv_eqrows;
     if (k == "halo_overlap") return c->halo_overlap;
     if (k == "gs_graph") return c->gs_graph;
@@ -530,7 +524,6 @@ int sprs_csr_destroy(sprs_csr *A) {
         if (A->val) (void)hipFree(A->val);
     }
     if (A->rowblk) (void)hipFree(A->rowblk);
-    if (A->blk_order) (void)hipFree(A->blk_order);
     if (A->blk_desc) (void)hipFree(A->blk_desc);
     if (A->blk_desc_eq) (void)hipFree(A->blk_desc_eq);
     free_dict(A);
@@ -559,12 +552,17 @@ int64_t sprs_csr_nnz(const sprs_csr *A) { return A ? A->nnz : -1; }
 int sprs_csr_wide_blocks(const sprs_csr *A, int64_t *n_blocks, int64_t *n_uniform) {
     if (!A || !n_blocks || !n_uniform) return SPRS_INVALID_ARGUMENT;
     *n_blocks = 0; *n_uniform = 0;
-    if (!A->dict) return SPRS_OK;
+    if (dict_mode(A) == 0) {       // plain CSR stream: the 64-row blocks; "uniform" = equal-length blocks, which read no row_ptr
+        *n_blocks = A->n_rowblk; *n_uniform = A->blk_desc_eq ? A->n_eq_blocks : 0;
+        return SPRS_OK;
+    }
     // the descriptors the SpMV of this handle walks: 128-row blocks of the f64 pair-code stream, else the 64-row
     // blocks of the offset-code stream
-    const bool wide = A->dict->wide_desc && A->dict->n_wide > 0 && dict_mode(A) == 2;
-    const void *src = wide ? A->dict->wide_desc : A->dict->off_desc;
-    const int64_t nb = wide ? A->dict->n_wide : (A->dict->off_desc ? A->n_rowblk : 0);
+    const bool wide = A->dict->wide_desc && A->dict->n_wide > 0 && dict_mode(A) == 2 && A->ctx->spmv_wide != 0;
+    // (the 64-row pair-code kernel, spmv_wide = 0, walks the plain descriptors: no uniform blocks)
+    const bool offs = dict_mode(A) == 1 && A->ctx->spmv_uniform != 0;
+    const void *src = wide ? A->dict->wide_desc : (offs ? A->dict->off_desc : nullptr);
+    const int64_t nb = wide ? A->dict->n_wide : (src ? A->n_rowblk : 0);
     if (!src || nb == 0) return SPRS_OK;
     sprs_ctx *c = A->ctx;
     CtxLock lock(c);

@@ -79,6 +79,55 @@ __device__ __forceinline__ void reduce_partials2(const TA *__restrict__ pa, cons
     for (int w = 1; w < NWAVE; ++w) { ra = sadd(ra, smA[w]); rb = sadd(rb, smB[w]); }
 }
 
+// ---- last-arriving-workgroup finalize of a fused reduction (struct Fin, internal.hpp)
+// Inter-workgroup visibility on gfx950 (per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed by
+// another CU's stores): every handed-off byte is stored AND loaded with agent-scope (`sc1`) accesses, each storing lane
+// drains its store (`s_waitcnt vmcnt(0)`) before it counts its arrival with an agent-scope atomic add, and the workgroup
+// whose add returned gridDim.x - 1 loads only after that add has returned (its other waves behind a workgroup barrier) —
+// MI355X_MICROARCH.md, "Valid forms", first row of the sc1 hand-off table.  No cache-wide release / acquire is issued.
+__device__ __forceinline__ void st_through(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_through(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_through(cplx *p, cplx v) { st_through(&p->re, v.re); st_through(&p->im, v.im); }
+__device__ __forceinline__ void st_through(cplxf *p, cplxf v) { st_through(&p->re, v.re); st_through(&p->im, v.im); }
+__device__ __forceinline__ double ld_through(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_through(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ cplx ld_through(const cplx *p) { return cplx{ld_through(&p->re), ld_through(&p->im)}; }
+__device__ __forceinline__ cplxf ld_through(const cplxf *p) { return cplxf{ld_through(&p->re), ld_through(&p->im)}; }
+
+// thread 0's store of its workgroup's partial: through to memory when the launch finalizes, plain otherwise
+template <class T>
+__device__ __forceinline__ void st_partial(const Fin &fin, T *p, T v) {
+    if (fin.counter) st_through(p, v); else *p = v;
+}
+
+// Called by ALL threads of every workgroup after thread 0 has st_partial'ed its partial(s).  Same per-thread addition
+// order and same wave / block order as reduce_partials => the value is bit-identical to what a consumer's prologue (or
+// a finalize launch) computes from the same partials.  `two`: the reduction has a second array (base1 / out1, type TB).
+template <class TA, class TB>
+__device__ __forceinline__ void finalize_last_block(const Fin &fin, bool two, TA *smA, TB *smB) {
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's partials have left the CU ...
+        const unsigned int t = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before its arrival counts
+        s_last = t == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const TA *pa = reinterpret_cast<const TA *>(fin.base0);
+    TA a = szero<TA>();
+    for (int i = threadIdx.x; i < fin.P; i += BLOCK) a = sadd(a, ld_through(pa + i));
+    a = block_sum(a, smA);
+    if (threadIdx.x == 0) *reinterpret_cast<TA *>(fin.out0) = a;
+    if (two) {
+        const TB *pb = reinterpret_cast<const TB *>(fin.base1);
+        TB b = szero<TB>();
+        for (int i = threadIdx.x; i < fin.P; i += BLOCK) b = sadd(b, ld_through(pb + i));
+        b = block_sum(b, smB);
+        if (threadIdx.x == 0) *reinterpret_cast<TB *>(fin.out1) = b;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+}
+
 // 16-byte packs: 2 doubles or 1 complex per lane per access (global_load_dwordx4).
 template <class T, int PK>
 struct alignas(sizeof(T) * PK) Pack {

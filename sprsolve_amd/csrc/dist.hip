@@ -163,7 +163,7 @@ template int halo_exchange<cplxf>(const sprs_csr *, cplxf *);
 // split at creation.  Dot partials of the two launches are concatenated (spmv_num_partials()).
 template <class T>
 int dist_spmv(const sprs_csr *A, T *x_ext, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status,
-              bool conj_x) {
+              bool conj_x, const Fin *fin) {
     const sprs_dist_info *D = A->dist;
     if (D->ag_slice > 0) {
         // literal north_star exchange: all-gather the x slices of all ranks, then multiply
@@ -171,23 +171,25 @@ int dist_spmv(const sprs_csr *A, T *x_ext, T *y, int dot_mode, const T *u, T *pa
         constexpr size_t W = sizeof(T) / sizeof(Real<T>);
         SPRS_NCCL_TRY(c, rccl().AllGather(x_ext, D->ag_buf, (size_t)D->ag_slice * W, sizeof(Real<T>) == 4 ? ncclFloat : ncclDouble,
                                           (ncclComm_t)D->comm->nccl, c->stream));
-        return launch_spmv<T>(A, reinterpret_cast<const T *>(D->ag_buf), y, dot_mode, u, part0, part1, status, conj_x);
+        return launch_spmv<T>(A, reinterpret_cast<const T *>(D->ag_buf), y, dot_mode, u, part0, part1, status, conj_x, fin);
     }
     if (!D->order_int) {
         SPRS_TRY(halo_exchange<T>(A, x_ext));
-        return launch_spmv<T>(A, x_ext, y, dot_mode, u, part0, part1, status, conj_x);
+        return launch_spmv<T>(A, x_ext, y, dot_mode, u, part0, part1, status, conj_x, fin);
     }
     SPRS_TRY(halo_begin<T>(A, x_ext));
     SPRS_TRY(launch_spmv_subset<T>(A, D->order_int, D->n_int, x_ext, y, dot_mode, u, part0, part1, status, conj_x));
     SPRS_TRY(halo_wait(A));
+    // the boundary launch starts after the interior one has finished (same stream): its last workgroup finalizes the
+    // concatenated partials of both
     const int off = spmv_subset_grid(A, D->n_int);
     return launch_spmv_subset<T>(A, D->order_bnd, D->n_bnd, x_ext, y, dot_mode, u, part0 ? part0 + off : nullptr,
-                                 part1 ? part1 + off : nullptr, status, conj_x);
+                                 part1 ? part1 + off : nullptr, status, conj_x, fin);
 }
-template int dist_spmv<double>(const sprs_csr *, double *, double *, int, const double *, double *, double *, const int *, bool);
-template int dist_spmv<cplx>(const sprs_csr *, cplx *, cplx *, int, const cplx *, cplx *, cplx *, const int *, bool);
-template int dist_spmv<float>(const sprs_csr *, float *, float *, int, const float *, float *, float *, const int *, bool);
-template int dist_spmv<cplxf>(const sprs_csr *, cplxf *, cplxf *, int, const cplxf *, cplxf *, cplxf *, const int *, bool);
+template int dist_spmv<double>(const sprs_csr *, double *, double *, int, const double *, double *, double *, const int *, bool, const Fin *);
+template int dist_spmv<cplx>(const sprs_csr *, cplx *, cplx *, int, const cplx *, cplx *, cplx *, const int *, bool, const Fin *);
+template int dist_spmv<float>(const sprs_csr *, float *, float *, int, const float *, float *, float *, const int *, bool, const Fin *);
+template int dist_spmv<cplxf>(const sprs_csr *, cplxf *, cplxf *, int, const cplxf *, cplxf *, cplxf *, const int *, bool, const Fin *);
 
 }  // namespace sprs
 
@@ -245,7 +247,7 @@ int dist_csr_create(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz
         st = rowblk_spans(A, lo, hi);
         if (st != SPRS_OK) { sprs_csr_destroy(A); return st; }
         std::vector<int32_t> oi, ob, oiw, obw;
-        const bool wide = A->dict && A->dict->wide_desc && !A->blk_order;
+        const bool wide = A->dict && A->dict->wide_desc;
         if (wide) {
             // classify PAIRS of consecutive 64-row blocks (= the 128-row blocks of the two-rows-per-lane kernel) so
             // that both kernels can run the same split: a pair is boundary if either half reads the halo
@@ -259,9 +261,6 @@ int dist_csr_create(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz
             for (int b = 0; b < A->n_rowblk; ++b) (hi[b] >= n_local ? ob : oi).push_back(b);
         }
         if (!oi.empty() && !ob.empty() && ob.size() * 2 <= (size_t)A->n_rowblk) {
-            // keep the XCD-period placement of the local operator for the (large) interior launch
-            if (A->blk_order && !A->sched_strip_major && A->sched_period > 0 && !A->blk_row_start.empty())
-                oi = place_on_xcds(oi, A->blk_row_start, A->sched_period);
             if (wide) {
                 bool okw = hipMalloc((void **)&D->order_int_w, sizeof(int32_t) * oiw.size()) == hipSuccess &&
                            hipMalloc((void **)&D->order_bnd_w, sizeof(int32_t) * obw.size()) == hipSuccess &&
@@ -332,6 +331,15 @@ __global__ __launch_bounds__(sprs::BLOCK) void plan_mark_kernel(int64_t nnz, con
     }
     if (local) atomicOr(bad, 1);
 }
+// range check alone (the all-gather numbering renumbers after the ranks have agreed that every input is valid)
+__global__ __launch_bounds__(sprs::BLOCK) void plan_check_kernel(int64_t nnz, const int32_t *__restrict__ col, int32_t n_global, int *__restrict__ bad) {
+    int local = 0;
+    for (int64_t k = (int64_t)blockIdx.x * sprs::BLOCK + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * sprs::BLOCK) {
+        const int32_t g = col[k];
+        local |= (g < 0) | (g >= n_global);
+    }
+    if (local) atomicOr(bad, 1);
+}
 __global__ __launch_bounds__(sprs::BLOCK) void plan_compact_kernel(int32_t n_global, const uint8_t *__restrict__ mark,
                                                                    const int32_t *__restrict__ pos, int32_t *__restrict__ uniq) {
     for (int64_t g = (int64_t)blockIdx.x * sprs::BLOCK + threadIdx.x; g < n_global; g += (int64_t)gridDim.x * sprs::BLOCK)
@@ -364,20 +372,32 @@ __global__ __launch_bounds__(sprs::BLOCK) void plan_shift_kernel(int64_t n, int3
 }
 static inline int plan_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + sprs::BLOCK - 1) / sprs::BLOCK, 2048)); }
 
+// Collective error contract: the function is collective over the communicator, so a rank must never leave it while the
+// others are still heading for an exchange.  Everything a rank can find wrong BY ITSELF (arguments, an out-of-range
+// column, an allocation) only sets `err`; the flags travel with the counts in the first ncclAllGather and every rank
+// returns the largest one; the two later rank-local failure points (the send list's allocation, the handle's creation)
+// are agreed on the same way before anyone proceeds.  The caller's column array (adopt != 0) is renumbered only after the
+// first two agreements.  An RCCL call that fails is a communicator failure: it is returned at once.
 template <class T>
 int dist_csr_create_global(sprs_comm *comm, const int64_t *row_starts, int64_t nnz, const int32_t *d_rp, int32_t *d_ci_global,
                            const T *d_val, int adopt, int exchange, sprs_csr **out) {
-    if (!comm || !row_starts || !out || !d_rp || nnz < 0 || (nnz > 0 && (!d_ci_global || !d_val))) return SPRS_INVALID_ARGUMENT;
+    if (!comm || !out) return SPRS_INVALID_ARGUMENT;         // no communicator / nowhere to report: nothing collective can be done
     *out = nullptr;
     sprs_ctx *c = comm->ctx;
     const int world = comm->world, rank = comm->rank;
-    for (int r = 0; r < world; ++r)
-        if (row_starts[r + 1] < row_starts[r]) return SPRS_INVALID_ARGUMENT;
-    if (row_starts[0] != 0 || row_starts[world] >= INT32_MAX) return SPRS_INVALID_ARGUMENT;
-    const int32_t n_global = (int32_t)row_starts[world], r0 = (int32_t)row_starts[rank], r1 = (int32_t)row_starts[rank + 1];
-    const int64_t n_local = r1 - r0;
     CtxLock lock(c);
-    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    int err = SPRS_OK;                                         // this rank's own verdict so far
+    auto fail = [&](int code) { if (err == SPRS_OK) err = code; };
+    if (!row_starts || !d_rp || nnz < 0 || (nnz > 0 && (!d_ci_global || !d_val)) || (exchange != 0 && exchange != 1)) fail(SPRS_INVALID_ARGUMENT);
+    if (err == SPRS_OK) {
+        for (int r = 0; r < world; ++r)
+            if (row_starts[r + 1] < row_starts[r]) fail(SPRS_INVALID_ARGUMENT);
+        if (row_starts[0] != 0 || row_starts[world] >= INT32_MAX) fail(SPRS_INVALID_ARGUMENT);
+    }
+    const int32_t n_global = err == SPRS_OK ? (int32_t)row_starts[world] : 0, r0 = err == SPRS_OK ? (int32_t)row_starts[rank] : 0,
+                  r1 = err == SPRS_OK ? (int32_t)row_starts[rank + 1] : 0;
+    const int64_t n_local = r1 - r0;
+    if (hipSetDevice(c->device) != hipSuccess) fail(SPRS_ERR_HIP);
     uint8_t *mark = nullptr; int32_t *pos = nullptr, *uniq = nullptr, *send_idx = nullptr, *counts = nullptr, *col_copy = nullptr;
     int64_t *d_starts = nullptr; void *scan_tmp = nullptr; int *d_bad = nullptr;
     auto cleanup = [&]() {
@@ -385,62 +405,102 @@ int dist_csr_create_global(sprs_comm *comm, const int64_t *row_starts, int64_t n
             if (q) (void)hipFree(q);
         if (col_copy) (void)hipFree(col_copy);
     };
-    PLAN_HIP(hipMalloc((void **)&d_bad, sizeof(int)));
-    PLAN_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
+    // rank-local HIP step: a failure is recorded, the text kept, and the remaining local steps are skipped
+#define PLAN_LOCAL(expr) do { if (err == SPRS_OK) { const hipError_t e__ = (expr); if (e__ != hipSuccess) { snprintf(c->err, sizeof(c->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); err = SPRS_ERR_HIP; } } } while (0)
+    // agreement: all-gather one status word per rank, everybody leaves with the largest
+    std::vector<int32_t> h_flags((size_t)world);
+    auto agree = [&](int mine, int *verdict) -> int {
+        int32_t *d_flags = counts;       // [world + 1] scratch at the head of `counts` is free at every call site
+        const int32_t m = mine;
+        if (hipMemcpyAsync(d_flags + world, &m, sizeof(int32_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) return SPRS_ERR_HIP;
+        if (rccl().AllGather(d_flags + world, d_flags, 1, ncclInt32, (ncclComm_t)comm->nccl, c->stream) != ncclSuccess) return SPRS_ERR_RCCL;
+        if (hipMemcpyAsync(h_flags.data(), d_flags, sizeof(int32_t) * (size_t)world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return SPRS_ERR_HIP;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return SPRS_ERR_HIP;
+        int v = SPRS_OK;
+        for (int q = 0; q < world; ++q) v = std::max(v, (int)h_flags[(size_t)q]);
+        *verdict = v;
+        return SPRS_OK;
+    };
+    // `counts` carries every exchange of this function; without it this rank cannot even take part in the agreement, and
+    // its peers would wait for it: that one allocation failing is reported at once (as any RCCL failure is)
+    if (hipMalloc((void **)&counts, sizeof(int32_t) * ((size_t)world * (size_t)(world + 2) + 8)) != hipSuccess) {
+        snprintf(c->err, sizeof(c->err), "%s:%d: hipMalloc of the plan's exchange buffer failed", __FILE__, __LINE__);
+        cleanup();
+        return SPRS_ERR_HIP;
+    }
+    PLAN_LOCAL(hipMalloc((void **)&d_bad, sizeof(int)));
+    PLAN_LOCAL(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
     int32_t *col_out = d_ci_global;
     if (!adopt && nnz > 0) {      // the caller keeps its global indices: renumber into a private copy the handle will own
-        PLAN_HIP(hipMalloc((void **)&col_copy, sizeof(int32_t) * (size_t)nnz));
+        PLAN_LOCAL(hipMalloc((void **)&col_copy, sizeof(int32_t) * (size_t)nnz));
         col_out = col_copy;
     }
-    int bad = 0;
+    int bad = 0, verdict = SPRS_OK;
     if (exchange == 1) {
         int64_t slice = 0;
-        for (int r = 0; r < world; ++r) slice = std::max(slice, row_starts[r + 1] - row_starts[r]);
-        slice += slice & 1;                        // every slice stays 16-byte aligned
-        if ((int64_t)world * slice >= INT32_MAX) { cleanup(); return SPRS_INVALID_ARGUMENT; }
-        PLAN_HIP(hipMalloc((void **)&d_starts, sizeof(int64_t) * (size_t)(world + 1)));
-        PLAN_HIP(hipMemcpyAsync(d_starts, row_starts, sizeof(int64_t) * (size_t)(world + 1), hipMemcpyHostToDevice, c->stream));
-        if (nnz > 0) hipLaunchKernelGGL(plan_renumber_ag_kernel, dim3(plan_grid(nnz)), dim3(BLOCK), 0, c->stream, nnz, d_ci_global, col_out, world,
-                                        d_starts, slice, d_bad);
-        PLAN_HIP(hipGetLastError());
-        PLAN_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        PLAN_HIP(hipStreamSynchronize(c->stream));
-        if (bad) { cleanup(); return SPRS_INVALID_ARGUMENT; }
+        if (err == SPRS_OK) {
+            for (int r = 0; r < world; ++r) slice = std::max(slice, row_starts[r + 1] - row_starts[r]);
+            slice += slice & 1;                        // every slice stays 16-byte aligned
+            if ((int64_t)world * slice >= INT32_MAX) fail(SPRS_INVALID_ARGUMENT);
+        }
+        PLAN_LOCAL(hipMalloc((void **)&d_starts, sizeof(int64_t) * (size_t)(world + 1)));
+        PLAN_LOCAL(hipMemcpyAsync(d_starts, row_starts, sizeof(int64_t) * (size_t)(world + 1), hipMemcpyHostToDevice, c->stream));
+        // range check only (output to a scratch-free pass): the renumbering itself waits for the agreement
+        if (err == SPRS_OK && nnz > 0) {
+            hipLaunchKernelGGL(plan_check_kernel, dim3(plan_grid(nnz)), dim3(BLOCK), 0, c->stream, nnz, d_ci_global, n_global, d_bad);
+            PLAN_LOCAL(hipGetLastError());
+        }
+        PLAN_LOCAL(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        PLAN_LOCAL(hipStreamSynchronize(c->stream));
+        if (err == SPRS_OK && bad) fail(SPRS_INVALID_ARGUMENT);
+        { const int st = agree(err, &verdict); if (st != SPRS_OK) { cleanup(); return st; } }
+        if (verdict != SPRS_OK) { cleanup(); return err != SPRS_OK ? err : verdict; }
+        int st = SPRS_OK;
+        if (nnz > 0) {
+            hipLaunchKernelGGL(plan_renumber_ag_kernel, dim3(plan_grid(nnz)), dim3(BLOCK), 0, c->stream, nnz, d_ci_global, col_out, world,
+                               d_starts, slice, d_bad);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) st = SPRS_ERR_HIP;
+        }
         // a private copy is handed over to the handle (adopt = 0 semantics: copied again inside; keep it simple and correct)
-        const int st = dist_csr_create_allgather<T>(comm, n_local, slice, nnz, d_rp, col_out, d_val, adopt, out);
+        if (st == SPRS_OK) st = dist_csr_create_allgather<T>(comm, n_local, slice, nnz, d_rp, col_out, d_val, adopt, out);
+        { const int s2 = agree(st, &verdict); if (s2 != SPRS_OK) { if (*out) { sprs_csr_destroy(*out); *out = nullptr; } cleanup(); return s2; } }
+        if (verdict != SPRS_OK && *out) { sprs_csr_destroy(*out); *out = nullptr; }
         cleanup();
-        return st;
+        return st != SPRS_OK ? st : verdict;
     }
-    if (exchange != 0) { cleanup(); return SPRS_INVALID_ARGUMENT; }
     // ---- 1. mark, 2. scan, compact
-    PLAN_HIP(hipMalloc((void **)&mark, (size_t)n_global + 16));
-    PLAN_HIP(hipMalloc((void **)&pos, sizeof(int32_t) * ((size_t)n_global + 1)));
-    PLAN_HIP(hipMemsetAsync(mark, 0, (size_t)n_global + 16, c->stream));
-    if (nnz > 0) hipLaunchKernelGGL(plan_mark_kernel, dim3(plan_grid(nnz)), dim3(BLOCK), 0, c->stream, nnz, d_ci_global, r0, r1, n_global, mark, d_bad);
-    PLAN_HIP(hipGetLastError());
+    PLAN_LOCAL(hipMalloc((void **)&mark, (size_t)n_global + 16));
+    PLAN_LOCAL(hipMalloc((void **)&pos, sizeof(int32_t) * ((size_t)n_global + 1)));
+    PLAN_LOCAL(hipMemsetAsync(mark, 0, (size_t)n_global + 16, c->stream));
+    if (err == SPRS_OK && nnz > 0) {
+        hipLaunchKernelGGL(plan_mark_kernel, dim3(plan_grid(nnz)), dim3(BLOCK), 0, c->stream, nnz, d_ci_global, r0, r1, n_global, mark, d_bad);
+        PLAN_LOCAL(hipGetLastError());
+    }
     size_t tmp_bytes = 0;
-    PLAN_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, mark, pos, (int32_t)0, (size_t)n_global + 1, rocprim::plus<int32_t>(), c->stream));
-    PLAN_HIP(hipMalloc(&scan_tmp, tmp_bytes ? tmp_bytes : 16));
-    PLAN_HIP(rocprim::exclusive_scan(scan_tmp, tmp_bytes, mark, pos, (int32_t)0, (size_t)n_global + 1, rocprim::plus<int32_t>(), c->stream));
+    PLAN_LOCAL(rocprim::exclusive_scan(nullptr, tmp_bytes, mark, pos, (int32_t)0, (size_t)n_global + 1, rocprim::plus<int32_t>(), c->stream));
+    PLAN_LOCAL(hipMalloc(&scan_tmp, tmp_bytes ? tmp_bytes : 16));
+    PLAN_LOCAL(rocprim::exclusive_scan(scan_tmp, tmp_bytes, mark, pos, (int32_t)0, (size_t)n_global + 1, rocprim::plus<int32_t>(), c->stream));
     int32_t n_halo = 0;
-    PLAN_HIP(hipMemcpyAsync(&n_halo, pos + n_global, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));   // mark[n_global] == 0: total
-    PLAN_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    PLAN_HIP(hipStreamSynchronize(c->stream));
-    if (bad) { cleanup(); return SPRS_INVALID_ARGUMENT; }
+    PLAN_LOCAL(hipMemcpyAsync(&n_halo, pos + n_global, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));   // mark[n_global] == 0: total
+    PLAN_LOCAL(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PLAN_LOCAL(hipStreamSynchronize(c->stream));
+    if (err == SPRS_OK && bad) fail(SPRS_INVALID_ARGUMENT);
+    if (err != SPRS_OK) n_halo = 0;
+    // the renumbered columns n_local + pos[g] are int32 as well
+    if (err == SPRS_OK && n_local + (int64_t)n_halo >= INT32_MAX) fail(SPRS_INVALID_ARGUMENT);
     std::vector<int32_t> h_uniq((size_t)n_halo);
     if (n_halo > 0) {
-        PLAN_HIP(hipMalloc((void **)&uniq, sizeof(int32_t) * (size_t)n_halo));
-        hipLaunchKernelGGL(plan_compact_kernel, dim3(plan_grid(n_global)), dim3(BLOCK), 0, c->stream, n_global, mark, pos, uniq);
-        PLAN_HIP(hipGetLastError());
-        PLAN_HIP(hipMemcpyAsync(h_uniq.data(), uniq, sizeof(int32_t) * (size_t)n_halo, hipMemcpyDeviceToHost, c->stream));
+        PLAN_LOCAL(hipMalloc((void **)&uniq, sizeof(int32_t) * (size_t)n_halo));
+        if (err == SPRS_OK) {
+            hipLaunchKernelGGL(plan_compact_kernel, dim3(plan_grid(n_global)), dim3(BLOCK), 0, c->stream, n_global, mark, pos, uniq);
+            PLAN_LOCAL(hipGetLastError());
+        }
+        PLAN_LOCAL(hipMemcpyAsync(h_uniq.data(), uniq, sizeof(int32_t) * (size_t)n_halo, hipMemcpyDeviceToHost, c->stream));
+        PLAN_LOCAL(hipStreamSynchronize(c->stream));
     }
-    // ---- 3. renumber the columns
-    if (nnz > 0) hipLaunchKernelGGL(plan_renumber_kernel, dim3(plan_grid(nnz)), dim3(BLOCK), 0, c->stream, nnz, d_ci_global, col_out, r0, r1, pos);
-    PLAN_HIP(hipGetLastError());
-    PLAN_HIP(hipStreamSynchronize(c->stream));
-    // ---- 4. who needs what: counts in one all-gather, index lists in one send/recv group
-    std::vector<int32_t> need(world, 0), need_off(world + 1, 0);
-    {
+    // ---- 3. who needs what: counts (and this rank's verdict so far) in one all-gather
+    std::vector<int32_t> need(world + 1, 0), need_off(world + 1, 0);
+    if (err == SPRS_OK) {
         int p = 0;
         for (int32_t i = 0; i < n_halo; ++i) {
             while (h_uniq[(size_t)i] >= row_starts[p + 1]) ++p;      // ascending ids: owners ascend too
@@ -448,20 +508,33 @@ int dist_csr_create_global(sprs_comm *comm, const int64_t *row_starts, int64_t n
         }
         for (int q = 0; q < world; ++q) need_off[q + 1] = need_off[q] + need[q];
     }
-    PLAN_HIP(hipMalloc((void **)&counts, sizeof(int32_t) * (size_t)world * (size_t)(world + 1)));
-    PLAN_HIP(hipMemcpyAsync(counts, need.data(), sizeof(int32_t) * (size_t)world, hipMemcpyHostToDevice, c->stream));
-    PLAN_NCCL(rccl().AllGather(counts, counts + world, (size_t)world, ncclInt32, (ncclComm_t)comm->nccl, c->stream));
-    std::vector<int32_t> M((size_t)world * world);           // M[q * world + p]: rank q needs that many entries of rank p
-    PLAN_HIP(hipMemcpyAsync(M.data(), counts + world, sizeof(int32_t) * M.size(), hipMemcpyDeviceToHost, c->stream));
-    PLAN_HIP(hipStreamSynchronize(c->stream));
+    need[world] = err;                                               // the extra element: this rank's status
+    const size_t W1 = (size_t)world + 1;
+    int32_t *d_mine = counts + W1 * (size_t)world;                   // [world + 1], behind the gathered matrix
+    if (hipMemcpyAsync(d_mine, need.data(), sizeof(int32_t) * W1, hipMemcpyHostToDevice, c->stream) != hipSuccess) { cleanup(); return SPRS_ERR_HIP; }
+    PLAN_NCCL(rccl().AllGather(d_mine, counts, W1, ncclInt32, (ncclComm_t)comm->nccl, c->stream));
+    std::vector<int32_t> M(W1 * (size_t)world);                      // M[q * (world + 1) + p]: rank q needs that many entries of rank p; [.. + world]: rank q's status
+    if (hipMemcpyAsync(M.data(), counts, sizeof(int32_t) * M.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { cleanup(); return SPRS_ERR_HIP; }
+    for (int q = 0; q < world; ++q) verdict = std::max(verdict, (int)M[(size_t)q * W1 + (size_t)world]);
+    // every rank checks EVERY pair with the same data, so all reach the same conclusion
+    if (verdict == SPRS_OK)
+        for (int q = 0; q < world && verdict == SPRS_OK; ++q)
+            for (int p = 0; p < world; ++p) {
+                const int32_t cnt = M[(size_t)q * W1 + (size_t)p];
+                if (cnt < 0 || (int64_t)cnt > row_starts[p + 1] - row_starts[p] || (p == q && cnt != 0)) { verdict = SPRS_INVALID_ARGUMENT; break; }
+            }
+    if (verdict != SPRS_OK) { cleanup(); return err != SPRS_OK ? err : verdict; }
     std::vector<int64_t> send_off_all(world + 1, 0);
-    for (int q = 0; q < world; ++q) {
-        const int32_t cnt = q == rank ? 0 : M[(size_t)q * world + rank];
-        if (cnt < 0 || cnt > n_local) { cleanup(); return SPRS_INVALID_ARGUMENT; }
-        send_off_all[q + 1] = send_off_all[q] + cnt;
-    }
+    for (int q = 0; q < world; ++q) send_off_all[q + 1] = send_off_all[q] + (q == rank ? 0 : M[(size_t)q * W1 + (size_t)rank]);
     const int64_t n_send = send_off_all[world];
-    if (n_send > 0) PLAN_HIP(hipMalloc((void **)&send_idx, sizeof(int32_t) * (size_t)n_send));
+    // ---- 4. the send list's buffer is the last rank-local allocation in front of an exchange: agree on it
+    int st_local = SPRS_OK;
+    if (n_send > 0 && hipMalloc((void **)&send_idx, sizeof(int32_t) * (size_t)n_send) != hipSuccess) st_local = SPRS_ERR_HIP;
+    { const int st = agree(st_local, &verdict); if (st != SPRS_OK) { cleanup(); return st; } }
+    if (verdict != SPRS_OK) { cleanup(); return st_local != SPRS_OK ? st_local : verdict; }
+    // ---- 5. renumber the columns (in place when adopted: only now, with every rank's input accepted), exchange the lists
+    if (nnz > 0) hipLaunchKernelGGL(plan_renumber_kernel, dim3(plan_grid(nnz)), dim3(BLOCK), 0, c->stream, nnz, d_ci_global, col_out, r0, r1, pos);
     PLAN_NCCL(rccl().GroupStart());
     for (int q = 0; q < world; ++q) {
         if (q == rank) continue;
@@ -470,9 +543,9 @@ int dist_csr_create_global(sprs_comm *comm, const int64_t *row_starts, int64_t n
         if (cnt > 0) PLAN_NCCL(rccl().Recv(send_idx + send_off_all[q], (size_t)cnt, ncclInt32, q, (ncclComm_t)comm->nccl, c->stream));
     }
     PLAN_NCCL(rccl().GroupEnd());
+    int st = SPRS_OK;
     if (n_send > 0) hipLaunchKernelGGL(plan_shift_kernel, dim3(plan_grid(n_send)), dim3(BLOCK), 0, c->stream, n_send, send_idx, r0);   // global -> local
-    PLAN_HIP(hipGetLastError());
-    PLAN_HIP(hipStreamSynchronize(c->stream));
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) st = SPRS_ERR_HIP;
     // ---- one peer list for both directions
     std::vector<int32_t> peers; std::vector<int64_t> s_off(1, 0), r_off(1, 0);
     for (int q = 0; q < world; ++q) {
@@ -481,10 +554,15 @@ int dist_csr_create_global(sprs_comm *comm, const int64_t *row_starts, int64_t n
         peers.push_back(q); s_off.push_back(s_off.back() + ns); r_off.push_back(r_off.back() + nr);
     }
     // send_idx is grouped by ascending peer with no gaps: exactly the layout dist_csr_create expects
-    const int st = dist_csr_create<T>(comm, n_local, n_local + n_halo, nnz, d_rp, col_out, d_val, adopt, (int)peers.size(), peers.data(),
-                                      s_off.data(), send_idx, r_off.data(), out);
+    if (st == SPRS_OK)
+        st = dist_csr_create<T>(comm, n_local, n_local + n_halo, nnz, d_rp, col_out, d_val, adopt, (int)peers.size(), peers.data(),
+                                s_off.data(), send_idx, r_off.data(), out);
+    // the handle exists on all ranks or on none: a solve on it is collective too
+    { const int s2 = agree(st, &verdict); if (s2 != SPRS_OK) { if (*out) { sprs_csr_destroy(*out); *out = nullptr; } cleanup(); return s2; } }
+    if (verdict != SPRS_OK && *out) { sprs_csr_destroy(*out); *out = nullptr; }
     cleanup();
-    return st;
+    return st != SPRS_OK ? st : verdict;
+#undef PLAN_LOCAL
 }
 #undef PLAN_TRY
 #undef PLAN_HIP
@@ -506,6 +584,7 @@ int sprs_dist_csr_info(const sprs_csr *A, int64_t *n_local, int64_t *n_ext, int 
 int sprs_dist_csr_peers(const sprs_csr *A, int cap, int32_t *peer_rank, int64_t *send_off, int64_t *recv_off) {
     if (!A || !A->dist || cap < (int)A->dist->peer.size() || (cap > 0 && (!peer_rank || !send_off || !recv_off))) return SPRS_INVALID_ARGUMENT;
     const sprs_dist_info *D = A->dist;
+    CtxLock lock(A->ctx);          // host-side plan data only; the lock orders the read with a concurrent destroy / create on the context
     for (size_t p = 0; p < D->peer.size(); ++p) peer_rank[p] = D->peer[p];
     if (send_off) for (size_t p = 0; p < D->send_off.size(); ++p) send_off[p] = D->send_off[p];
     if (recv_off) for (size_t p = 0; p < D->recv_off.size(); ++p) recv_off[p] = D->recv_off[p];
@@ -516,7 +595,13 @@ int sprs_dist_csr_send_idx(const sprs_csr *A, int64_t cap, int32_t *send_idx_hos
     const sprs_dist_info *D = A->dist;
     const int64_t n = D->send_off.back();
     if (cap < n) return SPRS_INVALID_ARGUMENT;
-    if (n > 0) SPRS_HIP_TRY(A->ctx, hipMemcpy(send_idx_host, D->send_idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    if (n > 0) {
+        sprs_ctx *c = A->ctx;
+        CtxLock lock(c);
+        SPRS_HIP_TRY(c, hipSetDevice(c->device));
+        SPRS_HIP_TRY(c, hipMemcpyAsync(send_idx_host, D->send_idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     return SPRS_OK;
 }
 
@@ -571,6 +656,28 @@ int sprs_comm_allreduce_sum_f64(sprs_comm *comm, double *dev, size_t count) {
     return SPRS_OK;
 }
 
+// `reps` back-to-back all-reduces of `count` doubles on the context's stream between two events: what ONE hand-off of the
+// distributed recurrence costs on this communicator (bench.py's `allreduce_us`)
+int sprs_comm_allreduce_timed_f64(sprs_comm *comm, double *dev, size_t count, int reps, double *us_out) {
+    if (!comm || !dev || !us_out || reps < 1) return SPRS_INVALID_ARGUMENT;
+    sprs_ctx *c = comm->ctx;
+    CtxLock lock(c);
+    SPRS_HIP_TRY(c, hipSetDevice(c->device));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct Ev { hipEvent_t &a, &b; ~Ev() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } guard{e0, e1};
+    SPRS_HIP_TRY(c, hipEventCreate(&e0));
+    SPRS_HIP_TRY(c, hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) SPRS_TRY(allreduce_sum(comm, dev, count, false));
+    SPRS_HIP_TRY(c, hipEventRecord(e0, c->stream));
+    for (int i = 0; i < reps; ++i) SPRS_TRY(allreduce_sum(comm, dev, count, false));
+    SPRS_HIP_TRY(c, hipEventRecord(e1, c->stream));
+    SPRS_HIP_TRY(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    SPRS_HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+    *us_out = (double)ms * 1e3 / reps;
+    return SPRS_OK;
+}
+
 #define SPRS_DIST_API(X, T, CT)                                                                                          \
     int sprs_dist_csr_create_dev_##X(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz, const int32_t *rp,    \
                                      const int32_t *ci, const CT *val, int adopt, int n_peers, const int32_t *peer_rank, \
@@ -595,7 +702,7 @@ int sprs_comm_allreduce_sum_f64(sprs_comm *comm, double *dev, size_t count) {
     }                                                                                                                    \
     int sprs_dist_mul_vec_dev_##X(const sprs_csr *A, CT *x_ext, CT *y_local) {                                           \
         if (!A || !A->dist || A->dtype != dtype_of<T>::value) return SPRS_INVALID_ARGUMENT;                              \
-        return dist_spmv<T>(A, (T *)x_ext, (T *)y_local, 0, nullptr, nullptr, nullptr, nullptr, false);                  \
+        return dist_spmv<T>(A, (T *)x_ext, (T *)y_local, 0, nullptr, nullptr, nullptr, nullptr, false, nullptr);                  \
     }
 SPRS_DIST_API(d, double, double)
 SPRS_DIST_API(z, cplx, sprs_c64)

@@ -21,6 +21,18 @@ constexpr int MAX_GRID = 4096; // upper bound of the streaming-kernel grid (= ma
 // device-side status word of a running solve
 enum : int { ST_RUNNING = 0, ST_CONVERGED = 1, ST_RESTART = 2, ST_BREAKDOWN = 3, ST_INVALID_PC = 4 };
 
+// Hand-off of a fused reduction whose FINAL value is computed inside the producing launch (device.hpp,
+// finalize_last_block): the workgroup that arrives last re-reduces all partials in the library's fixed order and writes
+// the scalars to out0 / out1.  Used by the distributed solves, whose consumer is an ncclAllReduce of those scalars: one
+// stream operation per hand-off instead of a finalize launch plus the collective.  counter == nullptr: no finalize (the
+// consumer kernel re-reduces the partials itself, the single-GPU hand-off).
+struct Fin {
+    unsigned int *counter = nullptr;   // agent-scope arrival counter, zero between launches
+    const void *base0 = nullptr, *base1 = nullptr;   // first partial of the WHOLE reduction (an earlier launch may have written the head)
+    void *out0 = nullptr, *out1 = nullptr;           // the reduced values (16-byte slots of the solver's `red` buffer)
+    int P = 0;                         // partials of the whole reduction
+};
+
 }  // namespace sprs
 
 struct sprs_ctx {
@@ -30,18 +42,10 @@ struct sprs_ctx {
     int num_cu = 256;
     int grid = 512;      // blocks launched by streaming / reduction kernels (multiple of 8; 2 per CU, set in sprs_ctx_create)
     int spmv_grid = -1;    // workgroups of the persistent SpMV grid; -1 = auto (4 per CU)
-    // SpMV placement knobs; -1 = auto (measured on MI355X, profiles/r01_tuning.md): matrices whose stream
-    // fits the 256 MiB Infinity Cache run best with one contiguous chunk of row blocks per XCD and
-    // non-temporal (col_idx, val) loads (x stays in that XCD's L2); HBM-bound ones run best round-robin
-    // with plain loads (all XCDs sweep the same region, x re-reads are served by the Infinity Cache).
+    // SpMV placement: -1 = auto (measured on MI355X, profiles/r01_tuning.md): matrices whose stream fits the 256 MiB
+    // Infinity Cache run best with one contiguous chunk of row blocks per XCD (x stays in that XCD's L2); HBM-bound
+    // ones run best round-robin (all XCDs sweep the same region, x re-reads are served by the Infinity Cache).
     int xcd_chunk = -1;
-    int spmv_nt = -1;
-    // SpMV row-block schedule for matrices with far bands (3-D stencils), read at handle creation:
-    // 0 = natural order, round-robin over the XCDs (default: fastest in every measurement on MI355X);
-    // 1 = XCD-period placement (rows r and r +- P on the same XCD; cuts the L2->fabric x traffic from
-    // ~5.5 reads to ~1 but was 2 % SLOWER), >= 2 = strip-major walk with that many rows per strip
-    // (5-10 % slower).  Both kept as experiments — see profiles/r01_tuning.md.
-    int spmv_strip = 0;
     // dictionary-compressed SpMV stream: -1 auto (the most compact the matrix qualifies for), 0 plain CSR,
     // 1 offset codes + values, 2 (offset, value) pair codes.  Read at handle creation (what is built) and at launch (what is used).
     int spmv_dict = -1;
@@ -52,12 +56,9 @@ struct sprs_ctx {
     int spmv_seam = -1;    // f64 pair codes: blocks that are uniform but for one or two adjacent rows lacking one slot run the uniform path; 0 = off.  Read at creation
     int ew_chunk = -1;     // fused recurrence kernels walk one contiguous eighth of the vectors per XCD: -1 automatic (fused_chunked), 0 / 1
     int stream_nt = -1;    // fused recurrence kernels access their vectors with non-temporal loads / stores: -1 auto (by vector size), 0 / 1
-    int stream_nt_mask = 7; // ... in which of them: bit 0 K1 / MINRES kernels, bit 1 K3, bit 2 K5 (profiles/r02_tuning.md §20)
-                           // and at launch.  Off by default: it cuts the SpMV's fabric reads by 58 % (x crosses the fabric once) and the
-                           // kernel's time not at all (profiles/r02_tuning.md §7)
     int spmv_uniform = -1; // ... and blocks whose rows all repeat one code sequence read neither codes nor row_ptr; read at creation
     int halo_overlap = 1;  // distributed SpMV: run the halo-free rows while the halo travels
-    int gs_graph = 0;    // Gauss-Seidel: 1 = replay a sweep's level launches from a hipGraph (measured: no gain, r01_tuning.md)
+    int gs_graph = 0;    // Gauss-Seidel: 1 = replay a sweep's level launches from a hipGraph (tests/test_gpu_gauss_seidel.py; no gain measured, r01_tuning.md)
     int poll = 16;       // iterations between host polls of the device status word
     double *d_part = nullptr;  // reduction partials for the stand-alone vecalg entry points
     double *d_scal = nullptr;  // small device result buffer
@@ -171,10 +172,7 @@ struct sprs_csr {
     int32_t n_rowblk = 0;
     void *blk_desc = nullptr;      // device: one 16-byte {ra, rb|flag, pa, nn} descriptor per row block
     void *blk_desc_eq = nullptr;   // device: the plain-CSR kernel's copy, equal-length blocks flagged (rb bit 30, row length in nn >> 16)
-    int32_t *blk_order = nullptr;  // device: schedule of the row blocks (n_rowblk entries) or null = natural order
-    int64_t sched_period = 0;      // rows between the far bands the schedule folds over (0 = no schedule)
-    bool sched_strip_major = false;
-    std::vector<int64_t> blk_row_start;   // host copy of the row-block starts (kept when a schedule exists)
+    int32_t n_eq_blocks = 0;       // ... how many are flagged (their row_ptr entries are not read)
     // scratch for the host-slice trait entry points (lazily allocated)
     void *x_tmp = nullptr, *y_tmp = nullptr;
     double *part = nullptr;      // partials for mul_vec_dot
@@ -199,17 +197,16 @@ namespace sprs {
 // conj_x: gather conj(x[col]) instead of x[col] (CSMINRES: A * conj(q), cs_minres.rs:99-101, without materialising conj(q)).
 template <class T>
 int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status,
-                bool conj_x = false);
+                bool conj_x = false, const Fin *fin = nullptr);
 int build_rowblocks(sprs_csr *A, const int32_t *host_row_ptr);
 int validate_cols_device(const sprs_csr *A);   // SPRS_INVALID_ARGUMENT if any col_idx is outside [0, ncols)
 int spmv_num_partials(const sprs_csr *A);  // workgroups launch_spmv uses == partials it writes
 // per-row-block column span (device kernel + D2H): lo/hi sized n_rowblk
 int rowblk_spans(const sprs_csr *A, std::vector<int32_t> &lo, std::vector<int32_t> &hi);
-std::vector<int32_t> place_on_xcds(const std::vector<int32_t> &blocks, const std::vector<int64_t> &row_start, int64_t P);
 // SpMV over a subset of the row blocks (order[0..count)); writes `subset_grid(count)` partials
 template <class T>
 int launch_spmv_subset(const sprs_csr *A, const int32_t *order, int count, const T *x, T *y, int dot_mode, const T *u,
-                       T *part0, T *part1, const int *status, bool conj_x);
+                       T *part0, T *part1, const int *status, bool conj_x, const Fin *fin = nullptr);
 int spmv_subset_grid(const sprs_csr *A, int count);
 // ---- spmv_dict.hip
 // SPRS_OK also when the matrix does not qualify (A->dict stays null); blk / host_row_ptr: the row blocks just built
@@ -221,7 +218,7 @@ bool fused_chunked(const sprs_csr *A);
 
 template <class T>
 int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int count, int g, int xcd_chunk, const T *x, T *y,
-                     int dot_mode, const T *u, T *part0, T *part1, const int *status, bool conj_x);
+                     int dot_mode, const T *u, T *part0, T *part1, const int *status, bool conj_x, const Fin &fin);
 
 // ---- blas1.hip  (all on ctx->stream, asynchronous)
 template <class T, class S> int launch_axpy(sprs_ctx *c, size_t n, S a, const T *x, T *y);
@@ -246,7 +243,8 @@ template <class T> int halo_exchange(const sprs_csr *A, T *x_ext);
 template <class T> int halo_begin(const sprs_csr *A, T *x_ext);
 int halo_wait(const sprs_csr *A);
 template <class T>
-int dist_spmv(const sprs_csr *A, T *x_ext, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status, bool conj_x);
+int dist_spmv(const sprs_csr *A, T *x_ext, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status, bool conj_x,
+              const Fin *fin = nullptr);   // fin: handed to the LAST launch of the operator (P and base pointers span all of them)
 int allreduce_sum(sprs_comm *comm, void *dev, size_t count, bool f32 = false);   // in place, on the ctx stream; count elements of f64 (or f32)
 
 inline int grid_for(const sprs_ctx *c) {

@@ -54,10 +54,10 @@ __global__ __launch_bounds__(BLOCK) void fused_kernel(int64_t n, F f, int chunke
 }
 
 template <class T, class F>
-static int launch_fused(sprs_ctx *c, size_t n, int grid, int chunked_walk, F f, int which = 0) {
+static int launch_fused(sprs_ctx *c, size_t n, int grid, int chunked_walk, F f) {
     constexpr int PKW = pack_width<T>::value;
     const int chunked = (chunked_walk && grid % 8 == 0 && grid >= 8) ? 1 : 0;
-    if (stream_loads_nt(c, n * sizeof(T)) && ((c->stream_nt_mask >> which) & 1))
+    if (stream_loads_nt(c, n * sizeof(T)))
         hipLaunchKernelGGL((fused_kernel<PKW, true, F>), dim3(grid), dim3(BLOCK), 0, c->stream, (int64_t)n, f, chunked);
     else
         hipLaunchKernelGGL((fused_kernel<PKW, false, F>), dim3(grid), dim3(BLOCK), 0, c->stream, (int64_t)n, f, chunked);
@@ -170,6 +170,7 @@ template <class T, bool PC>
 struct BicgK5 {
     BicgState<T> *S; const T *partTT; const T *partTR; int P;
     const T *y; const T *z; const T *t; const T *r0; T *x; T *r; Real<T> *partN; T *partRho;
+    Fin fin;                    // distributed: the last workgroup reduces (partN, partRho) for the all-reduce
     T na, nw, w;
     Real<T> accN; T accR;
     __device__ __forceinline__ bool prologue() {
@@ -208,8 +209,9 @@ struct BicgK5 {
         __shared__ T smT[NWAVE];
         const Real<T> sN = block_sum(accN, smD);
         const T sR = block_sum(accR, smT);
-        if (threadIdx.x == 0) { partN[blockIdx.x] = sN; partRho[blockIdx.x] = sR; }
+        if (threadIdx.x == 0) { st_partial(fin, partN + blockIdx.x, sN); st_partial(fin, partRho + blockIdx.x, sR); }
         if (first_thread()) { S->w = w; S->rho_old = S->rho; S->its = S->its + 1; }
+        if (fin.counter) finalize_last_block<Real<T>, T>(fin, true, smD, smT);
     }
 };
 
@@ -220,6 +222,7 @@ template <class T, class V, bool PC>
 struct MinresM2 {
     MinresDev<T> *D; int par; const T *partAlpha; int P;
     const T *v_old; const T *v; T *v_new; const V *dinv; T *w_new; Real<T> *partBeta; T *partBeta2;
+    Fin fin;                    // distributed: the last workgroup reduces partBeta / partBeta2 for the all-reduce
     T nb, na; Real<T> accD; T accT;
     __device__ __forceinline__ bool prologue() {
         __shared__ T smT[NWAVE];
@@ -258,10 +261,12 @@ struct MinresM2 {
         __shared__ T smT[NWAVE];
         if (PC) {
             const T s = block_sum(accT, smT);
-            if (threadIdx.x == 0) partBeta2[blockIdx.x] = s;
+            if (threadIdx.x == 0) st_partial(fin, partBeta2 + blockIdx.x, s);
+            if (fin.counter) finalize_last_block<T, T>(fin, false, smT, smT);
         } else {
             const Real<T> s = block_sum(accD, smD);
-            if (threadIdx.x == 0) partBeta[blockIdx.x] = s;
+            if (threadIdx.x == 0) st_partial(fin, partBeta + blockIdx.x, s);
+            if (fin.counter) finalize_last_block<Real<T>, Real<T>>(fin, false, smD, smD);
         }
     }
 };
@@ -363,6 +368,8 @@ int KrylovBase<T>::init(const sprs_csr *A_, size_t size, int nvec_) {
     if (A->dist) {
         SPRS_HIP_TRY(ctx, hipMalloc((void **)&red, sizeof(double) * 32));
         SPRS_HIP_TRY(ctx, hipMemsetAsync(red, 0, sizeof(double) * 32, ctx->stream));
+        SPRS_HIP_TRY(ctx, hipMalloc((void **)&fin_counter, sizeof(unsigned int) * 64));      // one arrival counter per hand-off slot, 64 B apart
+        SPRS_HIP_TRY(ctx, hipMemsetAsync(fin_counter, 0, sizeof(unsigned int) * 64, ctx->stream));
         SPRS_HIP_TRY(ctx, hipMalloc((void **)&xext, sizeof(T) * stride));
     }
     SPRS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -377,8 +384,9 @@ void KrylovBase<T>::destroy() {
     if (part) (void)hipFree(part);
     if (partD) (void)hipFree(partD);
     if (red) (void)hipFree(red);
+    if (fin_counter) (void)hipFree(fin_counter);
     if (xext) (void)hipFree(xext);
-    red = nullptr; xext = nullptr;
+    red = nullptr; xext = nullptr; fin_counter = nullptr;
     for (auto e : ev) (void)hipEventDestroy(e);
     ev.clear();
     work = rhs_buf = x_buf = part = nullptr; partD = nullptr;
@@ -391,26 +399,22 @@ int KrylovBase<T>::ew_grid() const {
     return balanced_grid(ctx, workb);
 }
 
-// partial hand-off kernels for the distributed case: reduce up to two partial arrays into `red`
-template <class TA, class TB>
-__global__ __launch_bounds__(BLOCK) void finalize2_kernel(const TA *__restrict__ a, const TB *__restrict__ b, int P,
-                                                          double *__restrict__ ra, double *__restrict__ rb) {
-    __shared__ TA smA[NWAVE];
-    __shared__ TB smB[NWAVE];
-    const TA va = reduce_partials(a, P, smA);
-    if (threadIdx.x == 0) *reinterpret_cast<TA *>(ra) = va;
-    if (b != nullptr) {
-        const TB vb = reduce_partials(b, P, smB);
-        if (threadIdx.x == 0) *reinterpret_cast<TB *>(rb) = vb;
-    }
+// Hand-offs of the distributed case.  The producing launch's last-arriving workgroup has already reduced the partials
+// into `red` (struct Fin / finalize_last_block): all that is left per hand-off is ONE stream operation, the all-reduce.
+template <class T>
+Fin KrylovBase<T>::fin_for(int slot, const void *base0, const void *base1, int P) const {
+    if (!A->dist) return Fin{};
+    Fin f;
+    f.counter = fin_counter + 16 * slot;
+    f.base0 = base0; f.base1 = base1;
+    f.out0 = red + 2 * slot; f.out1 = red + 2 * slot + 2;
+    f.P = P;
+    return f;
 }
-
 template <class T>
 int KrylovBase<T>::red1(const T *a, int P, int slot, PartT *oa) {
     if (!A->dist) { *oa = PartT{a, P}; return SPRS_OK; }
     double *ra = red + 2 * slot;
-    hipLaunchKernelGGL((finalize2_kernel<T, T>), dim3(1), dim3(BLOCK), 0, ctx->stream, a, (const T *)nullptr, P, ra, ra);
-    SPRS_HIP_TRY(ctx, hipGetLastError());
     SPRS_TRY(allreduce_sum(comm(), ra, 16 / sizeof(Real<T>), sizeof(Real<T>) == 4));
     *oa = PartT{reinterpret_cast<const T *>(ra), 1};
     return SPRS_OK;
@@ -419,8 +423,6 @@ template <class T>
 int KrylovBase<T>::red2(const T *a, const T *b, int P, int slot, PartT *oa, PartT *ob) {
     if (!A->dist) { *oa = PartT{a, P}; *ob = PartT{b, P}; return SPRS_OK; }
     double *ra = red + 2 * slot, *rb = red + 2 * slot + 2;
-    hipLaunchKernelGGL((finalize2_kernel<T, T>), dim3(1), dim3(BLOCK), 0, ctx->stream, a, b, P, ra, rb);
-    SPRS_HIP_TRY(ctx, hipGetLastError());
     SPRS_TRY(allreduce_sum(comm(), ra, 32 / sizeof(Real<T>), sizeof(Real<T>) == 4));
     *oa = PartT{reinterpret_cast<const T *>(ra), 1};
     *ob = PartT{reinterpret_cast<const T *>(rb), 1};
@@ -430,8 +432,6 @@ template <class T>
 int KrylovBase<T>::redD1(const Real<T> *a, int P, int slot, PartD *oa) {
     if (!A->dist) { *oa = PartD{a, P}; return SPRS_OK; }
     double *ra = red + 2 * slot;
-    hipLaunchKernelGGL((finalize2_kernel<Real<T>, Real<T>>), dim3(1), dim3(BLOCK), 0, ctx->stream, a, (const Real<T> *)nullptr, P, ra, ra);
-    SPRS_HIP_TRY(ctx, hipGetLastError());
     SPRS_TRY(allreduce_sum(comm(), ra, 16 / sizeof(Real<T>), sizeof(Real<T>) == 4));
     *oa = PartD{reinterpret_cast<const Real<T> *>(ra), 1};
     return SPRS_OK;
@@ -440,8 +440,6 @@ template <class T>
 int KrylovBase<T>::redDT(const Real<T> *a, const T *b, int P, int slot, PartD *oa, PartT *ob) {
     if (!A->dist) { *oa = PartD{a, P}; *ob = PartT{b, P}; return SPRS_OK; }
     double *ra = red + 2 * slot, *rb = red + 2 * slot + 2;
-    hipLaunchKernelGGL((finalize2_kernel<Real<T>, T>), dim3(1), dim3(BLOCK), 0, ctx->stream, a, b, P, ra, rb);
-    SPRS_HIP_TRY(ctx, hipGetLastError());
     SPRS_TRY(allreduce_sum(comm(), ra, 32 / sizeof(Real<T>), sizeof(Real<T>) == 4));
     *oa = PartD{reinterpret_cast<const Real<T> *>(ra), 1};
     *ob = PartT{reinterpret_cast<const T *>(rb), 1};
@@ -449,7 +447,7 @@ int KrylovBase<T>::redDT(const Real<T> *a, const T *b, int P, int slot, PartD *o
 }
 
 template <class T>
-int KrylovBase<T>::spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, const int *status, bool conj_x) {
+int KrylovBase<T>::spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, const int *status, bool conj_x, const Fin *fin) {
     if (A->dist) {
         // the SpMV input needs its halo tail filled: work vectors have room for it, a caller's
         // vector (initial residual, restart) is staged through `xext`
@@ -462,8 +460,8 @@ int KrylovBase<T>::spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, con
         x = xe;
     }
     auto run = [&]() -> int {
-        if (A->dist) return dist_spmv<T>(A, const_cast<T *>(x), y, dot, u, p0, p1, status, conj_x);
-        return launch_spmv<T>(A, x, y, dot, u, p0, p1, status, conj_x);
+        if (A->dist) return dist_spmv<T>(A, const_cast<T *>(x), y, dot, u, p0, p1, status, conj_x, fin);
+        return launch_spmv<T>(A, x, y, dot, u, p0, p1, status, conj_x, fin);
     };
     if (!profile) return run();
     if (ev_used + 2 > ev.size()) {
@@ -616,20 +614,23 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
     typename KrylovBase<T>::PartT qB{partB, GS}, qTT{partTT, GS}, qTR{partTR, GS}, qRho{partRho, G};
     typename KrylovBase<T>::PartD qN{partN, G};
     auto K2 = [&]() -> int {                                                                 // :93/:160  v = A y ; r0.v
-        SPRS_TRY(this->spmv(y, v, 1, r0, partB, nullptr, d_status));
+        const Fin f = this->fin_for(0, partB, nullptr, GS);
+        SPRS_TRY(this->spmv(y, v, 1, r0, partB, nullptr, d_status, false, &f));
         return this->red1(partB, GS, 0, &qB);
     };
     auto K3 = [&](int check) -> int {
-        if (pc) return launch_fused<T>(c, n, G, cw, BicgK3<T, V, true>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()}, 1);
-        return launch_fused<T>(c, n, G, cw, BicgK3<T, V, false>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()}, 1);
+        if (pc) return launch_fused<T>(c, n, G, cw, BicgK3<T, V, true>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()});
+        return launch_fused<T>(c, n, G, cw, BicgK3<T, V, false>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()});
     };
     auto K4 = [&]() -> int {                                                                 // :104/:175 t = A s ; t.t, t.r
-        SPRS_TRY(this->spmv(sz, t, 2, r, partTT, partTR, d_status));
+        const Fin f = this->fin_for(1, partTT, partTR, GS);
+        SPRS_TRY(this->spmv(sz, t, 2, r, partTT, partTR, d_status, false, &f));
         return this->red2(partTT, partTR, GS, 1, &qTT, &qTR);
     };
     auto K5 = [&]() -> int {
-        if (pc) SPRS_TRY(launch_fused<T>(c, n, G, cw, BicgK5<T, true>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()}, 2));
-        else SPRS_TRY(launch_fused<T>(c, n, G, cw, BicgK5<T, false>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, T(), T(), T(), 0.0, T()}, 2));
+        const Fin f = this->fin_for(3, partN, partRho, G);
+        if (pc) SPRS_TRY(launch_fused<T>(c, n, G, cw, BicgK5<T, true>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, f, T(), T(), T(), 0.0, T()}));
+        else SPRS_TRY(launch_fused<T>(c, n, G, cw, BicgK5<T, false>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, f, T(), T(), T(), 0.0, T()}));
         return this->redDT(partN, partRho, G, 3, &qN, &qRho);
     };
     auto K1 = [&](int mode) -> int {
@@ -918,15 +919,16 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> t
             if (pc) { T *tp = w; w = w_new; w_new = tp; }                    // :259,264-265
             const T *q = pc ? w : v;                                         // operand of A and source of p
             // M1: v_new = A q (CSMINRES: A conj(q)) ; alpha = conj(q).v_new   (:116 / :271 / cs:99-103)
-            SPRS_TRY(this->spmv(q, v_new, 1, q, partAlpha, nullptr, d_status, sau));
+            const Fin fA = this->fin_for(0, partAlpha, nullptr, GS);
+            SPRS_TRY(this->spmv(q, v_new, 1, q, partAlpha, nullptr, d_status, sau, &fA));
             typename KrylovBase<T>::PartT qA, qB2{partBeta2, G};
             typename KrylovBase<T>::PartD qBt{partBeta, G};
             SPRS_TRY(this->red1(partAlpha, GS, 0, &qA));
             if (pc) {
-                SPRS_TRY(launch_fused<T>(c, n, G, cw, MinresM2<T, V, true>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, T(), T(), 0.0, T()}));
+                SPRS_TRY(launch_fused<T>(c, n, G, cw, MinresM2<T, V, true>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, this->fin_for(1, partBeta2, nullptr, G), T(), T(), 0.0, T()}));
                 SPRS_TRY(this->red1(partBeta2, G, 1, &qB2));
             } else {
-                SPRS_TRY(launch_fused<T>(c, n, G, cw, MinresM2<T, V, false>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, T(), T(), 0.0, T()}));
+                SPRS_TRY(launch_fused<T>(c, n, G, cw, MinresM2<T, V, false>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, this->fin_for(1, partBeta, nullptr, G), T(), T(), 0.0, T()}));
                 SPRS_TRY(this->redD1(partBeta, G, 1, &qBt));
             }
             { T *tp = p_oold; p_oold = p_old; p_old = p; p = tp; }           // :151-154

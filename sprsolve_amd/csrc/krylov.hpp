@@ -53,6 +53,7 @@ class KrylovBase {
     SolverStats stats;
     // distributed operator (A->dist): all-reduced scalars live in `red`, 16-byte slots
     double *red = nullptr;       // device, 32 doubles
+    unsigned int *fin_counter = nullptr;   // device: arrival counters of the in-launch finalizes (struct Fin), one per slot
     T *xext = nullptr;           // extended copy of a caller vector that has no halo tail
 
     int init(const sprs_csr *A_, size_t size, int nvec_);
@@ -60,7 +61,9 @@ class KrylovBase {
     T *vec(int i) { return work + (size_t)i * stride; }
     T *pslot(int s) { return part + (size_t)s * MAX_GRID; }
     Real<T> *dslot(int s) { return partD + (size_t)s * MAX_GRID; }
-    int spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, const int *status, bool conj_x = false);
+    int spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, const int *status, bool conj_x = false, const sprs::Fin *fin = nullptr);
+    // distributed: descriptor that makes the producing launch reduce its partials into red[2*slot ..] (empty otherwise)
+    sprs::Fin fin_for(int slot, const void *base0, const void *base1, int P) const;
     int begin_solve();
     int end_solve();
     void trace_row(double a0, double a1, T b, T c, T d);
@@ -70,8 +73,9 @@ class KrylovBase {
     int ew_grid() const;  // workgroups used by the fused element-wise kernels for this n
     sprs_comm *comm() const { return A->dist ? A->dist->comm : nullptr; }
     // Hand a producer's partials to its consumer kernel.  Single GPU: the consumer re-reduces the
-    // P partials itself.  Distributed: reduce locally (fixed order), all-reduce over the ranks, and
-    // the consumer reads one value.  `slot` picks a 16-byte cell of `red`.
+    // P partials itself.  Distributed: the producer's last workgroup has reduced them into `red`
+    // (fixed order; fin_for), these all-reduce over the ranks, and the consumer reads one value.
+    // `slot` picks a 16-byte cell of `red`.
     struct PartT { const T *p; int P; };
     struct PartD { const Real<T> *p; int P; };
     int red1(const T *a, int P, int slot, PartT *oa);

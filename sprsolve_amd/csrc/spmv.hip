@@ -12,7 +12,7 @@
 //    row with coalesced loads, 64-lane __shfl_down butterfly.  Sums are re-associated
 //    (documented tolerance: relative 1e-13 of sum |x*val|).
 //  * Row blocks are computed once at handle creation (the analogue of mkl_sparse_optimize,
-//    src/mkl_mat.rs:81-148).  The grid is persistent (<= ctx->grid workgroups) and, with
+//    src/mkl_mat.rs:81-148).  The grid is persistent (4 workgroups per CU) and, with
 //    xcd_chunk, each XCD walks its own contiguous chunk of row blocks so the x-gather of
 //    neighbouring rows hits that XCD's L2.
 //  * Optional fused epilogue: per-workgroup partials of conj(u).y, or of conj(y).y and
@@ -24,8 +24,6 @@
 namespace sprs {
 
 struct BlkDescHost { int32_t ra, rb, pa, nn; };   // == BlkDesc (device side)
-
-int build_schedule(sprs_csr *A, const std::vector<int32_t> &blk);
 
 // Host-side analysis: greedy partition of the rows into blocks (see header comment).
 int build_rowblocks(sprs_csr *A, const int32_t *rp) {
@@ -76,7 +74,7 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
             const int L = d.nn / rows;
             bool eq = L >= 1 && L <= 0x7fff;
             for (int r = d.ra; eq && r < d.rb; ++r) eq = rp[r + 1] - rp[r] == L;
-            if (eq) { d.rb = (int32_t)((uint32_t)d.rb | UNI2); d.nn = d.nn | (L << 16); }
+            if (eq) { d.rb = (int32_t)((uint32_t)d.rb | UNI2); d.nn = d.nn | (L << 16); A->n_eq_blocks++; }
         }
         if (A->nrows < (1 << 30) && c->spmv_eqrows != 0) {
             SPRS_HIP_TRY(c, hipMalloc(&A->blk_desc_eq, sizeof(BlkDescHost) * (desc.size() ? desc.size() : 1)));
@@ -88,38 +86,19 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
     SPRS_HIP_TRY(c, hipMalloc((void **)&A->rowblk, blk.size() * sizeof(int32_t)));
     SPRS_HIP_TRY(c, hipMemcpyAsync(A->rowblk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    SPRS_TRY(build_schedule(A, blk));
     bool has_vec = false;
     for (int b = 0; b < A->n_rowblk; ++b) has_vec |= ((uint32_t)blk[b] & VEC_FLAG) != 0;
     return build_dict(A, has_vec, blk, rp);   // dictionary-compressed stream when the matrix qualifies (spmv_dict.hip)
 }
 
-// streaming (read-once) loads: keep the matrix stream from evicting the gathered x lines
-template <bool NT, class U>
-__device__ __forceinline__ U ld_stream(const U *p) {
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
-}
-__device__ __forceinline__ cplx ld_stream_c(const cplx *p, bool nt) {
-    if (nt) return cplx{__builtin_nontemporal_load(&p->re), __builtin_nontemporal_load(&p->im)};
-    return *p;
-}
-template <bool NT> __device__ __forceinline__ double ld_val(const double *p) { return ld_stream<NT>(p); }
-template <bool NT> __device__ __forceinline__ cplx ld_val(const cplx *p) { return ld_stream_c(p, NT); }
-template <bool NT> __device__ __forceinline__ float ld_val(const float *p) { return ld_stream<NT>(p); }
-template <bool NT> __device__ __forceinline__ cplxf ld_val(const cplxf *p) {
-    if (NT) return cplxf{__builtin_nontemporal_load(&p->re), __builtin_nontemporal_load(&p->im)};
-    return *p;
-}
-
-template <class T, int DOT, bool CONJX, bool NT>
+template <class T, int DOT, bool CONJX>
 __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk, int eq_desc, const BlkDesc *__restrict__ desc,
                                                      const int32_t *__restrict__ order,
                                                      const int32_t *__restrict__ row_ptr,
                                                      const int32_t *__restrict__ col_idx, const T *__restrict__ val,
                                                      const T *__restrict__ x, T *__restrict__ y,
                                                      const T *__restrict__ u, T *__restrict__ part0,
-                                                     T *__restrict__ part1, const int *__restrict__ status) {
+                                                     T *__restrict__ part1, const int *__restrict__ status, const Fin fin) {
     constexpr int CAP = nnz_cap<T>::value;      // per wavefront
     constexpr int ITEMS = CAP / WAVE;
     __shared__ T prod_all[NWAVE][CAP];
@@ -182,8 +161,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
 #pragma unroll
                 for (int i = 0; i < ITEMS; ++i) {
                     const int k = min(lane + i * WAVE, last);
-                    cidx[i] = ld_stream<NT>(col_idx + pa + k);
-                    vv[i] = ld_val<NT>(val + pa + k);
+                    cidx[i] = col_idx[pa + k];
+                    vv[i] = val[pa + k];
                 }
 #pragma unroll
                 for (int i = 0; i < ITEMS; ++i) xg[i] = x[cidx[i]];
@@ -218,7 +197,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
             const int r = ra;
             const int s = row_ptr[r], e = row_ptr[r + 1];
             T acc = szero<T>();
-            for (int k = s + lane; k < e; k += WAVE) { const int cj = ld_stream<NT>(col_idx + k); const T vj = ld_val<NT>(val + k); acc = sadd(acc, smul(CONJX ? sconj(x[cj]) : x[cj], vj)); }
+            for (int k = s + lane; k < e; k += WAVE) { const int cj = col_idx[k]; const T vj = val[k]; acc = sadd(acc, smul(CONJX ? sconj(x[cj]) : x[cj], vj)); }
             acc = wave_sum(acc);
             if (lane == 0) {
                 y[r] = acc;
@@ -230,12 +209,13 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
     if (run_state != ST_RUNNING) return;           // a wavefront that had no row block comes straight here
     if (DOT >= 1) {
         d0 = block_sum(d0, red);
-        if (tid == 0) part0[blockIdx.x] = d0;
+        if (tid == 0) st_partial(fin, part0 + blockIdx.x, d0);
     }
     if (DOT == 2) {
         d1 = block_sum(d1, red);
-        if (tid == 0) part1[blockIdx.x] = d1;
+        if (tid == 0) st_partial(fin, part1 + blockIdx.x, d1);
     }
+    if (DOT >= 1 && fin.counter) finalize_last_block<T, T>(fin, DOT == 2, red, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -300,85 +280,6 @@ int rowblk_spans(const sprs_csr *A, std::vector<int32_t> &lo, std::vector<int32_
     return SPRS_OK;
 }
 
-// Interleave `blocks` (row-block ids, ascending) so that schedule position j — which the persistent walk
-// gives to a workgroup on XCD j mod 8 — holds a block of row group (row_start / (P/8)) mod 8 == j mod 8.
-std::vector<int32_t> place_on_xcds(const std::vector<int32_t> &blocks, const std::vector<int64_t> &row_start, int64_t P) {
-    const int64_t G = std::max<int64_t>(P / 8, 1);
-    std::vector<std::vector<int32_t>> q(8);
-    for (int32_t b : blocks) q[(size_t)((row_start[(size_t)b] / G) % 8)].push_back(b);
-    std::vector<int32_t> order(blocks.size());
-    size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0}, filled = 0;
-    while (filled < blocks.size()) {
-        for (int x = 0; x < 8 && filled < blocks.size(); ++x) {
-            int src = x;
-            if (pos[src] >= q[src].size()) {          // this XCD's queue ran dry: take from the longest one
-                size_t best = 0;
-                for (int y = 0; y < 8; ++y)
-                    if (q[y].size() - pos[y] > best) { best = q[y].size() - pos[y]; src = y; }
-            }
-            order[filled++] = q[src][pos[src]++];
-        }
-    }
-    return order;
-}
-
-int build_schedule(sprs_csr *A, const std::vector<int32_t> &blk) {
-    sprs_ctx *c = A->ctx;
-    const int nb = A->n_rowblk;
-    int strip = c->spmv_strip;
-    if (strip == 0 || nb < 64 || A->nnz == 0) return SPRS_OK;
-    std::vector<int32_t> lo, hi;
-    SPRS_TRY(rowblk_spans(A, lo, hi));
-    // period = typical reach of the far band: median over blocks of max(row_start - lo, hi - row_end)
-    std::vector<int64_t> reach;
-    reach.reserve(nb);
-    for (int b = 0; b < nb; ++b) {
-        const int64_t ra = (int64_t)((uint32_t)blk[b] & ~VEC_FLAG), rb = (int64_t)((uint32_t)blk[b + 1] & ~VEC_FLAG);
-        if (hi[b] < 0) continue;
-        reach.push_back(std::max<int64_t>(std::max<int64_t>(ra - lo[b], (int64_t)hi[b] - (rb - 1)), 0));
-    }
-    if (reach.size() < 64) return SPRS_OK;
-    std::nth_element(reach.begin(), reach.begin() + reach.size() / 2, reach.end());
-    const int64_t P = reach[reach.size() / 2];
-    const size_t sT = dtype_size(A->dtype);
-    std::vector<int32_t> order(nb);
-    if (strip == -1 || strip == 1) {
-        // ---- XCD-period placement (experimental).
-        // Workgroup w runs on XCD w mod 8 (observed round-robin dispatch; a locality hint only) and, in the
-        // persistent walk, processes schedule positions w, w + grid, ...; so position j belongs to XCD j mod 8.
-        // Rows are cut into groups of P/8 rows and group g is given to XCD g mod 8: rows r and r +- P then
-        // live on the SAME XCD, one group apart in that XCD's own sequence, so the far-band x entries a group
-        // gathers are exactly the lines its XCD fetched for the previous group / will reuse for the next one.
-        // x then crosses the fabric about once instead of ~5.5 times, while all XCDs still sweep the matrix
-        // front to back together (the (col_idx, val) stream stays 8 contiguous runs).
-        if ((double)P * sT < 256.0 * 1024 || P * 3 > A->nrows) return SPRS_OK;   // no far band worth placing
-        std::vector<int32_t> all(nb);
-        for (int b = 0; b < nb; ++b) all[b] = b;
-        std::vector<int64_t> rs(nb);
-        for (int b = 0; b < nb; ++b) rs[b] = (int64_t)((uint32_t)blk[b] & ~VEC_FLAG);
-        A->blk_row_start = rs;
-        order = place_on_xcds(all, rs, P);
-    } else {
-        // ---- strip-major walk (experimental, measured slower: profiles/r01_tuning.md)
-        if (P < 2 * (int64_t)strip) return SPRS_OK;
-        std::vector<std::pair<uint64_t, int32_t>> key(nb);
-        const uint64_t nper = (uint64_t)(A->nrows / P + 2);
-        for (int b = 0; b < nb; ++b) {
-            const uint64_t r = (uint64_t)((uint32_t)blk[b] & ~VEC_FLAG);
-            const uint64_t k = r / (uint64_t)P, o = r % (uint64_t)P;
-            key[b] = {((o / (uint64_t)strip) * nper + k) * (uint64_t)strip + (o % (uint64_t)strip), b};
-        }
-        std::sort(key.begin(), key.end());
-        for (int b = 0; b < nb; ++b) order[b] = key[b].second;
-    }
-    SPRS_HIP_TRY(c, hipMalloc((void **)&A->blk_order, sizeof(int32_t) * nb));
-    SPRS_HIP_TRY(c, hipMemcpyAsync(A->blk_order, order.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, c->stream));
-    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    A->sched_period = P;
-    A->sched_strip_major = !(strip == -1 || strip == 1);
-    return SPRS_OK;
-}
-
 // number of workgroups launch_spmv uses == number of partials it writes
 // Matrices whose whole stream fits the 256 MiB Infinity Cache behave differently from HBM-bound ones
 // (profiles/r01_tuning.md): they want one contiguous chunk of row blocks per XCD (x stays in that XCD's
@@ -415,28 +316,23 @@ int spmv_subset_grid(const sprs_csr *A, int count) { return grid_for_blocks(A, c
 bool fused_chunked(const sprs_csr *A) {
     const sprs_ctx *c = A->ctx;
     if (c->ew_chunk >= 0) return c->ew_chunk != 0;
-    if (A->dist || A->blk_order || c->xcd_chunk == 0 || !is_cache_resident(A)) return false;
+    if (A->dist || c->xcd_chunk == 0 || !is_cache_resident(A)) return false;
     return A->dict && A->dict->max_off >= 0 && A->dict->max_off * 32 <= (int64_t)A->nrows;
 }
 
 template <class T>
 static int launch_spmv_impl(const sprs_csr *A, const int32_t *order, int count, int g, const T *x, T *y, int dot_mode,
-                            const T *u, T *part0, T *part1, const int *status, bool conj_x) {
+                            const T *u, T *part0, T *part1, const int *status, bool conj_x, const Fin *finp) {
+    const Fin fin = (finp && dot_mode != 0) ? *finp : Fin{};
     sprs_ctx *c = A->ctx;
     const T *v = reinterpret_cast<const T *>(A->val);
-    const bool cache_resident = is_cache_resident(A);
-    // a scheduled matrix wants each XCD on its own contiguous run of the schedule (that is what makes
-    // the far-band x entries hit in that XCD's L2) and the read-once stream kept out of L2
-    // (the XCD-period schedule encodes its placement in the order array and needs the round-robin walk)
-    const bool sched = A->blk_order != nullptr;
-    const int xcd_chunk = sched ? (A->sched_strip_major ? 1 : 0) : (c->xcd_chunk < 0 ? (cache_resident ? 1 : 0) : c->xcd_chunk);
+    // cache-resident matrices: one contiguous chunk of row blocks per XCD; HBM-bound ones: round-robin (see above)
+    const int xcd_chunk = c->xcd_chunk < 0 ? (is_cache_resident(A) ? 1 : 0) : c->xcd_chunk;
     if (const int dm = dict_mode(A))
-        return launch_spmv_dict<T>(A, dm, order, count, g, xcd_chunk, x, y, dot_mode, u, part0, part1, status, conj_x);
-    const bool nt = c->spmv_nt > 0;   // measured: non-temporal stream loads never pay once the loads are batched
-#define SPRS_SPMV2(D, CJ, NTF)                                                                                        \
-    SPRS_LAUNCH_SPMV(c, (spmv_kernel<T, D, CJ, NTF>), g, count,                                                       \
-                       xcd_chunk, A->blk_desc_eq ? 1 : 0, reinterpret_cast<const BlkDesc *>(A->blk_desc_eq ? A->blk_desc_eq : A->blk_desc), order, A->row_ptr, A->col_idx, v, x, y, u, part0, part1, status)
-#define SPRS_SPMV(D, CJ) do { if (nt) SPRS_SPMV2(D, CJ, true); else SPRS_SPMV2(D, CJ, false); } while (0)
+        return launch_spmv_dict<T>(A, dm, order, count, g, xcd_chunk, x, y, dot_mode, u, part0, part1, status, conj_x, fin);
+#define SPRS_SPMV(D, CJ)                                                                                              \
+    SPRS_LAUNCH_SPMV(c, (spmv_kernel<T, D, CJ>), g, count,                                                            \
+                       xcd_chunk, A->blk_desc_eq ? 1 : 0, reinterpret_cast<const BlkDesc *>(A->blk_desc_eq ? A->blk_desc_eq : A->blk_desc), order, A->row_ptr, A->col_idx, v, x, y, u, part0, part1, status, fin)
     if (conj_x && is_complex<T>::value) {  // only CSMINRES on complex data needs the conjugated gather
         if (dot_mode == 0) SPRS_SPMV(0, true);
         else if (dot_mode == 1) SPRS_SPMV(1, true);
@@ -446,7 +342,6 @@ static int launch_spmv_impl(const sprs_csr *A, const int32_t *order, int count, 
         else if (dot_mode == 1) SPRS_SPMV(1, false);
         else SPRS_SPMV(2, false);
     }
-#undef SPRS_SPMV2
 #undef SPRS_SPMV
     SPRS_HIP_TRY(c, hipGetLastError());
     return SPRS_OK;
@@ -454,14 +349,14 @@ static int launch_spmv_impl(const sprs_csr *A, const int32_t *order, int count, 
 
 template <class T>
 int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status,
-                bool conj_x) {
-    return launch_spmv_impl<T>(A, A->blk_order, (int)A->n_rowblk, spmv_grid(A), x, y, dot_mode, u, part0, part1, status, conj_x);
+                bool conj_x, const Fin *fin) {
+    return launch_spmv_impl<T>(A, nullptr, (int)A->n_rowblk, spmv_grid(A), x, y, dot_mode, u, part0, part1, status, conj_x, fin);
 }
 
 template <class T>
 int launch_spmv_subset(const sprs_csr *A, const int32_t *order, int count, const T *x, T *y, int dot_mode, const T *u,
-                       T *part0, T *part1, const int *status, bool conj_x) {
-    return launch_spmv_impl<T>(A, order, count, grid_for_blocks(A, count), x, y, dot_mode, u, part0, part1, status, conj_x);
+                       T *part0, T *part1, const int *status, bool conj_x, const Fin *fin) {
+    return launch_spmv_impl<T>(A, order, count, grid_for_blocks(A, count), x, y, dot_mode, u, part0, part1, status, conj_x, fin);
 }
 
 // distributed operators with an interior/boundary split run two launches whose partials are concatenated
@@ -471,8 +366,8 @@ int spmv_num_partials(const sprs_csr *A) {
 }
 
 #define SPRS_INST_SPMV(T)                                                                                              \
-    template int launch_spmv<T>(const sprs_csr *, const T *, T *, int, const T *, T *, T *, const int *, bool);        \
-    template int launch_spmv_subset<T>(const sprs_csr *, const int32_t *, int, const T *, T *, int, const T *, T *, T *, const int *, bool);
+    template int launch_spmv<T>(const sprs_csr *, const T *, T *, int, const T *, T *, T *, const int *, bool, const Fin *); \
+    template int launch_spmv_subset<T>(const sprs_csr *, const int32_t *, int, const T *, T *, int, const T *, T *, T *, const int *, bool, const Fin *);
 SPRS_INST_SPMV(double)
 SPRS_INST_SPMV(cplx)
 SPRS_INST_SPMV(float)

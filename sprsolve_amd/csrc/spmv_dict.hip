@@ -76,56 +76,149 @@ __device__ __forceinline__ int probe64(unsigned long long *tab, int *count, uint
     return -1;
 }
 
+// The same insert-or-find on a workgroup's LDS table (no agent-scope traffic: the hot path of the collection pass)
+__device__ __forceinline__ int lds_probe32(uint32_t *tab, int *count, uint32_t key) {
+    uint32_t h = hash32(key) & (HSLOTS - 1);
+    for (int t = 0; t < HSLOTS; ++t, h = (h + 1) & (HSLOTS - 1)) {
+        uint32_t cur = __hip_atomic_load(tab + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (cur == key) return (int)h;
+        if (cur == EMPTY32) {
+            if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > TAB) return -1;
+            cur = atomicCAS(tab + h, EMPTY32, key);
+            if (cur == EMPTY32) { atomicAdd(count, 1); return (int)h; }
+            if (cur == key) return (int)h;
+        }
+    }
+    return -1;
+}
+__device__ __forceinline__ int lds_probe64(unsigned long long *tab, int *count, uint64_t key) {
+    uint32_t h = hash64(key) & (HSLOTS - 1);
+    for (int t = 0; t < HSLOTS; ++t, h = (h + 1) & (HSLOTS - 1)) {
+        uint64_t cur = __hip_atomic_load(tab + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (cur == key) return (int)h;
+        if (cur == EMPTY64) {
+            if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > TAB) return -1;
+            cur = atomicCAS(tab + h, (unsigned long long)EMPTY64, (unsigned long long)key);
+            if (cur == EMPTY64) { atomicAdd(count, 1); return (int)h; }
+            if (cur == key) return (int)h;
+        }
+    }
+    return -1;
+}
+
 // counts[0] = distinct offsets, counts[1] = distinct values, counts[2] = value dictionary impossible
+//
+// Two levels (the analogue of mkl_sparse_optimize must stay cheap next to the solve it prepares, mkl_mat.rs:81-148): a
+// workgroup collects the distinct keys of ITS rows in LDS tables — no agent-scope access per entry — and merges them into
+// the global tables once, at its end: <= 257 inserts per workgroup and dictionary instead of one atomic probe chain per
+// entry (cfg 3: 14.6 ms -> well under 1 ms, profiles/r03_tuning.md).  A table that takes its 257th key is dead, in LDS as
+// in HBM: offsets dead => the workgroup stops (no compressed stream at all); values dead => it stops looking at values.
+// The global tables end up holding the same key SETS as a flat insertion; the codes are assigned on the host in sorted
+// key order, so the dictionaries are identical.
 template <class T, bool VALS>
 __global__ __launch_bounds__(BLOCK) void dict_collect_kernel(int n, const int32_t *__restrict__ row_ptr,
                                                              const int32_t *__restrict__ col_idx, const T *__restrict__ val,
                                                              uint32_t *off_h, unsigned long long *val_h, int *counts) {
+    __shared__ uint32_t s_off[HSLOTS];
+    __shared__ unsigned long long s_val[VALS ? HSLOTS : 1];
+    __shared__ int s_cnt[4];           // [0] offsets, [1] values held by the LDS tables, [2] a value equal to EMPTY64 was seen
+    for (int i = threadIdx.x; i < HSLOTS; i += BLOCK) { s_off[i] = EMPTY32; if (VALS) s_val[i] = EMPTY64; }
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t last_off = EMPTY32;
     uint64_t last_val = EMPTY64;
-    // Once a dictionary has overflowed nothing more can be learnt about it: a matrix with random values kept probing
-    // a dead table for every one of its 349 M entries (884 ms at handle creation, profiles/r02_tuning.md).  The
-    // overflow flags are re-read once per row, not per entry.
-    bool vals_dead = !VALS, offs_dead = false;
-    for (int row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK) {
-        if (!offs_dead && __hip_atomic_load(counts + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > TAB) offs_dead = true;
-        if (offs_dead) return;                      // > 256 offsets: no compressed stream at all
+    bool vals_dead = !VALS;
+    int trip = 0;
+    for (int row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK, ++trip) {
+        // the overflow flags are re-read once per row: this workgroup's (LDS) every time, the chip's every 16th trip
+        if (__hip_atomic_load(s_cnt + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > TAB) break;
+        if ((trip & 15) == 0 && __hip_atomic_load(counts + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > TAB) break;
         if constexpr (VALS) {
-            if (!vals_dead && (__hip_atomic_load(counts + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > TAB ||
-                               __hip_atomic_load(counts + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) vals_dead = true;
+            if (!vals_dead) {
+                vals_dead = __hip_atomic_load(s_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > TAB ||
+                            __hip_atomic_load(s_cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+                if (!vals_dead && (trip & 15) == 0)
+                    vals_dead = __hip_atomic_load(counts + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > TAB ||
+                                __hip_atomic_load(counts + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            }
         }
-        for (int k = row_ptr[row]; k < row_ptr[row + 1]; ++k) {
+        const int ks = row_ptr[row], ke = row_ptr[row + 1];
+        for (int k = ks; k < ke; ++k) {
             const uint32_t d = (uint32_t)(col_idx[k] - row);
-            if (d != last_off) { (void)probe32(off_h, counts + 0, d, true); last_off = d; }
+            if (d != last_off) { (void)lds_probe32(s_off, s_cnt + 0, d); last_off = d; }
             if constexpr (VALS) {
                 if (vals_dead) continue;
                 const uint64_t kv = key_of(val[k]);
-                if (kv == EMPTY64) { counts[2] = 1; continue; }
-                if (kv != last_val) { (void)probe64(val_h, counts + 1, kv, true); last_val = kv; }
+                if (kv == EMPTY64) { s_cnt[2] = 1; continue; }
+                if (kv != last_val) { (void)lds_probe64(s_val, s_cnt + 1, kv); last_val = kv; }
             }
         }
+    }
+    __syncthreads();
+    // ---- merge: every key this workgroup saw goes into the global table once
+    if (s_cnt[0] > TAB) { if (threadIdx.x == 0) atomicMax(counts + 0, TAB + 1); }
+    else
+        for (int i = threadIdx.x; i < HSLOTS; i += BLOCK)
+            if (s_off[i] != EMPTY32) (void)probe32(off_h, counts + 0, s_off[i], true);
+    if constexpr (VALS) {
+        if (s_cnt[2] != 0) { if (threadIdx.x == 0) counts[2] = 1; }
+        else if (s_cnt[1] > TAB) { if (threadIdx.x == 0) atomicMax(counts + 1, TAB + 1); }
+        else
+            for (int i = threadIdx.x; i < HSLOTS; i += BLOCK)
+                if (s_val[i] != EMPTY64) (void)probe64(val_h, counts + 1, s_val[i], true);
     }
 }
 
+// Encoding pass: the (now read-only) hash tables and the code of every slot are staged in LDS once per workgroup; the
+// per-entry look-ups never leave the CU.
 template <class T, bool VALS>
 __global__ __launch_bounds__(BLOCK) void dict_encode_kernel(int n, const int32_t *__restrict__ row_ptr,
                                                             const int32_t *__restrict__ col_idx, const T *__restrict__ val,
-                                                            uint32_t *off_h, const uint8_t *__restrict__ off_code_of_slot,
-                                                            unsigned long long *val_h, const uint8_t *__restrict__ val_code_of_slot,
+                                                            const uint32_t *__restrict__ off_h, const uint8_t *__restrict__ off_code_of_slot,
+                                                            const unsigned long long *__restrict__ val_h, const uint8_t *__restrict__ val_code_of_slot,
                                                             uint8_t *__restrict__ idx_code, uint8_t *__restrict__ val_code,
                                                             int *__restrict__ bad) {
+    __shared__ uint32_t s_off[HSLOTS];
+    __shared__ uint8_t s_offc[HSLOTS];
+    __shared__ unsigned long long s_val[VALS ? HSLOTS : 1];
+    __shared__ uint8_t s_valc[VALS ? HSLOTS : 1];
+    for (int i = threadIdx.x; i < HSLOTS; i += BLOCK) {
+        s_off[i] = off_h[i]; s_offc[i] = off_code_of_slot[i];
+        if constexpr (VALS) { s_val[i] = val_h[i]; s_valc[i] = val_code_of_slot[i]; }
+    }
+    __syncthreads();
+    auto find32 = [&](uint32_t key) -> int {
+        uint32_t h = hash32(key) & (HSLOTS - 1);
+        for (int t = 0; t < HSLOTS; ++t, h = (h + 1) & (HSLOTS - 1)) {
+            const uint32_t cur = s_off[h];
+            if (cur == key) return (int)h;
+            if (cur == EMPTY32) return -1;
+        }
+        return -1;
+    };
+    [[maybe_unused]] auto find64 = [&](uint64_t key) -> int {
+        uint32_t h = hash64(key) & (HSLOTS - 1);
+        for (int t = 0; t < HSLOTS; ++t, h = (h + 1) & (HSLOTS - 1)) {
+            const uint64_t cur = s_val[h];
+            if (cur == key) return (int)h;
+            if (cur == EMPTY64) return -1;
+        }
+        return -1;
+    };
+    int lbad = 0;
     for (int row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK) {
         for (int k = row_ptr[row]; k < row_ptr[row + 1]; ++k) {
-            const int so = probe32(off_h, nullptr, (uint32_t)(col_idx[k] - row), false);
-            if (so < 0) { *bad = 1; continue; }
-            idx_code[k] = off_code_of_slot[so];
+            const int so = find32((uint32_t)(col_idx[k] - row));
+            if (so < 0) { lbad = 1; continue; }
+            idx_code[k] = s_offc[so];
             if constexpr (VALS) {
-                const int sv = probe64(val_h, nullptr, key_of(val[k]), false);
-                if (sv < 0) { *bad = 1; continue; }
-                val_code[k] = val_code_of_slot[sv];
+                const int sv = find64(key_of(val[k]));
+                if (sv < 0) { lbad = 1; continue; }
+                val_code[k] = s_valc[sv];
             }
         }
     }
+    if (lbad) *bad = 1;
 }
 
 // mark the (offset code, value code) pairs that occur / translate them to pair codes
@@ -155,7 +248,7 @@ template <class T> struct alignas(sizeof(T) >= 8 ? 16 : 8) PairEnt { int32_t off
 template <class T, bool PAIR, int ITEMS>
 struct BlkLoads {
     int ra, rb, pa, nn;      // descriptor (nn = entries of the block, also for uniform blocks)
-    int ulen;                // > 0: uniform block — every row repeats the first row's ulen codes; no row_ptr, 1-3 code dwords
+    int ulen;                // > 0: uniform block — every row repeats the first row's ulen (<= UNI_OFF_MAXLEN) codes; no row_ptr, 1-9 code dwords
     int s;                   // row_ptr[row] of this lane's row
     T uu;                    // dot operand of this lane's row
     uint32_t wc[2];          // code dwords
@@ -172,7 +265,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
                                                           const T *__restrict__ val_tab,          // per pair code: value
                                                           const T *__restrict__ val, const T *__restrict__ x,
                                                           T *__restrict__ y, const T *__restrict__ u, T *__restrict__ part0,
-                                                          T *__restrict__ part1, const int *__restrict__ status) {
+                                                          T *__restrict__ part1, const int *__restrict__ status, const Fin fin) {
     constexpr int CAP = nnz_cap<T>::value;          // nnz per row block (per wavefront)
     constexpr int CW = (CAP + 3 + CPAD + 3) / 4;    // dwords: CAP code bytes at any 4-byte phase + the readable pad
     constexpr int ITEMS = CAP / WAVE;
@@ -247,7 +340,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
         else L.s = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(row_ptr) + (uint32_t)rcl * 4u);   // row_ptr[row + 1] comes from the next lane (adopt)
         if (DOT != 0) L.uu = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(u) + (uint32_t)rcl * (uint32_t)sizeof(T));
         const int shift = L.pa & 3;
-        // dwords covering [pa, pa + nn) (<= CAP/4 + 1) — of a uniform block only the first row's codes: 1-3 dwords
+        // dwords covering [pa, pa + nn) (<= CAP/4 + 1) — of a uniform block only the first row's codes: 1-9 dwords
         const int nd = max((shift + (uni ? L.ulen : L.nn) + 3) >> 2, 1);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -368,12 +461,13 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
     }
     if (DOT >= 1) {
         d0 = block_sum(d0, red);
-        if (tid == 0) part0[blockIdx.x] = d0;
+        if (tid == 0) st_partial(fin, part0 + blockIdx.x, d0);
     }
     if (DOT == 2) {
         d1 = block_sum(d1, red);
-        if (tid == 0) part1[blockIdx.x] = d1;
+        if (tid == 0) st_partial(fin, part1 + blockIdx.x, d1);
     }
+    if (DOT >= 1 && fin.counter) finalize_last_block<T, T>(fin, DOT == 2, red, red);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -628,7 +722,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
                                                            const double *__restrict__ val_tab, const double *__restrict__ x,
                                                            double *__restrict__ y, const double *__restrict__ u,
                                                            double *__restrict__ part0, double *__restrict__ part1,
-                                                           const int *__restrict__ status, int nrows, int ncols) {
+                                                           const int *__restrict__ status, int nrows, int ncols, const Fin fin) {
     using T = double;
     __shared__ PairEnt<T> s_pair[TAB];
     __shared__ __attribute__((aligned(16))) uint32_t s_c[NWAVE][CW2];
@@ -857,12 +951,13 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
     }
     if (DOT >= 1) {
         d0 = block_sum(d0, red);
-        if (tid == 0) part0[blockIdx.x] = d0;
+        if (tid == 0) st_partial(fin, part0 + blockIdx.x, d0);
     }
     if (DOT == 2) {
         d1 = block_sum(d1, red);
-        if (tid == 0) part1[blockIdx.x] = d1;
+        if (tid == 0) st_partial(fin, part1 + blockIdx.x, d1);
     }
+    if (DOT >= 1 && fin.counter) finalize_last_block<T, T>(fin, DOT == 2, red, red);
 }
 
 // XCD-period schedule (knob "spmv_period") of a stream's row blocks.  With the far band P = max |col - row| (a 3-D
@@ -1002,7 +1097,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
         }
     }
     if (c->spmv_uniform != 0 && A->n_rowblk > 0) {
-        // Uniform 64-row blocks of the offset-code stream: all rows repeat the first row's (<= 8) offset codes — the
+        // Uniform 64-row blocks of the offset-code stream: all rows repeat the first row's (<= UNI_OFF_MAXLEN) offset codes — the
         // interior of any stencil or band, whatever its VALUES.  Such a block needs neither row_ptr nor its code bytes
         // (9 B/nnz + 4 B/row -> 8 B/nnz); flagged in a private copy of the descriptors (the plain kernel keeps its own).
         DICT_TRY2(hipMalloc(&D->off_desc, sizeof(BlkDesc) * (size_t)A->n_rowblk));
@@ -1123,17 +1218,14 @@ int dict_mode(const sprs_csr *A) {
         // (cfg-5 pattern, random values: 885 vs 1130 us) and cache-resident ones alike (cfg 3: 21.8 vs 23.9 us, MINRES
         // 21.8 k vs 20.8 k it/s).  Complex ones run slower (cfg 4: 24.7 vs 15.0 us; 17 instead of 20 B/nnz is not worth
         // the lane-per-row layout): auto keeps the plain stream for those.
-        const double sz = (double)dtype_size(A->dtype);
-        const bool cache_resident = (double)A->nnz * (sz + 4) + 3.0 * A->nrows * sz < 192.0 * 1024 * 1024;
         if (dtype_is_complex(A->dtype)) return 0;
-        (void)cache_resident;
     }
     return 1;
 }
 
 template <class T>
 int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int count, int g, int xcd_chunk, const T *x, T *y,
-                     int dot_mode, const T *u, T *part0, T *part1, const int *status, bool conj_x) {
+                     int dot_mode, const T *u, T *part0, T *part1, const int *status, bool conj_x, const Fin &fin) {
     sprs_ctx *c = A->ctx;
     const sprs_dict *D = A->dict;
     const T *v = reinterpret_cast<const T *>(A->val);
@@ -1145,7 +1237,7 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
         // whose split is made on pairs of 64-row blocks for this purpose (dist.hip)
         const int32_t *order_w = nullptr;
         int count_w = -1;
-        if (order == nullptr && count == A->n_rowblk) { count_w = D->n_wide; order_w = c->spmv_period != 0 ? D->wide_order : nullptr; }
+        if (order == nullptr && count == A->n_rowblk) { count_w = D->n_wide; order_w = c->spmv_period != 0 ? D->wide_order : nullptr; if (order_w) xcd_chunk = 0; }   // the period order encodes its XCD placement for the round-robin walk
         else if (A->dist && A->dist->order_int_w && order == A->dist->order_int && count == A->dist->n_int) { order_w = A->dist->order_int_w; count_w = A->dist->n_int_w; }
         else if (A->dist && A->dist->order_bnd_w && order == A->dist->order_bnd && count == A->dist->n_bnd) { order_w = A->dist->order_bnd_w; count_w = A->dist->n_bnd_w; }
         if (pair && D->wide_desc && c->spmv_wide != 0 && count_w >= 0 && A->nrows >= 2 && A->ncols >= 2) {
@@ -1153,7 +1245,7 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
             const BlkDesc *wd = reinterpret_cast<const BlkDesc *>(D->wide_desc);
             const double *pvd = reinterpret_cast<const double *>(D->pair_val);
 #define SPRS_WSPMV(DM, YN) SPRS_LAUNCH_SPMV(c, (spmv_pair2_kernel<DM, YN>), gw, count_w, xcd_chunk, wd, order_w, \
-                                          A->row_ptr, D->pair_code, D->pair_off, pvd, x, y, u, part0, part1, status, (int)A->nrows, (int)A->ncols)
+                                          A->row_ptr, D->pair_code, D->pair_off, pvd, x, y, u, part0, part1, status, (int)A->nrows, (int)A->ncols, fin)
             if (stream_loads_nt(c, (size_t)A->nrows * sizeof(T))) {          // HBM-sized result: non-temporal y stores
                 if (dot_mode == 0) SPRS_WSPMV(0, true); else if (dot_mode == 1) SPRS_WSPMV(1, true); else SPRS_WSPMV(2, true);
             } else {
@@ -1166,13 +1258,13 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
     }
     const uint8_t *code = pair ? D->pair_code : D->idx_code;
     const int32_t *otab = pair ? D->pair_off : D->off_tab;
-    if (!pair && order == nullptr && count == A->n_rowblk && c->spmv_period > 0 && D->off_order) order = D->off_order;
+    if (!pair && order == nullptr && count == A->n_rowblk && c->spmv_period > 0 && D->off_order) { order = D->off_order; xcd_chunk = 0; }
     // the offset-code stream runs on its own descriptors (uniform blocks flagged); same block numbering as blk_desc
     const BlkDesc *dsc = reinterpret_cast<const BlkDesc *>((!pair && D->off_desc && c->spmv_uniform != 0) ? D->off_desc : A->blk_desc);
 #define SPRS_DSPMV2(DM, CJ, PR)                                                                                         \
     SPRS_LAUNCH_SPMV(c, (spmv_dict_kernel<T, DM, CJ, PR>), g, count, xcd_chunk,                                          \
                        dsc, order, A->row_ptr, code, otab, pv, v, x, y, u,                                              \
-                       part0, part1, status)
+                       part0, part1, status, fin)
 #define SPRS_DSPMV(DM, CJ) do { if (pair) SPRS_DSPMV2(DM, CJ, (has_val_dict<T>::value)); else SPRS_DSPMV2(DM, CJ, false); } while (0)
     if (conj_x && is_complex<T>::value) {
         if (dot_mode == 0) SPRS_DSPMV(0, true);
@@ -1190,7 +1282,7 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
 }
 
 #define SPRS_INST_DSPMV(T)                                                                                              \
-    template int launch_spmv_dict<T>(const sprs_csr *, int, const int32_t *, int, int, int, const T *, T *, int, const T *, T *, T *, const int *, bool);
+    template int launch_spmv_dict<T>(const sprs_csr *, int, const int32_t *, int, int, int, const T *, T *, int, const T *, T *, T *, const int *, bool, const Fin &);
 SPRS_INST_DSPMV(double)
 SPRS_INST_DSPMV(cplx)
 SPRS_INST_DSPMV(float)

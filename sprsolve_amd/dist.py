@@ -31,6 +31,13 @@ class Comm:
         pre_sync(dev)
         check(_lib.lib().sprs_comm_allreduce_sum_f64(self.h, dev_ptr(dev), int(count)), self.ctx.h)
 
+    def allreduce_us(self, dev, count=4, reps=200):
+        """Mean microseconds of one in-place all-reduce of `count` doubles on the library's stream (collective)."""
+        pre_sync(dev)
+        us = C.c_double(0.0)
+        check(_lib.lib().sprs_comm_allreduce_timed_f64(self.h, dev_ptr(dev), int(count), int(reps), C.byref(us)), self.ctx.h)
+        return float(us.value)
+
     def count(self):
         """ncclCommCount: how many ranks RCCL itself sees on this communicator."""
         n = C.c_int(0)
@@ -134,7 +141,7 @@ class DistCsr(HipCsr):
         self.ctx.sync()
 
 
-def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, time_solve, exchange="halo"):
+def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, time_marginal, exchange="halo"):
     """N > 1 leg of bench.py: cfg 5 row-partitioned in z-slabs, strong scaling."""
     import sprsolve_amd as sa
     from . import gen_torch
@@ -151,12 +158,17 @@ def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, t
         return out
     comm = Comm(ctx, rank, world, tdist)
     # the plan is built by the library (device passes + RCCL), partition.py only names the row ranges
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     A = DistCsr.from_global(comm, starts, nnz_loc, ip, ix, dv, exchange=exchange, adopt=True)
+    torch.cuda.synchronize()
+    create_ms = (time.perf_counter() - t0) * 1e3        # plan (device passes + RCCL exchanges) + handle (row blocks, dictionaries)
     plan = A.plan
     n_loc = plan["n_local"]
     s = sa.BiCGStab.new(A, n_loc)
     x = torch.zeros(n_loc, dtype=torch.float64, device=dev)
-    dt, prof = time_solve(torch, tdist, s, None, rhs, x, steps, warmup, world)
+    ms_step, dt, prof, trec = time_marginal(torch, tdist, s, None, rhs, x, steps, warmup, world)
     t_spmv = prof["spmv_ms_total"] / max(prof["spmv_launches"], 1) * 1e-3
     bs = nnz_loc * 12 + (n_loc + 1) * 4 + 2 * n_loc * 8
     x.zero_()
@@ -174,16 +186,21 @@ def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, t
     sinfo = dict(stream={0: "csr", 1: "offset-codes", 2: "pair-codes"}[mode], mode=mode, distinct_offsets=n_off,
                  distinct_pairs=n_pair, bytes_per_nnz=per_nnz,
                  format_bytes_per_launch=nnz_loc * per_nnz + (n_loc + 1) * 4 + 2 * n_loc * 8, rows=n_loc, nnz=nnz_loc)
-    if mode != 0:
-        nb, nu = A.wide_blocks()
-        uf = nu / nb if nb else 0.0
-        sinfo.update(row_blocks=nb, uniform_blocks=nu,
-                     compulsory_bytes_per_launch=int(nnz_loc * (per_nnz - 1) + (1.0 - uf) * (nnz_loc + (n_loc + 1) * 4) + 2 * n_loc * 8))
+    nb, nu = A.wide_blocks()
+    uf = nu / nb if nb else 0.0
+    code_b = 0 if mode == 0 else 1
+    sinfo.update(row_blocks=nb, descriptor_only_blocks=nu,
+                 bytes_moved_per_launch=int(nnz_loc * (per_nnz - code_b) + (1.0 - uf) * (nnz_loc * code_b + (n_loc + 1) * 4) + 2 * n_loc * 8))
     # evidence that the collectives really span `world` ranks, and what each rank moves per SpMV
     halo_b = int(plan["recv_entries"]) * 8
     send_b = int(plan["send_entries"]) * 8
     per_rank = gather(dict(rank=rank, rccl_ranks=comm.count(), halo_recv_bytes=halo_b, halo_send_bytes=send_b,
                            peers=[int(p) for p in plan["peers"]], rows=n_loc, nnz=nnz_loc))
+    # what one dot-product hand-off costs on this communicator: an all-reduce of 4 doubles on the solver's stream
+    scratch = torch.zeros(4, dtype=torch.float64, device=dev)
+    ar_us = comm.allreduce_us(scratch, 4, 200)
     dist_info = dict(rccl_ranks=min(p["rccl_ranks"] for p in per_rank), exchange=exchange,
-                     halo_bytes=[p["halo_recv_bytes"] for p in per_rank], per_rank=per_rank)
+                     halo_bytes=[p["halo_recv_bytes"] for p in per_rank], allreduce_us=ar_us,
+                     allreduce_note="mean of 200 back-to-back ncclAllReduce(4 x f64) on the solver's stream; a BiCGStab iteration has 3",
+                     per_rank=per_rank, ms_per_step=ms_step, timing=trec, create_ms=create_ms)
     return dt, prof, t_spmv, bs, check_, nx * ny * nz, int(tot), sinfo, dist_info

@@ -39,6 +39,27 @@ def main(rank, world, port, kind, outdir, exchange="halo"):
         return out
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     comm = sdist.Comm(ctx, rank, world, tdist)
+    if exchange in ("halo_bad", "allgather_bad"):
+        # ONE rank holds an out-of-range column: the plan builder is collective, so EVERY rank must come back with
+        # SPRS_INVALID_ARGUMENT (none may be left waiting in an exchange) and no rank's adopted column array may have
+        # been renumbered.  A well-formed creation on the same communicator must still work afterwards.
+        ixb = np.array(ix, copy=True)
+        if rank == world - 1:
+            ixb[ixb.size // 2] = n + 7
+        col_dev = t(ixb)
+        try:
+            sdist.DistCsr.from_global(comm, starts, int(ip[-1]), t(ip), col_dev, t(d), exchange=exchange[:-4], adopt=True)
+            status = 0
+        except ValueError:
+            status = 7
+        untouched = bool(np.array_equal(col_dev.cpu().numpy(), ixb))
+        col2 = t(ix)
+        A2 = sdist.DistCsr.from_global(comm, starts, int(ip[-1]), t(ip), col2, t(d), exchange=exchange[:-4], adopt=True)
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), status=status, untouched=untouched, n_ext=A2.plan["n_ext"])
+        tdist.barrier()
+        comm.close()
+        tdist.destroy_process_group()
+        return
     if exchange in ("halo_c", "allgather_c"):
         # the plan builder behind the C ABI (csrc/dist.hip) against partition.py's plan of the same row block
         ref = (partition.build_plan(np.asarray(ix), starts, rank, gather) if exchange == "halo_c"

@@ -76,6 +76,18 @@ def test_real_ranks_match_single_process(oracle, mock_lib, world, kind, exchange
         assert len({int(r["its_pc"]) for r in res}) == 1
 
 
+@pytest.mark.parametrize("world,exchange", [(2, "halo_bad"), (3, "halo_bad"), (3, "allgather_bad")])
+def test_plan_builder_errors_are_collective(mock_lib, world, exchange):
+    """sprs_dist_csr_create_global_dev_* with a malformed row block on ONE rank (csrc/dist.hip, "collective error
+    contract"): every rank returns SPRS_INVALID_ARGUMENT together — the workers would hang in the counts all-gather or the
+    index send/recv otherwise (the 300 s limit of _run) — the adopted column arrays are left as they were, and the
+    communicator is still usable for a well-formed creation."""
+    res = _run(world, "poisson3d", mock_lib, exchange)
+    assert [int(r["status"]) for r in res] == [7] * world
+    assert all(bool(r["untouched"]) for r in res)
+    assert all(int(r["n_ext"]) > 0 for r in res)
+
+
 def test_bench_launches_its_own_ranks(mock_lib):
     """`python bench.py --gpus 2` with NO launcher around it (how the driver starts the scaling bench): the parent
     must start the two ranks itself, relay rank 0's one JSON line and return 0.  Two ranks share this box's single GPU

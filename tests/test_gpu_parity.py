@@ -142,7 +142,7 @@ def test_spmv_device_vectors_and_grid_options(sa, oracle):
     g0, c0, s0 = ctx.get("grid"), ctx.get("xcd_chunk"), ctx.get("spmv_grid")
     try:
         for grid, chunk in ((g0, 1), (g0, 0), (8, 1), (64, 0), (2048, 1), (1024, -1)):
-            ctx.set("spmv_grid", grid); ctx.set("grid", min(grid, 2048)); ctx.set("xcd_chunk", chunk); ctx.set("spmv_nt", chunk)
+            ctx.set("spmv_grid", grid); ctx.set("grid", min(grid, 2048)); ctx.set("xcd_chunk", chunk)
             dx = sa.DevVec.from_numpy(x); dy = sa.DevVec(n, np.float64); dy.upload(np.full(n, np.nan))
             A.mul_vec_unchecked(dx, dy)
             assert np.array_equal(bits(dy.to_numpy()), bits(ref)), (grid, chunk)
@@ -150,7 +150,53 @@ def test_spmv_device_vectors_and_grid_options(sa, oracle):
             e = oracle.conj_dot(x, ref)
             assert abs(d - e) <= RED_RTOL * np.sum(np.abs(x * ref))
     finally:
-        ctx.set("grid", g0); ctx.set("xcd_chunk", c0); ctx.set("spmv_grid", s0); ctx.set("spmv_nt", -1)
+        ctx.set("grid", g0); ctx.set("xcd_chunk", c0); ctx.set("spmv_grid", s0)
+
+
+def test_eqrows_poll_and_chunk_knobs(sa, oracle):
+    """The three knobs no other test turns: spmv_eqrows (plain stream: equal-length blocks take their extents from the
+    descriptor — read at creation; y bit-identical either way), poll (how often the host looks at the status word: the
+    iterates cannot depend on it), ew_chunk (XCD-chunked walk of the fused kernels: groups the reductions' partials
+    differently, nothing else)."""
+    from sprsolve_amd import gen
+    R = 96
+    indptr, indices, data = gen.grid_laplacian_dirichlet(R, R)
+    rhs = gen.dirichlet_rhs(R, R)
+    n = R * R
+    x = rand_vec(n, np.float64, 17)
+    ref = oracle.spmv(indptr, indices, data, x)
+    ctx = sa.default_ctx()
+    e0, p0, c0, d0 = ctx.get("spmv_eqrows"), ctx.get("poll"), ctx.get("ew_chunk"), ctx.get("spmv_dict")
+    try:
+        ctx.set("spmv_dict", 0)
+        for eq in (0, 1):
+            ctx.set("spmv_eqrows", eq)
+            A = sa.HipCsr.new((n, n), indptr, indices, data)
+            nb, ne = A.wide_blocks()
+            assert nb == (n + 63) // 64 and (ne > 0) == (eq == 1), (eq, nb, ne)      # rows 1..R-2 of the grid hold 5-entry runs
+            y = np.full(n, np.nan); A.mul_vec(x, y)
+            assert np.array_equal(bits(y), bits(ref)), eq
+        ctx.set("spmv_dict", -1); ctx.set("spmv_eqrows", -1)
+        A = sa.HipCsr.new((n, n), indptr, indices, data)
+        out = {}
+        for poll in (1, 16, 7):
+            ctx.set("poll", poll)
+            s = sa.BiCGStab.new(A, n)
+            xs = np.zeros(n)
+            out[poll] = s.solve(rhs, xs, 3000, 1e-10) + (xs.copy(),)
+        assert out[1][0] == out[16][0] == out[7][0] and out[1][1] == out[16][1] == out[7][1]
+        assert np.array_equal(bits(out[1][2]), bits(out[16][2])) and np.array_equal(bits(out[1][2]), bits(out[7][2]))
+        ctx.set("poll", 16)
+        g = np.arange(n)
+        exact = (g // R + g % R).astype(float)
+        for ch in (0, 1):
+            ctx.set("ew_chunk", ch)
+            s = sa.BiCGStab.new(A, n)
+            xs = np.zeros(n)
+            its, res = s.solve(rhs, xs, 3000, 1e-10)
+            assert res <= 1e-10 and np.max(np.abs(xs - exact)) < 1e-6, (ch, its, res)
+    finally:
+        ctx.set("spmv_eqrows", e0); ctx.set("poll", p0); ctx.set("ew_chunk", c0); ctx.set("spmv_dict", d0)
 
 
 # ------------------------------------------------------------------ vecalg
@@ -791,6 +837,53 @@ def test_cfg5_poisson3d_50m_properties(sa):
     assert res <= 1e-8 and float((x - 1.0).abs().max().item()) < 1e-4
     A.mul_vec_unchecked(x, y)
     assert float(torch.linalg.vector_norm(y - rhs) / torch.linalg.vector_norm(rhs)) < 2e-8
+
+
+@pytest.mark.parametrize("values", ["poisson", "random"])
+def test_cfg5_full_size_spmv_against_oracle(sa, oracle, values):
+    """BASELINE cfg 5 at FULL size (500x500x200: 50 M rows, 349.1 M nnz), both value sets — the constant-coefficient operator
+    (pair codes: uniform / seam blocks, column triples, XCD-period walk, 32-bit byte offsets) and U(-1,1) coefficients
+    ("identical random CSR inputs": offset codes, uniform 64-row blocks) — one SpMV per stream, y compared BIT FOR BIT with the
+    oracle's fold (mat.rs:100-105; its row-parallel path, mat.rs:85-107, whose rows are folded exactly like the serial
+    ones) and the streams with each other; the fused mul_vec_dot within 1e-13 * sum|terms| of conj_dot(x, A x)."""
+    import torch
+    from sprsolve_amd import gen_torch
+    dev = torch.device("cuda", 0)
+    nx, ny, nz = 500, 500, 200
+    n = nx * ny * nz
+    ip, ix, dv, _ = gen_torch.poisson3d(nx, ny, nz, device=dev, values=values)
+    nnz = int(ip[-1].item())
+    assert nnz == 349_100_000
+    torch.manual_seed(5)
+    x = torch.rand(n, dtype=torch.float64, device=dev) * 2.0 - 1.0
+    ctx = sa.default_ctx(0)
+    ctx.set("spmv_dict", -1)
+    A = sa.HipCsr.from_device((n, n), nnz, ip, ix, dv, adopt=True)
+    mode = A.stream_format()[0]
+    assert mode == (2 if values == "poisson" else 1), mode          # the stream bench.py times for this value set
+    y = torch.empty_like(x); y0 = torch.empty_like(x)
+    try:
+        A.mul_vec_unchecked(x, y)                                    # the compressed stream
+        d_fused = A.mul_vec_dot_unchecked(x, y0)
+        assert torch.equal(y.view(torch.int64), y0.view(torch.int64))
+        ctx.set("spmv_dict", 0)
+        assert A.stream_format()[0] == 0
+        A.mul_vec_unchecked(x, y0)                                   # the plain (col_idx, val) stream of the same handle
+        d_plain = A.mul_vec_dot_unchecked(x, y0)
+    finally:
+        ctx.set("spmv_dict", -1)
+    assert torch.equal(y.view(torch.int64), y0.view(torch.int64)), "the compressed and the plain stream disagree"
+    xh = x.cpu().numpy(); yh = y.cpu().numpy()
+    iph, ixh, dvh = ip.cpu().numpy(), ix.cpu().numpy(), dv.cpu().numpy()
+    del A, y0, x, y, ip, ix, dv
+    torch.cuda.empty_cache()
+    oracle.set_threads(min(16, oracle.max_threads()))
+    ref = oracle.spmv(iph, ixh, dvh, xh, parallel=True)
+    assert np.array_equal(yh.view(np.uint64), ref.view(np.uint64)), \
+        "%d of %d rows differ from the reference fold" % (int(np.count_nonzero(yh.view(np.uint64) != ref.view(np.uint64))), n)
+    terms = float(np.abs(xh * ref).sum())
+    exact = float(np.dot(xh, ref))
+    assert abs(d_fused - exact) <= 1e-13 * terms and abs(d_plain - exact) <= 1e-13 * terms, (d_fused, d_plain, exact, terms)
 
 
 @pytest.mark.parametrize("dtype", ALL_DTYPES, ids=ALL_IDS)
