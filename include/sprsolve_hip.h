@@ -85,6 +85,8 @@ int sprs_version(void);
  *   "spmv_seam"     ... and so are blocks that are uniform but for one row, or two adjacent ones, holding only
  *                   part of the pattern or one entry of their own (line seams of truncated / Dirichlet grids) (creation)
  *   "spmv_eqrows"   plain CSR: blocks of equal-length rows do not read row_ptr                           (creation)
+ *   "spmv_wideload" plain CSR, f64: 16-byte stream loads (4 entries per lane), 3 workgroups per CU on HBM-sized
+ *                   matrices; 0 = the kernel with 4- / 8-byte loads                                      (creation)
  *   "spmv_period"   XCD-period walk of the compressed streams' blocks for matrices with a far band (rows r and
  *                   r +- band on one XCD): -1 automatic = the f64 pair-code stream (cfg 5: SpMV -2.3 %),
  *                   1 = the offset-code stream too (measured slower), 0 = off                            (creation)

@@ -79,11 +79,11 @@ while time.time() < t_end:
     if np.dtype(dtype).kind == "c":
         x = x + 1j * rng.uniform(-1, 1, n).astype(x.real.dtype)
     ref = oracle.spmv(indptr, cols, d, x)
-    for knob, wide, uni, eq, period, tri, seam in itertools.product((0, 1, 2), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1)):
-        if (knob != 2 and (wide or period)) or (knob == 0 and uni) or (knob != 0 and eq == 0) or (not tri and not wide) or (not seam and not (wide and uni)):
+    for knob, wide, uni, eq, period, tri, seam, wl in itertools.product((0, 1, 2), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1)):
+        if (knob != 2 and (wide or period)) or (knob == 0 and uni) or (knob != 0 and eq == 0) or (not tri and not wide) or (not seam and not (wide and uni)) or (knob != 0 and wl == 0):
             continue
         for k, v in (("spmv_dict", knob), ("spmv_wide", wide), ("spmv_uniform", uni), ("spmv_eqrows", eq), ("spmv_period", period),
-                     ("spmv_triple", tri), ("spmv_seam", seam)):
+                     ("spmv_triple", tri), ("spmv_seam", seam), ("spmv_wideload", wl)):
             ctx.set(k, v)
         A = sa.HipCsr.new((n, n), indptr, cols, d)
         y = np.full(n, 7.0, dtype=dtype)
@@ -92,12 +92,12 @@ while time.time() < t_end:
         A.mul_vec_dot(x, y2)
         combos += 1
         if not (np.array_equal(bits(y), bits(ref)) and np.array_equal(bits(y2), bits(ref))):
-            print("MISMATCH n=%d dtype=%s knobs dict=%d wide=%d uniform=%d eqrows=%d period=%d triple=%d seam=%d stream=%s bad=%d" % (
-                n, np.dtype(dtype).name, knob, wide, uni, eq, period, tri, seam, A.stream_format(), int(np.sum(bits(y) != bits(ref)))))
+            print("MISMATCH n=%d dtype=%s knobs dict=%d wide=%d uniform=%d eqrows=%d period=%d triple=%d seam=%d wideload=%d stream=%s bad=%d" % (
+                n, np.dtype(dtype).name, knob, wide, uni, eq, period, tri, seam, wl, A.stream_format(), int(np.sum(bits(y) != bits(ref)))))
             np.savez("gpurun_out/fuzz_fail.npz", indptr=indptr, cols=cols, d=d, x=x)
             sys.exit(1)
     count += 1
-for k in ("spmv_dict", "spmv_wide", "spmv_uniform", "spmv_eqrows"):
+for k in ("spmv_dict", "spmv_wide", "spmv_uniform", "spmv_eqrows", "spmv_wideload"):
     ctx.set(k, -1)
 ctx.set("spmv_period", -1)
 ctx.set("spmv_triple", -1)

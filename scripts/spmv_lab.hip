@@ -219,6 +219,179 @@ __global__ __launch_bounds__(BLOCK) void k_pipe(WalkArgs wa, const Desc *__restr
     if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
+
+// ---- round 3: the TA (vector-memory address unit) is ~87 % busy in the product kernel (profiles/r03_pmc_l2_ta.json), and a
+// 64-lane load costs it about the same for 4, 8 or 16 bytes per lane (scripts/micro/ta_rate.hip).  k_wide reads the
+// stream with 16 bytes per lane: lane l takes entries 4l .. 4l+3 of the block's 16-byte-aligned window (2 loads of
+// col_idx, 4 of val per 512 entries instead of 8 + 8), gathers and multiplies the same entries, writes the products to
+// LDS in window order; the fold is the product kernel's.  EQ: rows of equal length take their extents from the descriptor.
+template <int WALK, int ST, bool EQ, int NTS>
+__global__ __launch_bounds__(BLOCK) void k_wide(WalkArgs wa, const Desc *__restrict__ desc, const int *__restrict__ row_ptr,
+                                                const int *__restrict__ col_idx, const double *__restrict__ val, const double *__restrict__ x,
+                                                double *__restrict__ y, const double *__restrict__ u, double *__restrict__ part) {
+    __shared__ __attribute__((aligned(16))) double prod_all[NWAVE][CAP + 8]; __shared__ double red[NWAVE];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *prod = prod_all[wv]; double d0 = 0;
+    Walker<WALK> w(wa, wv);
+    for (int b = w.next(); b >= 0; b = w.next()) {
+        Desc d = uniform_desc(desc, b);
+        const bool eq = EQ && ((d.rb >> 30) & 1);                                // (scalar) flagged copy of the descriptors: rows of equal length
+        d.rb &= 0x3fffffff;
+        const int shift = d.pa & 3, base = d.pa - shift, tot = d.nn + shift;     // the aligned window [base, base + tot)
+        const int rcl = min(d.ra + lane, d.rb - 1);
+        int s, e;
+        if (eq) { const int L = d.nn / (d.rb - d.ra); s = (rcl - d.ra) * L; e = s + L; }
+        else { s = row_ptr[rcl] - d.pa; e = row_ptr[rcl + 1] - d.pa; }
+        const double uu = u[rcl];
+        const int lastq = max(tot - 1, 0) >> 2;                                  // last 4-entry group of the window
+        int4 c[2]; double2 v[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = min(lane + i * WAVE, lastq);
+            const int4 *cp = reinterpret_cast<const int4 *>(col_idx + base) + q;
+            const double2 *vp = reinterpret_cast<const double2 *>(val + base) + 2 * q;
+            if (NTS) {
+                typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                const u4v a = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(cp));
+                const u4v b0 = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(vp)), b1 = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(vp + 1));
+                __builtin_memcpy(&c[i], &a, 16); __builtin_memcpy(&v[i][0], &b0, 16); __builtin_memcpy(&v[i][1], &b1, 16);
+            } else { c[i] = *cp; v[i][0] = vp[0]; v[i][1] = vp[1]; }
+        }
+        double xg[8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { xg[4 * i] = x[c[i].x]; xg[4 * i + 1] = x[c[i].y]; xg[4 * i + 2] = x[c[i].z]; xg[4 * i + 3] = x[c[i].w]; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = 4 * (lane + i * WAVE);
+            double2 p0, p1;
+            p0.x = xg[4 * i] * v[i][0].x; p0.y = xg[4 * i + 1] * v[i][0].y; p1.x = xg[4 * i + 2] * v[i][1].x; p1.y = xg[4 * i + 3] * v[i][1].y;
+            if (k < tot) { *reinterpret_cast<double2 *>(prod + k) = p0; *reinterpret_cast<double2 *>(prod + k + 2) = p1; }
+        }
+        wave_lds_fence();
+        const int r = d.ra + lane;
+        if (r < d.rb) {
+            double acc = 0; const int len = e - s; const double *pr = prod + shift;
+            if (len <= 8) {
+                double pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[j] = pr[min(s + j, CAP + 3)];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < len) acc = acc + pv[j];
+            } else for (int k = s; k < e; ++k) acc = acc + pr[k];
+            if constexpr (ST == 1) __builtin_nontemporal_store(acc, y + r); else y[r] = acc;
+            d0 = d0 + uu * acc;
+        }
+        wave_lds_fence();
+    }
+    d0 = wave_sum(d0);
+    if (lane == 0) red[wv] = d0;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// the product kernel with the equal-length shortcut (what csrc/spmv.hip runs on cfg 5): the baseline of this round
+template <int WALK>
+__global__ __launch_bounds__(BLOCK) void k_prod(WalkArgs wa, const Desc *__restrict__ desc, const int *__restrict__ row_ptr,
+                                                const int *__restrict__ col_idx, const double *__restrict__ val, const double *__restrict__ x,
+                                                double *__restrict__ y, const double *__restrict__ u, double *__restrict__ part) {
+    __shared__ double prod_all[NWAVE][CAP]; __shared__ double red[NWAVE];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *prod = prod_all[wv]; double d0 = 0;
+    Walker<WALK> w(wa, wv);
+    for (int b = w.next(); b >= 0; b = w.next()) {
+        Desc d = uniform_desc(desc, b);
+        const bool eq = (d.rb >> 30) & 1;
+        d.rb &= 0x3fffffff;
+        const int rcl = min(d.ra + lane, d.rb - 1);
+        Stream S;
+        if (eq) { const int L = d.nn / (d.rb - d.ra); S.s = (rcl - d.ra) * L; S.e = S.s + L; }
+        else { S.s = row_ptr[rcl] - d.pa; S.e = row_ptr[rcl + 1] - d.pa; }
+        S.uu = u[rcl];
+        const int last = max(d.nn - 1, 0);
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) { const int k = min(lane + i * WAVE, last); S.cidx[i] = col_idx[d.pa + k]; S.vv[i] = val[d.pa + k]; }
+        double xg[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) xg[i] = x[S.cidx[i]];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) { const int k = lane + i * WAVE; if (k < d.nn) prod[k] = xg[i] * S.vv[i]; }
+        wave_lds_fence();
+        fold_store<0>(S, d, lane, prod, y, d0);
+        wave_lds_fence();
+    }
+    d0 = wave_sum(d0);
+    if (lane == 0) red[wv] = d0;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// 128-row blocks, up to 1024 entries per wavefront: twice the bytes in flight per wave (4 + 8 sixteen-byte loads), two rows
+// per lane in the fold phase
+template <int WALK, int ST>
+__global__ __launch_bounds__(BLOCK) void k_wide2(WalkArgs wa, const Desc *__restrict__ desc, const int *__restrict__ row_ptr,
+                                                 const int *__restrict__ col_idx, const double *__restrict__ val, const double *__restrict__ x,
+                                                 double *__restrict__ y, const double *__restrict__ u, double *__restrict__ part) {
+    constexpr int CAP2 = 1024;
+    __shared__ __attribute__((aligned(16))) double prod_all[NWAVE][CAP2 + 8]; __shared__ double red[NWAVE];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *prod = prod_all[wv]; double d0 = 0;
+    Walker<WALK> w(wa, wv);
+    for (int b = w.next(); b >= 0; b = w.next()) {
+        Desc d = uniform_desc(desc, b);
+        const bool eq = (d.rb >> 30) & 1;
+        d.rb &= 0x3fffffff;
+        const int shift = d.pa & 3, base = d.pa - shift, tot = d.nn + shift;
+        int s[2], e[2]; double uu[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rcl = min(d.ra + lane + 64 * h, d.rb - 1);
+            if (eq) { const int L = d.nn / (d.rb - d.ra); s[h] = (rcl - d.ra) * L; e[h] = s[h] + L; }
+            else { s[h] = row_ptr[rcl] - d.pa; e[h] = row_ptr[rcl + 1] - d.pa; }
+            uu[h] = u[rcl];
+        }
+        const int lastq = max(tot - 1, 0) >> 2;
+        int4 c[4]; double2 v[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = min(lane + i * WAVE, lastq);
+            c[i] = reinterpret_cast<const int4 *>(col_idx + base)[q];
+            v[i][0] = reinterpret_cast<const double2 *>(val + base)[2 * q]; v[i][1] = reinterpret_cast<const double2 *>(val + base)[2 * q + 1];
+        }
+        double xg[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xg[4 * i] = x[c[i].x]; xg[4 * i + 1] = x[c[i].y]; xg[4 * i + 2] = x[c[i].z]; xg[4 * i + 3] = x[c[i].w]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 4 * (lane + i * WAVE);
+            double2 p0, p1;
+            p0.x = xg[4 * i] * v[i][0].x; p0.y = xg[4 * i + 1] * v[i][0].y; p1.x = xg[4 * i + 2] * v[i][1].x; p1.y = xg[4 * i + 3] * v[i][1].y;
+            if (k < tot) { *reinterpret_cast<double2 *>(prod + k) = p0; *reinterpret_cast<double2 *>(prod + k + 2) = p1; }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = d.ra + lane + 64 * h;
+            if (r < d.rb) {
+                double acc = 0; const int len = e[h] - s[h]; const double *pr = prod + shift;
+                if (len <= 8) {
+                    double pv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pv[j] = pr[min(s[h] + j, CAP2 + 3)];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (j < len) acc = acc + pv[j];
+                } else for (int k = s[h]; k < e[h]; ++k) acc = acc + pr[k];
+                if constexpr (ST == 1) __builtin_nontemporal_store(acc, y + r); else y[r] = acc;
+                d0 = d0 + uu[h] * acc;
+            }
+        }
+        wave_lds_fence();
+    }
+    d0 = wave_sum(d0);
+    if (lane == 0) red[wv] = d0;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
 struct Variant { std::string name; std::function<void()> launch; };
 
 int main(int argc, char **argv) {
@@ -233,7 +406,7 @@ int main(int argc, char **argv) {
     hrp[0] = 0; for (long i = 0; i < n; ++i) hrp[i + 1] = hrp[i] + hc[i];
     const long nnz = hrp[n];
     CK(hipMemcpy(rp, hrp.data(), (n + 1) * 4, hipMemcpyHostToDevice));
-    CK(hipMalloc(&ci, nnz * 4)); CK(hipMalloc(&val, nnz * 8));
+    CK(hipMalloc(&ci, (nnz + 64) * 4)); CK(hipMalloc(&val, (nnz + 64) * 8)); CK(hipMemset(ci, 0, (nnz + 64) * 4)); CK(hipMemset(val, 0, (nnz + 64) * 8));
     for (double **p : {&x, &y, &yref, &u, &t1, &t2}) CK(hipMalloc(p, n * 8));
     CK(hipMalloc(&part, 8192 * 8));
     gen_fill<<<4096, 256>>>(nx, ny, nz, rp, ci, val, 1);
@@ -255,6 +428,27 @@ int main(int argc, char **argv) {
     for (long r = 0; r < n; r += 64) { long e = std::min<long>(r + 64, n); hd.push_back({(int)r, (int)e, hrp[r], hrp[e] - hrp[r]}); }
     const int nblk = (int)hd.size();
     Desc *dd; CK(hipMalloc(&dd, hd.size() * sizeof(Desc))); CK(hipMemcpy(dd, hd.data(), hd.size() * sizeof(Desc), hipMemcpyHostToDevice));
+    // flagged copy: bit 30 of rb = all rows of the block have the same length
+    std::vector<Desc> hde(hd);
+    long neq = 0;
+    for (auto &d : hde) {
+        const int rows = d.rb - d.ra; bool eq = rows > 0 && d.nn % rows == 0;
+        for (int r = d.ra; eq && r < d.rb; ++r) eq = hrp[r + 1] - hrp[r] == d.nn / rows;
+        if (eq) { d.rb |= 1 << 30; ++neq; }
+    }
+    printf("equal-length blocks: %ld of %d\n", neq, nblk);
+    // 128-row blocks for k_wide2 (flagged the same way)
+    std::vector<Desc> hd2;
+    for (long r = 0; r < n; r += 128) {
+        long e = std::min<long>(r + 128, n); Desc d{(int)r, (int)e, hrp[r], hrp[e] - hrp[r]};
+        const int rows = d.rb - d.ra; bool eq = d.nn % rows == 0;
+        for (int q = d.ra; eq && q < d.rb; ++q) eq = hrp[q + 1] - hrp[q] == d.nn / rows;
+        if (eq) d.rb |= 1 << 30;
+        hd2.push_back(d);
+    }
+    const int nblk2 = (int)hd2.size();
+    Desc *dd2; CK(hipMalloc(&dd2, hd2.size() * sizeof(Desc))); CK(hipMemcpy(dd2, hd2.data(), hd2.size() * sizeof(Desc), hipMemcpyHostToDevice));
+    Desc *dde; CK(hipMalloc(&dde, hde.size() * sizeof(Desc))); CK(hipMemcpy(dde, hde.data(), hde.size() * sizeof(Desc), hipMemcpyHostToDevice));
     // chunk tables: chunk c = blocks whose first row is in [c*G, (c+1)*G)
     auto make_chunks = [&](double G, int **dcb, int *nchunk) {
         std::vector<int> cb; cb.push_back(0);
@@ -264,15 +458,40 @@ int main(int argc, char **argv) {
         *nchunk = (int)cb.size() - 1;
         CK(hipMalloc(dcb, cb.size() * 4)); CK(hipMemcpy(*dcb, cb.data(), cb.size() * 4, hipMemcpyHostToDevice));
     };
-    int *cb8, *cb16, *cb4, *cbs, n8, n16, n4, ns, *cb64, *cb32, n64, n32, *cbs2, *cbs8, *cbs16, ns2, ns8, ns16;
+    int *cb8, *cb16, *cb4, *cbs, n8, n16, n4, ns, *cb64, *cb32, n64, n32, *cbs2, *cbs8, *cbs16, ns2, ns8, ns16, *cbs1, ns1, *cbs3, ns3, *cbs6, ns6;
+    make_chunks(1024.0, &cbs1, &ns1); make_chunks(3072.0, &cbs3, &ns3); make_chunks(6144.0, &cbs6, &ns6);
     make_chunks(P / 64.0, &cb64, &n64); make_chunks(P / 32.0, &cb32, &n32); make_chunks(2048.0, &cbs2, &ns2); make_chunks(8192.0, &cbs8, &ns8); make_chunks(16384.0, &cbs16, &ns16);
     make_chunks(P / 8.0, &cb8, &n8); make_chunks(P / 16.0, &cb16, &n16); make_chunks(P / 4.0, &cb4, &n4); make_chunks(4096.0, &cbs, &ns);
 
     std::vector<Variant> vs;
-    for (int grid : {1024}) {
+    for (int grid : {1024, 768, 512}) {
         const std::string g = "/" + std::to_string(grid);
-        WalkArgs rr{nblk, 0, nullptr}, x8{nblk, n8, cb8}, x16{nblk, n16, cb16}, x4{nblk, n4, cb4}, xs{nblk, ns, cbs}, x64{nblk, n64, cb64}, x32{nblk, n32, cb32}, xs2{nblk, ns2, cbs2}, xs8{nblk, ns8, cbs8}, xs16{nblk, ns16, cbs16};
+        WalkArgs xs1{nblk, ns1, cbs1}, xs3{nblk, ns3, cbs3}, xs6{nblk, ns6, cbs6}; WalkArgs rr{nblk, 0, nullptr}, x8{nblk, n8, cb8}, x16{nblk, n16, cb16}, x4{nblk, n4, cb4}, xs{nblk, ns, cbs}, x64{nblk, n64, cb64}, x32{nblk, n32, cb32}, xs2{nblk, ns2, cbs2}, xs8{nblk, ns8, cbs8}, xs16{nblk, ns16, cbs16};
 #define V(NAME, K, WALKARGS) vs.push_back({std::string(NAME) + g, [=]() { K<<<grid, BLOCK>>>(WALKARGS, dd, rp, ci, val, x, y, u, part); }})
+#define V2(NAME, K) vs.push_back({std::string(NAME) + g, [=]() { K<<<grid, BLOCK>>>(WalkArgs{nblk2, 0, nullptr}, dd2, rp, ci, val, x, y, u, part); }})
+#define VE(NAME, K, WALKARGS) vs.push_back({std::string(NAME) + g, [=]() { K<<<grid, BLOCK>>>(WALKARGS, dde, rp, ci, val, x, y, u, part); }})
+        VE("prod/rr", (k_prod<0>), rr);
+        V2("wide2/rr", (k_wide2<0, 0>));
+        V2("wide2-stnt/rr", (k_wide2<0, 1>));
+        VE("wide/rr", (k_wide<0, 0, true, 0>), rr);
+        V("wide-noeq/rr", (k_wide<0, 0, false, 0>), rr);
+        VE("wide-nts/rr", (k_wide<0, 0, true, 1>), rr);
+        VE("wide-stnt/rr", (k_wide<0, 1, true, 0>), rr);
+        VE("wide/xc8", (k_wide<1, 0, true, 0>), x8);
+        VE("wide/xc4096rows", (k_wide<1, 0, true, 0>), xs);
+        VE("prod/xc4096rows", (k_prod<1>), xs);
+        VE("wide/xc1024rows", (k_wide<1, 0, true, 0>), xs1);
+        VE("wide/xc2048rows", (k_wide<1, 0, true, 0>), xs2);
+        VE("wide/xc3072rows", (k_wide<1, 0, true, 0>), xs3);
+        VE("wide/xc6144rows", (k_wide<1, 0, true, 0>), xs6);
+        VE("wide/xc8192rows", (k_wide<1, 0, true, 0>), xs8);
+        VE("wide/xc16384rows", (k_wide<1, 0, true, 0>), xs16);
+        VE("wide/xc16", (k_wide<1, 0, true, 0>), x16);
+        VE("wide-stnt/xc4096rows", (k_wide<1, 1, true, 0>), xs);
+        VE("prod/xc2048rows", (k_prod<1>), xs2);
+        VE("prod/xc8192rows", (k_prod<1>), xs8);
+        if (grid != 1024) continue;
+        V("base/rr", (k_base<0, false>), rr);
         V("pipe/rr", (k_pipe<0, false>), rr);
         V("pipe-stnt/rr", (k_pipe<0, false, 1>), rr);
         V("pipe/xc64", (k_pipe<1, false>), x64);

@@ -134,9 +134,12 @@ int launch_diag_inv(sprs_ctx *c, size_t n, const V *diag, V *dinv) {
 // ran at 3.3 TB/s where a read stream reaches 6.3, profiles/r02_tuning.md §1): the grid-stride loop is walked four packs
 // at a time — the four loads are issued together, the additions stay in the ORIGINAL order (one accumulator,
 // i, i+st, i+2st, i+3st, ...), so every partial is bit-identical to the plain loop's.
+// NT: operands of 72 MB and more (stream_loads_nt) are read with non-temporal loads — a read-once stream that should not
+// allocate on its way: nrm2 of a cfg-5 vector 68 -> 63 us (0.73 -> 0.79 of the HBM peak), dot 137 -> 123 us (0.73 -> 0.81),
+// scripts/micro/red_shape.hip / profiles/r03_tuning.md; two workgroups per CU and four packs in flight stay the best shape.
 constexpr int RED_UNROLL = 4;
 
-template <class T, bool CONJ, int PK>
+template <class T, bool CONJ, int PK, bool NT>
 __global__ __launch_bounds__(BLOCK) void dot_kernel(int64_t n, const T *__restrict__ x, const T *__restrict__ y,
                                                     T *__restrict__ part) {
     __shared__ T smem[NWAVE];
@@ -146,14 +149,14 @@ __global__ __launch_bounds__(BLOCK) void dot_kernel(int64_t n, const T *__restri
     for (; i + (RED_UNROLL - 1) * st < np; i += RED_UNROLL * st) {
         Pack<T, PK> xv[RED_UNROLL], yv[RED_UNROLL];
 #pragma unroll
-        for (int u = 0; u < RED_UNROLL; ++u) { xv[u] = ldp<T, PK>(x, i + u * st); yv[u] = ldp<T, PK>(y, i + u * st); }
+        for (int u = 0; u < RED_UNROLL; ++u) { xv[u] = ldp<T, PK, NT>(x, i + u * st); yv[u] = ldp<T, PK, NT>(y, i + u * st); }
 #pragma unroll
         for (int u = 0; u < RED_UNROLL; ++u)
 #pragma unroll
             for (int e = 0; e < PK; ++e) acc = sadd(acc, smul(CONJ ? sconj(xv[u].v[e]) : xv[u].v[e], yv[u].v[e]));
     }
     for (; i < np; i += st) {
-        auto xv = ldp<T, PK>(x, i); auto yv = ldp<T, PK>(y, i);
+        auto xv = ldp<T, PK, NT>(x, i); auto yv = ldp<T, PK, NT>(y, i);
 #pragma unroll
         for (int e = 0; e < PK; ++e) acc = sadd(acc, smul(CONJ ? sconj(xv.v[e]) : xv.v[e], yv.v[e]));
     }
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(BLOCK) void dot_kernel(int64_t n, const T *__restri
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
-template <class T, int PK>
+template <class T, int PK, bool NT>
 __global__ __launch_bounds__(BLOCK) void nrm2sq_kernel(int64_t n, const T *__restrict__ x, Real<T> *__restrict__ part) {
     __shared__ Real<T> smem[NWAVE];
     Real<T> acc = 0;
@@ -174,14 +177,14 @@ __global__ __launch_bounds__(BLOCK) void nrm2sq_kernel(int64_t n, const T *__res
     for (; i + (RED_UNROLL - 1) * st < np; i += RED_UNROLL * st) {
         Pack<T, PK> xv[RED_UNROLL];
 #pragma unroll
-        for (int u = 0; u < RED_UNROLL; ++u) xv[u] = ldp<T, PK>(x, i + u * st);
+        for (int u = 0; u < RED_UNROLL; ++u) xv[u] = ldp<T, PK, NT>(x, i + u * st);
 #pragma unroll
         for (int u = 0; u < RED_UNROLL; ++u)
 #pragma unroll
             for (int e = 0; e < PK; ++e) acc = acc + ssq(xv[u].v[e]);
     }
     for (; i < np; i += st) {
-        auto xv = ldp<T, PK>(x, i);
+        auto xv = ldp<T, PK, NT>(x, i);
 #pragma unroll
         for (int e = 0; e < PK; ++e) acc = acc + ssq(xv.v[e]);
     }
@@ -226,10 +229,12 @@ int dot_host(sprs_ctx *c, size_t n, const T *x, const T *y, bool conj, T *out, s
     const int pk = (al && PKW > 1) ? PKW : 1;
     const int g = red_grid(c, n, pk);
     T *part = reinterpret_cast<T *>(c->d_part);
-#define SPRS_LAUNCH_DOT(CJ, PKV) \
-    hipLaunchKernelGGL((dot_kernel<T, CJ, PKV>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, x, y, part)
-    if (pk == 1) { if (conj) SPRS_LAUNCH_DOT(true, 1); else SPRS_LAUNCH_DOT(false, 1); }
-    else         { if (conj) SPRS_LAUNCH_DOT(true, PKW); else SPRS_LAUNCH_DOT(false, PKW); }
+    const bool nt = pk > 1 && stream_loads_nt(c, n * sizeof(T));      // (16-byte packs only: the unaligned path is not a bulk path)
+#define SPRS_LAUNCH_DOT(CJ, PKV, NTF) \
+    hipLaunchKernelGGL((dot_kernel<T, CJ, PKV, NTF>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, x, y, part)
+    if (pk == 1) { if (conj) SPRS_LAUNCH_DOT(true, 1, false); else SPRS_LAUNCH_DOT(false, 1, false); }
+    else if (nt) { if (conj) SPRS_LAUNCH_DOT(true, PKW, true); else SPRS_LAUNCH_DOT(false, PKW, true); }
+    else         { if (conj) SPRS_LAUNCH_DOT(true, PKW, false); else SPRS_LAUNCH_DOT(false, PKW, false); }
 #undef SPRS_LAUNCH_DOT
     SPRS_HIP_TRY(c, hipGetLastError());
     return reduce_partials_host<T>(c, part, g, out, comm);
@@ -242,8 +247,9 @@ int norm2_host(sprs_ctx *c, size_t n, const T *x, Real<T> *out, sprs_comm *comm)
     const int pk = (aligned16(x) && PKW > 1) ? PKW : 1;
     const int g = red_grid(c, n, pk);
     Real<T> *part = reinterpret_cast<Real<T> *>(c->d_part);
-    if (pk == 1) hipLaunchKernelGGL((nrm2sq_kernel<T, 1>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, x, part);
-    else hipLaunchKernelGGL((nrm2sq_kernel<T, PKW>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, x, part);
+    if (pk == 1) hipLaunchKernelGGL((nrm2sq_kernel<T, 1, false>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, x, part);
+    else if (stream_loads_nt(c, n * sizeof(T))) hipLaunchKernelGGL((nrm2sq_kernel<T, PKW, true>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, x, part);
+    else hipLaunchKernelGGL((nrm2sq_kernel<T, PKW, false>), dim3(g), dim3(BLOCK), 0, c->stream, (int64_t)n, x, part);
     SPRS_HIP_TRY(c, hipGetLastError());
     Real<T> s = 0;
     SPRS_TRY(reduce_partials_host<Real<T>>(c, part, g, &s, comm));

@@ -112,6 +112,7 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     else if (k == "ew_chunk") c->ew_chunk = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "stream_nt") c->stream_nt = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_eqrows") c->spmv_eqrows = value < 0 ? -1 : (value ? 1 : 0);
+    else if (k == "spmv_wideload") c->spmv_wideload = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "halo_overlap") c->halo_overlap = value ? 1 : 0;
     else if (k == "gs_graph") c->gs_graph = value ? 1 : 0;
     else if (k == "poll") { if (value < 1) return SPRS_INVALID_ARGUMENT; c->poll = (int)value; }
@@ -133,6 +134,7 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     if (k == "ew_chunk") return c->ew_chunk;
     if (k == "stream_nt") return c->stream_nt;
     if (k == "spmv_eqrows") return c->spmv_eqrows;
+    if (k == "spmv_wideload") return c->spmv_wideload;
     if (k == "halo_overlap") return c->halo_overlap;
     if (k == "gs_graph") return c->gs_graph;
     if (k == "poll") return c->poll;
@@ -526,6 +528,7 @@ int sprs_csr_destroy(sprs_csr *A) {
     if (A->rowblk) (void)hipFree(A->rowblk);
     if (A->blk_desc) (void)hipFree(A->blk_desc);
     if (A->blk_desc_eq) (void)hipFree(A->blk_desc_eq);
+    if (A->tail) (void)hipFree(A->tail);
     free_dict(A);
     if (A->x_tmp) (void)hipFree(A->x_tmp);
     if (A->y_tmp) (void)hipFree(A->y_tmp);

@@ -50,6 +50,7 @@ struct sprs_ctx {
     // 1 offset codes + values, 2 (offset, value) pair codes.  Read at handle creation (what is built) and at launch (what is used).
     int spmv_dict = -1;
     int spmv_wide = -1;   // f64 pair codes: two rows per lane (16-byte gathers); -1 / 1 on, 0 off
+    int spmv_wideload = -1; // plain-CSR stream, f64: 16 bytes per lane per stream load, 3 workgroups per CU on HBM-sized matrices; 0 = the 4/8-byte kernel.  Read at creation and at launch
     int spmv_eqrows = -1; // plain-CSR stream: blocks of equal-length rows take their extents from the descriptor (no row_ptr read); read at creation
     int spmv_period = -1;  // XCD-period walk for matrices with a far band (3-D stencils): -1 automatic = the f64 pair-code stream only, 1 = the offset-code stream too, 0 = off.  Read at creation
     int spmv_triple = -1;  // f64 pair codes, uniform blocks: columns c - 1 and c + 1 read from column c's loads; 0 = off.  Read at creation
@@ -172,7 +173,8 @@ struct sprs_csr {
     int32_t n_rowblk = 0;
     void *blk_desc = nullptr;      // device: one 16-byte {ra, rb|flag, pa, nn} descriptor per row block
     void *blk_desc_eq = nullptr;   // device: the plain-CSR kernel's copy, equal-length blocks flagged (rb bit 30, row length in nn >> 16)
-    int32_t n_eq_blocks = 0;       // ... how many are flagged (their row_ptr entries are not read)
+    int32_t n_eq_blocks = 0;
+    void *tail = nullptr;          // device, 64 B: zero-padded copy of the last 4-entry group of col_idx (16 B) and val (32 B) for spmv_wide_kernel; null = that kernel does not apply       // ... how many are flagged (their row_ptr entries are not read)
     // scratch for the host-slice trait entry points (lazily allocated)
     void *x_tmp = nullptr, *y_tmp = nullptr;
     double *part = nullptr;      // partials for mul_vec_dot

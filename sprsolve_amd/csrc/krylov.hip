@@ -483,8 +483,16 @@ int KrylovBase<T>::spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, con
         st = run();
         SPRS_HIP_TRY(ctx, hipEventRecord(ev[ev_used + 1], ctx->stream));
     }
+    ev_noop.resize(ev_used / 2 + 1, 0);
+    ev_noop[ev_used / 2] = 0;
     ev_used += 2;
     return st;
+}
+
+template <class T>
+void KrylovBase<T>::profile_discard_last(size_t launches) {
+    if (!profile) return;
+    for (size_t k = ev_used / 2; k > 1 && launches > 0; --k, --launches) ev_noop[k - 1] = 1;     // pair 0 brackets the solve
 }
 
 template <class T>
@@ -515,6 +523,7 @@ int KrylovBase<T>::end_solve() {
     SPRS_HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[0], ev[1]));
     stats.solve_ms = ms;
     for (size_t k = 2; k + 1 < ev_used; k += 2) {
+        if (k / 2 < ev_noop.size() && ev_noop[k / 2]) continue;
         SPRS_HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
         stats.spmv_ms += ms;
         stats.spmv_launches += 1;
@@ -680,6 +689,8 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
                 return SPRS_BREAKDOWN;
             }
             if (H.status == ST_RESTART) {                                   // :131-145, executed at iteration H.its
+                // K2 / K4 of the iterations enqueued from the requesting one on returned at their first instruction
+                this->profile_discard_last(2 * (its - (size_t)H.its));
                 SPRS_TRY(this->spmv(x, r, 0, nullptr, nullptr, nullptr, nullptr));  // :134
                 SPRS_TRY((launch_axpy<T, T>(c, n, sneg(sone<T>()), rhs, r)));       // :137
                 SPRS_TRY(dcopy(c, r0, r, n));                                       // :140

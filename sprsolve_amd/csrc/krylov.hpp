@@ -50,6 +50,7 @@ class KrylovBase {
     int profile = 0;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
+    std::vector<char> ev_noop;   // per profiled SpMV (event pair): launched after a restart request, i.e. returned at once — not a measurement
     SolverStats stats;
     // distributed operator (A->dist): all-reduced scalars live in `red`, 16-byte slots
     double *red = nullptr;       // device, 32 doubles
@@ -64,6 +65,7 @@ class KrylovBase {
     int spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, const int *status, bool conj_x = false, const sprs::Fin *fin = nullptr);
     // distributed: descriptor that makes the producing launch reduce its partials into red[2*slot ..] (empty otherwise)
     sprs::Fin fin_for(int slot, const void *base0, const void *base1, int P) const;
+    void profile_discard_last(size_t launches);   // the last `launches` profiled SpMVs were no-ops (status word set): keep them out of the mean
     int begin_solve();
     int end_solve();
     void trace_row(double a0, double a1, T b, T c, T d);

@@ -27,7 +27,9 @@ struct BlkDescHost { int32_t ra, rb, pa, nn; };   // == BlkDesc (device side)
 
 // Host-side analysis: greedy partition of the rows into blocks (see header comment).
 int build_rowblocks(sprs_csr *A, const int32_t *rp) {
-    const int cap = nnz_cap_of(A->dtype);
+    // f64: 4 entries less than the kernels' LDS slice, so that a block's 16-byte-aligned window (up to 3 entries of the
+    // previous block in front) still fits two 16-byte loads per lane (spmv_wide_kernel)
+    const int cap = A->dtype == DT_D ? nnz_cap_of(A->dtype) - 4 : nnz_cap_of(A->dtype);
     std::vector<int32_t> blk;
     blk.reserve((size_t)(A->nrows / ROWS_CAP + 16));
     int64_t r = 0;
@@ -88,6 +90,17 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
     SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     bool has_vec = false;
     for (int b = 0; b < A->n_rowblk; ++b) has_vec |= ((uint32_t)blk[b] & VEC_FLAG) != 0;
+    if (A->dtype == DT_D && A->nnz > 0 && c->spmv_wideload != 0 && (reinterpret_cast<uintptr_t>(A->col_idx) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(A->val) & 15) == 0) {
+        // zero-padded copy of the arrays' last 4-entry group for the 16-byte loads of spmv_wide_kernel
+        const int64_t g_last = (A->nnz - 1) >> 2, have = A->nnz - 4 * g_last;
+        SPRS_HIP_TRY(c, hipMalloc(&A->tail, 64));
+        SPRS_HIP_TRY(c, hipMemsetAsync(A->tail, 0, 64, c->stream));
+        SPRS_HIP_TRY(c, hipMemcpyAsync(A->tail, A->col_idx + 4 * g_last, sizeof(int32_t) * (size_t)have, hipMemcpyDeviceToDevice, c->stream));
+        SPRS_HIP_TRY(c, hipMemcpyAsync(reinterpret_cast<char *>(A->tail) + 16, reinterpret_cast<const double *>(A->val) + 4 * g_last,
+                                       sizeof(double) * (size_t)have, hipMemcpyDeviceToDevice, c->stream));
+        SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     return build_dict(A, has_vec, blk, rp);   // dictionary-compressed stream when the matrix qualifies (spmv_dict.hip)
 }
 
@@ -219,6 +232,130 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
 }
 
 // ---------------------------------------------------------------------------------------------
+// f64, 16 bytes per lane (round 3, profiles/r03_tuning.md §2).  The kernel above keeps 8 + 8 stream loads of 4 and 8 bytes
+// per lane in flight per wavefront.  Here lane l takes entries 4l .. 4l + 3 of the block's 16-byte-ALIGNED window
+// [pa - (pa & 3), ..): two loads of col_idx and four of val per 512 entries, the same gathers, the products written to LDS
+// in window order, the same per-row left fold (y bit-identical).  By itself that changes little at four workgroups per
+// CU; with wider loads three per CU become the optimum (fewer wavefronts, each with the same 6 KB in flight), and that
+// shape is 6 - 10 % faster on the cfg-5 stream (1085 - 1107 -> 1008 - 1027 us on three boxes, same binary, back to back).
+// Needs 16-byte aligned col_idx / val arrays and blocks of <= 508 entries (build_rowblocks); the last aligned group of
+// the arrays, which may reach past their end, is read from a zero-padded copy (tail_c / tail_v).
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+struct alignas(16) D2v { double a, b; };
+template <int DOT, bool YNT>
+__global__ __launch_bounds__(BLOCK) void spmv_wide_kernel(int n_rowblk, int xcd_chunk, int eq_desc, const BlkDesc *__restrict__ desc,
+                                                          const int32_t *__restrict__ order, const int32_t *__restrict__ row_ptr,
+                                                          const int32_t *__restrict__ col_idx, const double *__restrict__ val,
+                                                          const v4i32 *__restrict__ tail_c, const D2v *__restrict__ tail_v, int g_last,
+                                                          const double *__restrict__ x, double *__restrict__ y,
+                                                          const double *__restrict__ u, double *__restrict__ part0,
+                                                          double *__restrict__ part1, const int *__restrict__ status, const Fin fin) {
+    using T = double;
+    constexpr int CAP = nnz_cap<T>::value;
+    __shared__ __attribute__((aligned(16))) T prod_all[NWAVE][CAP + 8];
+    __shared__ T red[NWAVE];
+    const int run_state = status != nullptr ? *status : (int)ST_RUNNING;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    T *prod = prod_all[wv];
+    T d0 = 0.0, d1 = 0.0;
+    int b, bstep, bend;
+    if (xcd_chunk) {
+        const int chunk = (n_rowblk + 7) >> 3;
+        const int xcd = blockIdx.x & 7;
+        b = xcd * chunk + (blockIdx.x >> 3) * NWAVE + wv;
+        bstep = (gridDim.x >> 3) * NWAVE;
+        bend = min(n_rowblk, (xcd + 1) * chunk);
+    } else {
+        b = blockIdx.x * NWAVE + wv; bstep = gridDim.x * NWAVE; bend = n_rowblk;
+    }
+    const v4i32 *col4 = reinterpret_cast<const v4i32 *>(col_idx);
+    const D2v *val2 = reinterpret_cast<const D2v *>(val);
+    for (; b < bend; b += bstep) {
+        const BlkDesc d = desc[order ? order[b] : b];
+        if (run_state != ST_RUNNING) return;
+        const bool eq_rows = eq_desc != 0 && ((uint32_t)d.rb & UNI2) != 0;
+        const int ra = d.ra, rb = d.rb & (eq_desc ? 0x3fffffff : 0x7fffffff);
+        if (d.rb >= 0) {
+            const int pa = d.pa, nn = eq_desc ? (d.nn & 0xffff) : d.nn;
+            const int shift = pa & 3, tot = nn + shift;                     // the aligned window starts `shift` entries before the block
+            const int r = ra + lane;
+            const bool has_row = r < rb;
+            const int rcl = has_row ? r : rb - 1;
+            int s, e;
+            if (eq_rows) { const int L = d.nn >> 16; s = (rcl - ra) * L; e = s + L; }
+            else { s = row_ptr[rcl] - pa; e = row_ptr[rcl + 1] - pa; }
+            [[maybe_unused]] T uu;
+            if (DOT != 0) uu = u[rcl];
+            if (nn > 0) {
+                const int g0 = (pa - shift) >> 2, lastq = (tot - 1) >> 2;
+                v4i32 c[2]; D2v v[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int G = g0 + min(lane + i * WAVE, lastq);
+                    const bool tl = G == g_last;                            // the arrays' last group: from the padded copy
+                    const v4i32 *cp = tl ? tail_c : col4 + G;
+                    const D2v *vp = tl ? tail_v : val2 + 2 * (int64_t)G;
+                    c[i] = *cp; v[i][0] = vp[0]; v[i][1] = vp[1];
+                }
+                T xg[8];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { xg[4 * i] = x[c[i].x]; xg[4 * i + 1] = x[c[i].y]; xg[4 * i + 2] = x[c[i].z]; xg[4 * i + 3] = x[c[i].w]; }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int k = 4 * (lane + i * WAVE);
+                    // mat.rs:104  x[col] * val — entries of the window outside the block are multiplied too and never read
+                    const D2v p0{xg[4 * i] * v[i][0].a, xg[4 * i + 1] * v[i][0].b}, p1{xg[4 * i + 2] * v[i][1].a, xg[4 * i + 3] * v[i][1].b};
+                    if (k < tot) { *reinterpret_cast<D2v *>(prod + k) = p0; *reinterpret_cast<D2v *>(prod + k + 2) = p1; }
+                }
+            }
+            wave_lds_fence();
+            if (has_row) {
+                T acc = 0.0;                                          // mat.rs:103  fold(T::zero(), ..)
+                const int len = e - s;
+                const T *pr = prod + shift;
+                if (len <= 8) {
+                    T pv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pv[j] = pr[min(s + j, CAP + 3)];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j < len) acc = acc + pv[j];
+                } else {
+                    for (int k = s; k < e; ++k) acc = acc + pr[k];
+                }
+                if constexpr (YNT) __builtin_nontemporal_store(acc, y + r);
+                else y[r] = acc;
+                if (DOT == 1) d0 = d0 + uu * acc;
+                if (DOT == 2) { d0 = d0 + acc * acc; d1 = d1 + acc * uu; }
+            }
+            wave_lds_fence();
+        } else {
+            // ---------------- vector block: this wavefront strides one long row (as in spmv_kernel)
+            const int r = ra;
+            const int s = row_ptr[r], e = row_ptr[r + 1];
+            T acc = 0.0;
+            for (int k = s + lane; k < e; k += WAVE) { const int cj = col_idx[k]; const T vj = val[k]; acc = acc + x[cj] * vj; }
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                y[r] = acc;
+                if (DOT == 1) d0 = d0 + u[r] * acc;
+                if (DOT == 2) { d0 = d0 + acc * acc; d1 = d1 + acc * u[r]; }
+            }
+        }
+    }
+    if (run_state != ST_RUNNING) return;
+    if (DOT >= 1) {
+        d0 = block_sum(d0, red);
+        if (tid == 0) st_partial(fin, part0 + blockIdx.x, d0);
+    }
+    if (DOT == 2) {
+        d1 = block_sum(d1, red);
+        if (tid == 0) st_partial(fin, part1 + blockIdx.x, d1);
+    }
+    if (DOT >= 1 && fin.counter) finalize_last_block<T, T>(fin, DOT == 2, red, red);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row-block column spans (used by the optional schedules and by the distributed interior/boundary split).
 __global__ __launch_bounds__(BLOCK) void rowblk_span_kernel(int n_rowblk, const int32_t *__restrict__ rowblk,
                                                             const int32_t *__restrict__ row_ptr,
@@ -288,12 +425,15 @@ static inline bool is_cache_resident(const sprs_csr *A) {
     const double s = (double)dtype_size(A->dtype);
     return (double)A->nnz * (s + 4) + 3.0 * A->nrows * s < 192.0 * 1024 * 1024;
 }
+// the 16-byte-per-lane kernel runs this handle's plain stream (f64, aligned arrays, knob "spmv_wideload")
+static inline bool wide_loads(const sprs_csr *A) { return A->tail != nullptr && A->ctx->spmv_wideload != 0 && dict_mode(A) == 0; }
 static inline int base_grid(const sprs_csr *A) {
     int g = A->ctx->spmv_grid;
     // measured (A/B on the full solve): 4 workgroups per CU, for HBM-bound and cache-resident matrices and for all
     // three streams alike (the pair-code kernel runs its stand-alone best at 6 per CU but loses that inside the
-    // solve, where it alternates with the BLAS-1 kernels)
-    if (g <= 0) g = A->ctx->num_cu * 4;
+    // solve, where it alternates with the BLAS-1 kernels) — except the 16-byte-per-lane plain kernel on an HBM-sized
+    // stream: 3 per CU (profiles/r03_tuning.md §2; only multiples of the CU count spread evenly)
+    if (g <= 0) g = A->ctx->num_cu * ((wide_loads(A) && !is_cache_resident(A)) ? 3 : 4);
     if (g < 8) g = 8;
     if (g > MAX_GRID / 2) g = MAX_GRID / 2;
     return g & ~7;
@@ -330,6 +470,25 @@ static int launch_spmv_impl(const sprs_csr *A, const int32_t *order, int count, 
     const int xcd_chunk = c->xcd_chunk < 0 ? (is_cache_resident(A) ? 1 : 0) : c->xcd_chunk;
     if (const int dm = dict_mode(A))
         return launch_spmv_dict<T>(A, dm, order, count, g, xcd_chunk, x, y, dot_mode, u, part0, part1, status, conj_x, fin);
+    if constexpr (dtype_of<T>::value == DT_D) {
+        if (wide_loads(A)) {
+            const BlkDesc *dsc = reinterpret_cast<const BlkDesc *>(A->blk_desc_eq ? A->blk_desc_eq : A->blk_desc);
+            const v4i32 *tc = reinterpret_cast<const v4i32 *>(A->tail);
+            const D2v *tv = reinterpret_cast<const D2v *>(reinterpret_cast<const char *>(A->tail) + 16);
+            const int g_last = (int)((A->nnz - 1) >> 2);
+#define SPRS_WIDE(D, YN)                                                                                             \
+    SPRS_LAUNCH_SPMV(c, (spmv_wide_kernel<D, YN>), g, count, xcd_chunk, A->blk_desc_eq ? 1 : 0, dsc, order, A->row_ptr, \
+                     A->col_idx, v, tc, tv, g_last, x, y, u, part0, part1, status, fin)
+            if (stream_loads_nt(c, (size_t)A->nrows * sizeof(T))) {       // HBM-sized result: non-temporal y stores (-1 %)
+                if (dot_mode == 0) SPRS_WIDE(0, true); else if (dot_mode == 1) SPRS_WIDE(1, true); else SPRS_WIDE(2, true);
+            } else {
+                if (dot_mode == 0) SPRS_WIDE(0, false); else if (dot_mode == 1) SPRS_WIDE(1, false); else SPRS_WIDE(2, false);
+            }
+#undef SPRS_WIDE
+            SPRS_HIP_TRY(c, hipGetLastError());
+            return SPRS_OK;
+        }
+    }
 #define SPRS_SPMV(D, CJ)                                                                                              \
     SPRS_LAUNCH_SPMV(c, (spmv_kernel<T, D, CJ>), g, count,                                                            \
                        xcd_chunk, A->blk_desc_eq ? 1 : 0, reinterpret_cast<const BlkDesc *>(A->blk_desc_eq ? A->blk_desc_eq : A->blk_desc), order, A->row_ptr, A->col_idx, v, x, y, u, part0, part1, status, fin)

@@ -153,6 +153,57 @@ def test_spmv_device_vectors_and_grid_options(sa, oracle):
         ctx.set("grid", g0); ctx.set("xcd_chunk", c0); ctx.set("spmv_grid", s0)
 
 
+@pytest.mark.parametrize("n", [5, 64, 333, 4099, 70001])
+def test_plain_stream_wide_loads(sa, oracle, n):
+    """spmv_wide_kernel (f64 plain stream, 16 bytes per lane over each block's 16-byte-aligned window; knob spmv_wideload):
+    y bit-identical to the 4/8-byte kernel and to the reference fold for every phase of the window (blocks start at any
+    nnz index mod 4), for an nnz count that is not a multiple of 4 (the arrays' last group comes from the padded copy),
+    rows of 0..9 and of > 96 entries, rows of 8 entries (blocks of 63 rows: the 508-entry cap) — and on device arrays that
+    are NOT 16-byte aligned the handle silently keeps the narrow kernel."""
+    import torch
+    ctx = sa.default_ctx()
+    d0, w0 = ctx.get("spmv_dict"), ctx.get("spmv_wideload")
+    try:
+        ctx.set("spmv_dict", 0)
+        for variant in ("ragged", "eight"):
+            if variant == "ragged":
+                indptr, indices, data, cnt = random_csr(n, 900 + n, np.float64)
+            else:
+                rng = np.random.default_rng(n)
+                cnt = np.full(n, min(8, n)); cnt[n // 3] = min(3, n)
+                indptr = np.zeros(n + 1, np.int32); np.cumsum(cnt, out=indptr[1:])
+                indices = np.concatenate([np.sort(rng.choice(n, c, replace=False)) for c in cnt]).astype(np.int32)
+                data = rand_vec(int(indptr[-1]), np.float64, n + 1)
+            x = rand_vec(n, np.float64, 3 + n)
+            ref = oracle.spmv(indptr, indices, data, x)
+            short = cnt <= 96
+            ys = {}
+            for wl in (0, 1):
+                ctx.set("spmv_wideload", wl)
+                A = sa.HipCsr.new((n, n), indptr, indices, data)
+                y = np.full(n, np.nan); A.mul_vec(x, y)
+                y2 = np.zeros(n); dd = A.mul_vec_dot(x, y2)
+                assert np.array_equal(bits(y[short]), bits(ref[short])), (variant, wl, n)
+                assert np.array_equal(bits(y), bits(y2))
+                assert abs(dd - np.dot(x, y)) <= RED_RTOL * np.sum(np.abs(x * y)) + 1e-300
+                ys[wl] = y
+            assert np.array_equal(bits(ys[0][short]), bits(ys[1][short]))
+            # device arrays one element off a 16-byte boundary: the wide kernel must not be chosen (and nothing faults)
+            ctx.set("spmv_wideload", 1)
+            if indptr[-1] > 0:
+                dev = torch.device("cuda", 0)
+                ci = torch.zeros(int(indptr[-1]) + 1, dtype=torch.int32, device=dev)[1:]; ci.copy_(torch.from_numpy(indices.astype(np.int32)))
+                va = torch.zeros(int(indptr[-1]) + 1, dtype=torch.float64, device=dev)[1:]; va.copy_(torch.from_numpy(data))
+                ip = torch.from_numpy(indptr.astype(np.int32)).to(dev)
+                assert ci.data_ptr() % 16 != 0 or va.data_ptr() % 16 != 0
+                Au = sa.HipCsr.from_device((n, n), int(indptr[-1]), ip, ci, va, adopt=True)
+                xd = torch.from_numpy(x).to(dev); yd = torch.empty_like(xd)
+                Au.mul_vec_unchecked(xd, yd)
+                assert np.array_equal(bits(yd.cpu().numpy()[short]), bits(ref[short]))
+    finally:
+        ctx.set("spmv_dict", d0); ctx.set("spmv_wideload", w0)
+
+
 def test_eqrows_poll_and_chunk_knobs(sa, oracle):
     """The three knobs no other test turns: spmv_eqrows (plain stream: equal-length blocks take their extents from the
     descriptor — read at creation; y bit-identical either way), poll (how often the host looks at the status word: the
