@@ -153,7 +153,7 @@ def test_spmv_device_vectors_and_grid_options(sa, oracle):
         ctx.set("grid", g0); ctx.set("xcd_chunk", c0); ctx.set("spmv_grid", s0)
 
 
-@pytest.mark.parametrize("n", [5, 64, 333, 4099, 70001])
+@pytest.mark.parametrize("n", [17, 64, 333, 4099, 70001])
 def test_plain_stream_wide_loads(sa, oracle, n):
     """spmv_wide_kernel (f64 plain stream, 16 bytes per lane over each block's 16-byte-aligned window; knob spmv_wideload):
     y bit-identical to the 4/8-byte kernel and to the reference fold for every phase of the window (blocks start at any
