@@ -256,7 +256,11 @@ struct BlkLoads {
     T vv[PAIR ? 1 : ITEMS];  // values (offset-code stream only)
 };
 
-template <class T, int DOT, bool CONJX, bool PAIR>
+// WV (f64 offset codes only): the block's values are read with 16 bytes per lane over its 16-byte-aligned window (entries
+// 2l, 2l + 1 of [pa - (pa & 1), ..) per load: 4 loads per 512 entries instead of 8) and staged to LDS with 16-byte stores;
+// the last 2-entry group of val, which may reach one entry past the array, comes from the handle's zero-padded tail copy.
+struct alignas(16) V2d { double a, b; };
+template <class T, int DOT, bool CONJX, bool PAIR, bool WV = false>
 __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_chunk, const BlkDesc *__restrict__ desc,
                                                           const int32_t *__restrict__ order,
                                                           const int32_t *__restrict__ row_ptr,
@@ -265,7 +269,9 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
                                                           const T *__restrict__ val_tab,          // per pair code: value
                                                           const T *__restrict__ val, const T *__restrict__ x,
                                                           T *__restrict__ y, const T *__restrict__ u, T *__restrict__ part0,
-                                                          T *__restrict__ part1, const int *__restrict__ status, const Fin fin) {
+                                                          T *__restrict__ part1, const int *__restrict__ status, const Fin fin,
+                                                          const V2d *__restrict__ tail2, int g2_last) {
+    static_assert(!WV || (sizeof(T) == 8 && !PAIR), "wide value loads: f64 offset-code stream");
     constexpr int CAP = nnz_cap<T>::value;          // nnz per row block (per wavefront)
     constexpr int CW = (CAP + 3 + CPAD + 3) / 4;    // dwords: CAP code bytes at any 4-byte phase + the readable pad
     constexpr int ITEMS = CAP / WAVE;
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
     __shared__ PairEnt<T> s_pair[PAIR ? TAB : 1];
     __shared__ int32_t s_off8[PAIR ? 1 : TAB];
     __shared__ uint32_t s_c[NWAVE][CW];
-    __shared__ T s_v[PAIR ? 1 : NWAVE][PAIR ? 1 : CAP + 8];
+    __shared__ __attribute__((aligned(16))) T s_v[PAIR ? 1 : NWAVE][PAIR ? 1 : CAP + 16];
     __shared__ T red[NWAVE];
     // the solve's status word is requested first and looked at after the table loads: one memory round trip, not two
     // (a kernel of a finished solve must not store anything; it may load)
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
     if constexpr (PAIR) s_pair[tid] = PairEnt<T>{off_tab[tid] * (int32_t)sizeof(T), val_tab[tid]};    // BLOCK == TAB
     else s_off8[tid] = off_tab[tid] * (int32_t)sizeof(T);
     for (int i = lane; i < CW; i += WAVE) s_c[wv][i] = 0;       // the pad is read (and ignored) before it is ever written
-    if constexpr (!PAIR) for (int i = lane; i < CAP + 8; i += WAVE) s_v[wv][i] = szero<T>();
+    if constexpr (!PAIR) for (int i = lane; i < CAP + 16; i += WAVE) s_v[wv][i] = szero<T>();
     __syncthreads();                                // the only workgroup barrier: tables are read-only afterwards
     if (run_state != ST_RUNNING) return;
 
@@ -348,9 +354,20 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
             L.wc[i] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(code) + (uint32_t)(L.pa - shift + 4 * L.di[i]));
         }
         if constexpr (!PAIR) {
-            const int last = max(L.nn - 1, 0);
+            [[maybe_unused]] const int last = max(L.nn - 1, 0);
+            if constexpr (WV) {
+                const int vsh = L.pa & 1, g0 = (L.pa - vsh) >> 1, lastq = max(L.nn + vsh - 1, 0) >> 1;
+                const V2d *val2 = reinterpret_cast<const V2d *>(val);
 #pragma unroll
-            for (int i = 0; i < ITEMS; ++i) L.vv[i] = val[L.pa + min(lane + i * WAVE, last)];
+                for (int i = 0; i < ITEMS / 2; ++i) {
+                    const int G = g0 + min(lane + i * WAVE, lastq);
+                    const V2d q = *(G == g2_last ? tail2 : val2 + G);
+                    L.vv[2 * i] = q.a; L.vv[2 * i + 1] = q.b;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < ITEMS; ++i) L.vv[i] = val[L.pa + min(lane + i * WAVE, last)];
+            }
         }
     };
     // Phase 2: the loads have landed — put the code bytes (and values) into this wavefront's LDS slice.
@@ -366,10 +383,19 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
                     s_c[wv][2 * WAVE] = reinterpret_cast<const uint32_t *>(code + (L.pa - shift))[2 * WAVE];
             }
             if constexpr (!PAIR) {
+                if constexpr (WV) {
+                    const int tot = L.nn + (L.pa & 1);                  // window order: vs[k] = val[pa - (pa & 1) + k]
+#pragma unroll
+                    for (int i = 0; i < ITEMS / 2; ++i) {
+                        const int k = 2 * (lane + i * WAVE);
+                        if (k < tot) *reinterpret_cast<V2d *>(vs + k) = V2d{L.vv[2 * i], L.vv[2 * i + 1]};
+                    }
+                } else {
 #pragma unroll
                 for (int i = 0; i < ITEMS; ++i) {
                     const int k = lane + i * WAVE;
                     if (k < L.nn) vs[k] = L.vv[i];
+                }
                 }
             }
         }
@@ -377,11 +403,13 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
 
     // loop-carried state of the block being processed: plain values, no load in flight behind them
     int c_ra = 0, c_rb = 0, c_s = 0, c_len = 0, c_shift = 0;
+    [[maybe_unused]] int c_vsh = 0;       // WV: the staged values start this many entries into the wavefront's slice
     bool c_uni = false;      // scalar: every lane reads the FIRST row's codes
     T c_uu = szero<T>();
     auto adopt = [&](const Loads &L) {
         const int r = L.ra + lane;
         c_ra = L.ra; c_rb = L.rb; c_shift = L.pa & 3; c_uni = L.ulen > 0;
+        if constexpr (WV) c_vsh = L.pa & 1;
         c_s = L.s - L.pa;
         int e = __shfl_down(L.s, 1, WAVE);          // next row's start; the block's last row ends at pa + nn
         if (r == L.rb - 1) e = L.pa + L.nn;
@@ -439,7 +467,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
                 const int cd = cp[t];
                 int off8;
                 if constexpr (PAIR) { const PairEnt<T> e = s_pair[cd]; off8 = e.off8; av[t] = e.val; }
-                else { off8 = s_off8[cd]; av[t] = vs[kb + t]; }
+                else { off8 = s_off8[cd]; av[t] = vs[(WV ? c_vsh : 0) + kb + t]; }
                 const uint32_t vo = valid ? r8 + (uint32_t)off8 : 0u;     // lanes past their row gather x[0] and drop it
                 xg[t] = *reinterpret_cast<const T *>(xbytes + vo);
             }
@@ -1048,7 +1076,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
     if constexpr (VALS) {
         for (size_t i = 0; i < vals.size(); ++i) {
             T v;
-            if (sizeof(T) == 8) { uint64_t k = vals[i].first; memcpy(&v, &k, 8); }
+            if constexpr (sizeof(T) == 8) { uint64_t k = vals[i].first; memcpy(&v, &k, 8); }
             else { uint32_t k = (uint32_t)vals[i].first; memcpy(&v, &k, 4); }
             val_tab[i] = v;
             codes[HSLOTS + (size_t)vals[i].second] = (uint8_t)i;
@@ -1261,10 +1289,25 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
     if (!pair && order == nullptr && count == A->n_rowblk && c->spmv_period > 0 && D->off_order) { order = D->off_order; xcd_chunk = 0; }
     // the offset-code stream runs on its own descriptors (uniform blocks flagged); same block numbering as blk_desc
     const BlkDesc *dsc = reinterpret_cast<const BlkDesc *>((!pair && D->off_desc && c->spmv_uniform != 0) ? D->off_desc : A->blk_desc);
+    const V2d *tail2 = nullptr;
+    int g2_last = -1;
+    if constexpr (sizeof(T) == 8 && !is_complex<T>::value) {
+        if (!pair && A->tail && c->spmv_wideload != 0) {
+            // f64 offset codes: 16-byte value loads (the plain stream's measure, profiles/r03_tuning.md §2)
+            g2_last = (int)((A->nnz - 1) >> 1);
+            tail2 = reinterpret_cast<const V2d *>(reinterpret_cast<const char *>(A->tail) + 16) + (g2_last - 2 * (int)((A->nnz - 1) >> 2));
+#define SPRS_DSPMVW(DM) SPRS_LAUNCH_SPMV(c, (spmv_dict_kernel<T, DM, false, false, true>), g, count, xcd_chunk, dsc, order, A->row_ptr, \
+                                         code, otab, pv, v, x, y, u, part0, part1, status, fin, tail2, g2_last)
+            if (dot_mode == 0) SPRS_DSPMVW(0); else if (dot_mode == 1) SPRS_DSPMVW(1); else SPRS_DSPMVW(2);
+#undef SPRS_DSPMVW
+            SPRS_HIP_TRY(c, hipGetLastError());
+            return SPRS_OK;
+        }
+    }
 #define SPRS_DSPMV2(DM, CJ, PR)                                                                                         \
     SPRS_LAUNCH_SPMV(c, (spmv_dict_kernel<T, DM, CJ, PR>), g, count, xcd_chunk,                                          \
                        dsc, order, A->row_ptr, code, otab, pv, v, x, y, u,                                              \
-                       part0, part1, status, fin)
+                       part0, part1, status, fin, tail2, g2_last)
 #define SPRS_DSPMV(DM, CJ) do { if (pair) SPRS_DSPMV2(DM, CJ, (has_val_dict<T>::value)); else SPRS_DSPMV2(DM, CJ, false); } while (0)
     if (conj_x && is_complex<T>::value) {
         if (dot_mode == 0) SPRS_DSPMV(0, true);
