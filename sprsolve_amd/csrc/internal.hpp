@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <ctime>
 #include <mutex>
 #include <vector>
 
@@ -101,6 +103,14 @@ struct CtxLock {
         else                                                                                                             \
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(sprs::BLOCK), 0, (c)->stream, __VA_ARGS__);                      \
     } while (0)
+
+// SPRS_CREATE_TRACE=1: stage times of handle creation on stderr (diagnostics; profiles/r03_tuning.md §4)
+struct CreateTrace {
+    bool on; double t0;
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+    CreateTrace() : on(getenv("SPRS_CREATE_TRACE") != nullptr), t0(now()) {}
+    void lap(const char *what) { if (!on) return; const double t = now(); fprintf(stderr, "[sprs create] %-28s %8.2f ms\n", what, t - t0); t0 = t; }
+};
 
 #define SPRS_TRY(expr)                       \
     do {                                     \

@@ -18,6 +18,7 @@
 //  * Optional fused epilogue: per-workgroup partials of conj(u).y, or of conj(y).y and
 //    conj(y).u, so the solvers' dot products cost no extra pass over y.
 #include <algorithm>
+#include <thread>
 
 #include "device.hpp"
 
@@ -25,16 +26,56 @@ namespace sprs {
 
 struct BlkDescHost { int32_t ra, rb, pa, nn; };   // == BlkDesc (device side)
 
+// f(begin, end[, thread index]) over [0, n) on up to 16 host threads (fewer when n is small)
+template <class F>
+static void host_parallel_for(int64_t n, int64_t min_chunk, F &&f) {
+    auto call = [&](int64_t a, int64_t b, int t) {
+        if constexpr (std::is_invocable_v<F, int64_t, int64_t, int>) f(a, b, t); else f(a, b);
+    };
+    int64_t T = std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+    T = std::max<int64_t>(1, std::min<int64_t>(T, n / std::max<int64_t>(min_chunk, 1)));
+    if (T <= 1) { call(0, n, 0); return; }
+    std::vector<std::thread> th;
+    const int64_t per = (n + T - 1) / T;
+    for (int64_t t = 0; t < T; ++t) {
+        const int64_t a = t * per, b = std::min<int64_t>(n, a + per);
+        if (a >= b) break;
+        th.emplace_back(call, a, b, (int)t);
+    }
+    for (auto &x : th) x.join();
+}
+
 // Host-side analysis: greedy partition of the rows into blocks (see header comment).
 int build_rowblocks(sprs_csr *A, const int32_t *rp) {
     // f64: 4 entries less than the kernels' LDS slice, so that a block's 16-byte-aligned window (up to 3 entries of the
     // previous block in front) still fits two 16-byte loads per lane (spmv_wide_kernel)
     const int cap = A->dtype == DT_D ? nnz_cap_of(A->dtype) - 4 : nnz_cap_of(A->dtype);
+    CreateTrace tr;
     std::vector<int32_t> blk;
     blk.reserve((size_t)(A->nrows / ROWS_CAP + 16));
     int64_t r = 0;
     const int64_t n = A->nrows;
+    // Handle creation should stay cheap next to the solve it prepares (50 M rows: the per-row host loops were ~100 ms).
+    // Which 64-row groups hold a row longer than LONG_ROW is found by all host threads; the greedy walk then takes a whole
+    // 64-row block in one step wherever no such row is near and the 64 rows fit the cap (every prefix of them fits too, so
+    // the row-by-row walk would have stopped at the same place) and falls back to the row-by-row walk elsewhere.
+    const int64_t ngrp = (n + ROWS_CAP - 1) / ROWS_CAP;
+    std::vector<uint8_t> grp_long((size_t)ngrp + 2, 0);
+    host_parallel_for(ngrp, 4096, [&](int64_t g0, int64_t g1) {
+        for (int64_t g = g0; g < g1; ++g) {
+            const int64_t a = g * ROWS_CAP, b = std::min<int64_t>(a + ROWS_CAP, n);
+            int mx = 0;
+            for (int64_t q = a; q < b; ++q) mx = std::max(mx, rp[q + 1] - rp[q]);
+            grp_long[(size_t)g] = mx > LONG_ROW;
+        }
+    });
     while (r < n) {
+        if (r + ROWS_CAP <= n && !grp_long[(size_t)(r / ROWS_CAP)] && !grp_long[(size_t)((r + ROWS_CAP - 1) / ROWS_CAP)] &&
+            (int64_t)rp[r + ROWS_CAP] - rp[r] <= cap) {
+            blk.push_back((int32_t)r);
+            r += ROWS_CAP;
+            continue;
+        }
         int64_t len = (int64_t)rp[r + 1] - rp[r];
         if (len > LONG_ROW) {  // vector block: one long row, its wavefront strides it
             blk.push_back((int32_t)((uint32_t)r | VEC_FLAG));
@@ -53,6 +94,7 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
     }
     blk.push_back((int32_t)n);
     A->n_rowblk = (int32_t)blk.size() - 1;
+    tr.lap("  row-block partition");
     sprs_ctx *c = A->ctx;
     {
         std::vector<BlkDescHost> desc((size_t)A->n_rowblk);
@@ -68,15 +110,23 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
         // The plain-CSR kernel's own copy: stream blocks whose rows all have the same length L are flagged (rb bit 30,
         // L in nn's upper half) — the kernel then takes the row extents from the descriptor (row i starts at i*L) and
         // does not read row_ptr for the block: 4 B/row less traffic on every stencil / band interior.
-        for (int b = 0; b < A->n_rowblk && A->nrows < (1 << 30) && c->spmv_eqrows != 0; ++b) {
-            BlkDescHost &d = desc[b];
-            if (d.rb < 0) continue;                                  // vector block
-            const int rows = d.rb - d.ra;
-            if (rows < 1 || d.nn % rows != 0) continue;
-            const int L = d.nn / rows;
-            bool eq = L >= 1 && L <= 0x7fff;
-            for (int r = d.ra; eq && r < d.rb; ++r) eq = rp[r + 1] - rp[r] == L;
-            if (eq) { d.rb = (int32_t)((uint32_t)d.rb | UNI2); d.nn = d.nn | (L << 16); A->n_eq_blocks++; }
+        if (A->nrows < (1 << 30) && c->spmv_eqrows != 0) {
+            std::vector<int32_t> neq(64, 0);
+            host_parallel_for(A->n_rowblk, 1024, [&](int64_t b0, int64_t b1, int tid) {
+                int32_t cnt = 0;
+                for (int64_t b = b0; b < b1; ++b) {
+                    BlkDescHost &d = desc[(size_t)b];
+                    if (d.rb < 0) continue;                                  // vector block
+                    const int rows = d.rb - d.ra;
+                    if (rows < 1 || d.nn % rows != 0) continue;
+                    const int L = d.nn / rows;
+                    bool eq = L >= 1 && L <= 0x7fff;
+                    for (int q = d.ra; eq && q < d.rb; ++q) eq = rp[q + 1] - rp[q] == L;
+                    if (eq) { d.rb = (int32_t)((uint32_t)d.rb | UNI2); d.nn = d.nn | (L << 16); ++cnt; }
+                }
+                neq[(size_t)tid] = cnt;
+            });
+            for (int32_t v : neq) A->n_eq_blocks += v;
         }
         if (A->nrows < (1 << 30) && c->spmv_eqrows != 0) {
             SPRS_HIP_TRY(c, hipMalloc(&A->blk_desc_eq, sizeof(BlkDescHost) * (desc.size() ? desc.size() : 1)));
@@ -85,6 +135,7 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
             SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
     }
+    tr.lap("  descriptors + eq flags");
     SPRS_HIP_TRY(c, hipMalloc((void **)&A->rowblk, blk.size() * sizeof(int32_t)));
     SPRS_HIP_TRY(c, hipMemcpyAsync(A->rowblk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -101,7 +152,10 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
                                        sizeof(double) * (size_t)have, hipMemcpyDeviceToDevice, c->stream));
         SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    return build_dict(A, has_vec, blk, rp);   // dictionary-compressed stream when the matrix qualifies (spmv_dict.hip)
+    tr.lap("  rowblk upload + tail");
+    const int st = build_dict(A, has_vec, blk, rp);   // dictionary-compressed stream when the matrix qualifies (spmv_dict.hip)
+    tr.lap("  build_dict total");
+    return st;
 }
 
 template <class T, int DOT, bool CONJX>

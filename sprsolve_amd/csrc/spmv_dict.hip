@@ -1025,6 +1025,7 @@ template <class T>
 int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp) {
     sprs_ctx *c = A->ctx;
     constexpr bool VALS = has_val_dict<T>::value;
+    CreateTrace tr;
     const bool want_vals = VALS && c->spmv_dict != 1;
     const int n = (int)A->nrows;
     uint32_t *off_h = nullptr; unsigned long long *val_h = nullptr; int *counts = nullptr;
@@ -1057,6 +1058,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
     DICT_TRY(hipMemcpyAsync(h_off.data(), off_h, sizeof(uint32_t) * HSLOTS, hipMemcpyDeviceToHost, c->stream));
     DICT_TRY(hipMemcpyAsync(h_val.data(), val_h, sizeof(unsigned long long) * HSLOTS, hipMemcpyDeviceToHost, c->stream));
     DICT_TRY(hipStreamSynchronize(c->stream));
+    tr.lap("    dict collect");
     if (h_counts[0] > TAB || h_counts[0] == 0) { cleanup(); return SPRS_OK; }      // too many offsets: plain CSR
     const bool use_vals = want_vals && h_counts[2] == 0 && h_counts[1] > 0 && h_counts[1] <= TAB;
     // codes in ascending key order (deterministic tables regardless of which thread inserted first)
@@ -1109,6 +1111,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
     DICT_TRY2(hipGetLastError());
     DICT_TRY2(hipMemcpyAsync(h_counts, counts, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
     DICT_TRY2(hipStreamSynchronize(c->stream));
+    tr.lap("    dict encode");
     if (h_counts[3] != 0) { cleanup2(); free_dict(A); return SPRS_OK; }   // cannot happen (every key was inserted)
     {
         // the same schedule for the 64-row blocks of the offset-code stream (variable coefficients: 8-9 B per entry, at
@@ -1143,6 +1146,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
             for (const auto &d : hd) D->n_off_uniform += ((uint32_t)d.rb & UNI2) != 0;
         }
     }
+    tr.lap("    period order + uniform marks (offset stream)");
     if (use_vals) {
         // ---- pair stage: which (offset code, value code) pairs occur?  <= 256 of them -> one byte per nnz
         const int gk = (int)std::max<int64_t>(1, std::min<int64_t>(c->num_cu * 8, (A->nnz + BLOCK - 1) / BLOCK));
@@ -1173,6 +1177,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
                                seen + 65536, D->pair_code);
             DICT_TRY2(hipGetLastError());
             DICT_TRY2(hipStreamSynchronize(c->stream));
+            tr.lap("    pair mark + encode");
             D->n_pair = np;
             if constexpr (sizeof(T) == 8 && !is_complex<T>::value) {
                 // 128-row blocks of the two-rows-per-lane kernel: consecutive pairs of the 64-row blocks
@@ -1209,6 +1214,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
             }
         }
     }
+    tr.lap("    wide descriptors, marks, period order");
     cleanup2();
     return SPRS_OK;
 #undef DICT_TRY
