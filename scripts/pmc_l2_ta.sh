@@ -58,10 +58,19 @@ for which, e in out.items():
         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS"):
             if k in c:
                 d[k + "_over_WAVE_CYCLES"] = c[k] / c["SQ_WAVE_CYCLES"]
-    if "TA_TA_BUSY_sum" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
-        d["ta_busy_fraction_per_ta"] = c["TA_TA_BUSY_sum"] / (c["GRBM_GUI_ACTIVE"] * 256)     # one TA per CU
-    if "TCP_PENDING_STALL_CYCLES_sum" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
-        d["tcp_pending_stall_fraction_per_tcp"] = c["TCP_PENDING_STALL_CYCLES_sum"] / (c["GRBM_GUI_ACTIVE"] * 256)
+    # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs (17.9 M "cycles" for a 1048 us launch at ~2.1 GHz): one XCD's
+    # count is the launch's duration in cycles; TA_* / TCP_* "_sum" counters add up the 256 CUs' units
+    cyc = c.get("GRBM_GUI_ACTIVE", 0) / 8.0
+    if cyc > 0:
+        d["launch_cycles"] = cyc
+        for name, key in (("ta_busy_fraction", "TA_TA_BUSY_sum"), ("ta_addr_stalled_by_tcp_fraction", "TA_ADDR_STALLED_BY_TC_CYCLES_sum"),
+                          ("ta_data_stalled_by_tcp_fraction", "TA_DATA_STALLED_BY_TC_CYCLES_sum"),
+                          ("tcp_pending_stall_fraction", "TCP_PENDING_STALL_CYCLES_sum"),
+                          ("tcp_ta_data_stall_fraction", "TCP_TCP_TA_DATA_STALL_CYCLES_sum")):
+            if key in c:
+                d[name] = c[key] / (cyc * 256)           # mean over the 256 per-CU units
+    if "TCP_TCC_READ_REQ_sum" in c:
+        d["l1_miss_bytes_128B_lines"] = c["TCP_TCC_READ_REQ_sum"] * 128
     e["derived"] = d
 json.dump(out, open("gpurun_out/pmc_l2_ta.json", "w"), indent=1)
 print(json.dumps({k: v.get("derived", v) for k, v in out.items()}, indent=1))

@@ -2,7 +2,7 @@
 #   usage: bash scripts/profile_bench.sh <tag> [extra bench.py flags]
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="bench.py --no-cpu-baseline --no-also --steps 40 --warmup 5 $*"
+B="bench.py --no-cpu-baseline --no-also --steps 100 --warmup 5 $*"
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_stats -- python3 $B > gpurun_out/prof_${tag}_stats.json 2> gpurun_out/prof_${tag}_stats.err || exit 1
 echo "stats pass done"
 timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof_${tag}_fetch -- python3 $B > gpurun_out/prof_${tag}_fetch.json 2> gpurun_out/prof_${tag}_fetch.err || exit 1
