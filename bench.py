@@ -163,15 +163,18 @@ def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8, dot_launches=0):
     return r
 
 
+SPMV_SOURCES = ("device.hpp", "internal.hpp", "scalar.hpp", "spmv.hip", "spmv_dict.hip")
+
+
 def csrc_digest():
-    """sha256 over the kernel sources: a PMC summary taken with other sources is stale (there is no .git on the GPU box)."""
+    """sha256 over the sources that define the SpMV kernels and their launches: a PMC summary taken with other kernels is
+    stale (there is no .git on the GPU box to ask for a commit)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "sprsolve_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp")):
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(name.encode()); h.update(f.read())
+    for name in SPMV_SOURCES:
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode()); h.update(f.read())
     return h.hexdigest()[:16]
 
 
