@@ -70,7 +70,7 @@ def parse():
                     help="poisson3d values: the constant-coefficient operator, or U(-1,1) off-diagonals with a dominant diagonal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=40.0,
+    ap.add_argument("--cpu-seconds", type=float, default=24.0,
                     help="budget of the CPU baseline (both thread legs together); samples keep all rows and cut iterations")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the bootstrap (gloo + SPRS_BENCH_DEVICE + SPRS_RCCL_LIB rehearse "
