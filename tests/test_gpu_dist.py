@@ -139,6 +139,41 @@ def test_dist_operator_equals_plain(env, oracle, with_halo):
     assert np.max(np.abs(xs.cpu().numpy() - (i + j).ravel())) < 1e-5
 
 
+@pytest.mark.parametrize("values", ["poisson", "random"])
+def test_in_launch_finalize_under_load(env, values):
+    """The distributed hand-offs' final reduction is made by the last-arriving workgroup of the producing launch
+    (csrc/device.hpp, finalize_last_block: sc1 stores of the partials, drained, an agent-scope arrival counter, sc1 loads
+    by the workgroup whose add came last).  A stale or missing partial would change a scalar: 300 BiCGStab iterations
+    on a 2 M-row system with full grids (1024 SpMV workgroups, ~500 fused-kernel workgroups, all eight XCDs) through the
+    distributed path at world 1 must reproduce the plain path BIT FOR BIT — every traced scalar and x — three times."""
+    torch, sa, sdist, dev = env["torch"], env["sa"], env["sdist"], env["dev"]
+    from sprsolve_amd import gen_torch
+    nx, ny, nz = 200, 200, 50
+    n = nx * ny * nz
+    ip, ix, dv, rhs = gen_torch.poisson3d(nx, ny, nz, device=dev, values=values)
+    nnz = int(ip[-1].item())
+    plain = sa.HipCsr.from_device((n, n), nnz, ip, ix, dv, adopt=True)
+    ixg = ix.clone()                                          # from_global renumbers in place (world 1: the identity)
+    A = sdist.DistCsr.from_global(env["comm"], np.array([0, n], dtype=np.int64), nnz, ip, ixg, dv, exchange="halo", adopt=True)
+    assert A.plan["peers"] == [] and A.stream_format()[0] == plain.stream_format()[0]
+    K = 300
+
+    def run(op):
+        s = sa.BiCGStab.new(op, n); s.set_trace(K)
+        xs = torch.zeros(n, dtype=torch.float64, device=dev)
+        try:
+            s.solve(rhs, xs, K, 0.0)
+        except sa.error.InsufficientIterNum:
+            pass
+        return s.trace(), xs
+    t0, x0 = run(plain)
+    assert np.isfinite(t0[:50]).all()
+    for rep in range(3):
+        t1, x1 = run(A)
+        assert np.array_equal(t0, t1, equal_nan=True), "scalars differ in repetition %d" % rep
+        assert torch.equal(x0.view(torch.int64), x1.view(torch.int64))
+
+
 def test_comm_allreduce_world1(env):
     torch = env["torch"]
     t = torch.arange(8, dtype=torch.float64, device=env["dev"])
