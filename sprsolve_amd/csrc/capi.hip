@@ -263,26 +263,7 @@ int csr_create_dev(sprs_ctx *c, int64_t nrows, int64_t ncols, int64_t nnz, const
     if (nrows >= INT32_MAX || ncols >= INT32_MAX || nnz >= INT32_MAX) return SPRS_INVALID_ARGUMENT;
     SPRS_HIP_TRY(c, hipSetDevice(c->device));
     CreateTrace tr;
-    // Not a std::vector (value-initialising 200 MB for 50 M rows cost 45 ms before the copy overwrote it), and on
-    // transparent huge pages where the kernel grants them: first-touching 50 k small pages is most of what is left.
-    const size_t rp_bytes = sizeof(int32_t) * ((size_t)nrows + 1);
-    void *rp_mem = nullptr;
-    if (rp_bytes >= ((size_t)8 << 20) && posix_memalign(&rp_mem, (size_t)2 << 20, (rp_bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1)) == 0)
-        (void)madvise(rp_mem, (rp_bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1), MADV_HUGEPAGE);
-    else
-        rp_mem = malloc(rp_bytes);
-    if (!rp_mem) return SPRS_ERR_HIP;
-    std::unique_ptr<void, void (*)(void *)> rp_store(rp_mem, free);
-    int32_t *rp = static_cast<int32_t *>(rp_mem);
-    SPRS_HIP_TRY(c, hipMemcpyAsync(rp, d_rp, sizeof(int32_t) * ((size_t)nrows + 1), hipMemcpyDeviceToHost, c->stream));
-    SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    tr.lap("row_ptr to host");
-    if (rp[0] != 0 || rp[(size_t)nrows] != nnz) return SPRS_INVALID_ARGUMENT;
-    {
-        int worst = 0;           // (vectorisable: no early exit; 50 M rows in a few ms)
-        for (int64_t i = 0; i < nrows; ++i) worst |= rp[i + 1] < rp[i] ? 1 : 0;
-        if (worst) return SPRS_INVALID_ARGUMENT;
-    }
+    // row_ptr stays in HBM: build_rowblocks validates it (and copies it to the host only for irregular matrices)
     sprs_csr *A = new sprs_csr();
     A->ctx = c; A->dtype = dtype_of<T>::value;
     A->nrows = nrows; A->ncols = ncols; A->nnz = nnz;
@@ -303,11 +284,10 @@ int csr_create_dev(sprs_ctx *c, int64_t nrows, int64_t ncols, int64_t nnz, const
         }
         if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(SPRS_ERR_HIP);
     }
-    tr.lap("row_ptr check");
     int st = validate_cols_device(A);
     if (st != SPRS_OK) return fail(st);
     tr.lap("column range check (device)");
-    st = build_rowblocks(A, rp);
+    st = build_rowblocks(A, nullptr);
     if (st != SPRS_OK) return fail(st);
     tr.lap("build_rowblocks total");
     *out = A;

@@ -210,7 +210,7 @@ namespace sprs {
 template <class T>
 int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status,
                 bool conj_x = false, const Fin *fin = nullptr);
-int build_rowblocks(sprs_csr *A, const int32_t *host_row_ptr);
+int build_rowblocks(sprs_csr *A, const int32_t *host_row_ptr);   // host_row_ptr == null: row_ptr lives in HBM only (summaries first)
 int validate_cols_device(const sprs_csr *A);   // SPRS_INVALID_ARGUMENT if any col_idx is outside [0, ncols)
 int spmv_num_partials(const sprs_csr *A);  // workgroups launch_spmv uses == partials it writes
 // per-row-block column span (device kernel + D2H): lo/hi sized n_rowblk
@@ -221,8 +221,8 @@ int launch_spmv_subset(const sprs_csr *A, const int32_t *order, int count, const
                        T *part0, T *part1, const int *status, bool conj_x, const Fin *fin = nullptr);
 int spmv_subset_grid(const sprs_csr *A, int count);
 // ---- spmv_dict.hip
-// SPRS_OK also when the matrix does not qualify (A->dict stays null); blk / host_row_ptr: the row blocks just built
-int build_dict(sprs_csr *A, bool has_vector_blocks, const std::vector<int32_t> &blk, const int32_t *host_row_ptr);
+// SPRS_OK also when the matrix does not qualify (A->dict stays null); blk / blk_pa: the row blocks just built (first row / first entry)
+int build_dict(sprs_csr *A, bool has_vector_blocks, const std::vector<int32_t> &blk, const std::vector<int32_t> &blk_pa);
 void free_dict(sprs_csr *A);
 int dict_mode(const sprs_csr *A);                      // 0 plain, 1 offsets, 2 offsets + values: what launch_spmv will use
 // Should the fused recurrence kernels of a solve on A give every XCD one contiguous eighth of the vectors (spmv.hip)?

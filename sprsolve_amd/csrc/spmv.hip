@@ -18,6 +18,7 @@
 //  * Optional fused epilogue: per-workgroup partials of conj(u).y, or of conj(y).y and
 //    conj(y).u, so the solvers' dot products cost no extra pass over y.
 #include <algorithm>
+#include <memory>
 #include <thread>
 
 #include "device.hpp"
@@ -45,16 +46,138 @@ static void host_parallel_for(int64_t n, int64_t min_chunk, F &&f) {
     for (auto &x : th) x.join();
 }
 
-// Host-side analysis: greedy partition of the rows into blocks (see header comment).
+// Per 64-row group: where its entries start, the shortest and the longest of its rows, and whether row_ptr descends
+// inside it.  With these 16 bytes per group the host cuts a regular matrix (every stencil, every band of <= 7 entries
+// per row) into row blocks WITHOUT seeing row_ptr: 12.5 MB cross PCIe for 50 M rows instead of 200 MB, and no per-row
+// host loop runs at all.
+struct alignas(16) GroupSummary { int32_t first, minlen, maxlen, bad; };
+__global__ __launch_bounds__(BLOCK) void rowgroup_summary_kernel(int64_t n, int64_t ngrp, const int32_t *__restrict__ row_ptr,
+                                                                 GroupSummary *__restrict__ out) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (int64_t g = (int64_t)blockIdx.x * NWAVE + (threadIdx.x >> 6); g < ngrp; g += (int64_t)gridDim.x * NWAVE) {
+        const int64_t r = g * ROWS_CAP + lane;
+        const bool has = r < n;
+        const int32_t a = row_ptr[has ? r : n - 1], b = row_ptr[has ? r + 1 : n];
+        int mn = has ? b - a : INT32_MAX, mx = has ? b - a : INT32_MIN, bad = has && b < a ? 1 : 0;
+        for (int off = WAVE / 2; off > 0; off >>= 1) {
+            mn = min(mn, __shfl_xor(mn, off, WAVE)); mx = max(mx, __shfl_xor(mx, off, WAVE)); bad |= __shfl_xor(bad, off, WAVE);
+        }
+        const int32_t first = __shfl(a, 0, WAVE);
+        if (lane == 0) out[g] = GroupSummary{first, mn, mx, bad};
+    }
+}
+
+// Row blocks of a matrix whose row_ptr lives in HBM, from the per-group summaries.  Fills blk (row starts, VEC_FLAG on
+// vector blocks, n at the end), blk_pa (first entry of every block, nnz at the end) and eq (block has rows of one length).
+// Returns SPRS_OK with *done = false when the matrix is too irregular for this path (the caller then copies row_ptr).
+static int rowblocks_from_summaries(sprs_csr *A, int cap, std::vector<int32_t> &blk, std::vector<int32_t> &blk_pa,
+                                    std::vector<uint8_t> &eq, bool *done) {
+    sprs_ctx *c = A->ctx;
+    const int64_t n = A->nrows, ngrp = (n + ROWS_CAP - 1) / ROWS_CAP;
+    *done = false;
+    GroupSummary *d_sum = nullptr;
+    SPRS_HIP_TRY(c, hipMalloc((void **)&d_sum, sizeof(GroupSummary) * (size_t)ngrp));
+    std::vector<GroupSummary> sum((size_t)ngrp);
+    const int g = (int)std::min<int64_t>((ngrp + NWAVE - 1) / NWAVE, 4096);
+    hipLaunchKernelGGL(rowgroup_summary_kernel, dim3(g), dim3(BLOCK), 0, c->stream, n, ngrp, A->row_ptr, d_sum);
+    hipError_t e1 = hipGetLastError();
+    hipError_t e2 = hipMemcpyAsync(sum.data(), d_sum, sizeof(GroupSummary) * (size_t)ngrp, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e3 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_sum);
+    SPRS_HIP_TRY(c, e1); SPRS_HIP_TRY(c, e2); SPRS_HIP_TRY(c, e3);
+    // irregular groups (a long row, or more entries than a block holds) need their rows; a matrix that has many of them
+    // (ragged rows, bands of 8+ entries per row) takes the per-row path on the whole row_ptr instead
+    int64_t irregular = 0;
+    for (int64_t q = 0; q < ngrp; ++q) {
+        if (sum[(size_t)q].bad) return SPRS_INVALID_ARGUMENT;                 // row_ptr descends
+        const int64_t nxt = q + 1 < ngrp ? sum[(size_t)q + 1].first : A->nnz;
+        if (nxt < sum[(size_t)q].first) return SPRS_INVALID_ARGUMENT;
+        irregular += sum[(size_t)q].maxlen > LONG_ROW || nxt - sum[(size_t)q].first > cap;
+    }
+    if (sum[0].first != 0) return SPRS_INVALID_ARGUMENT;
+    if (irregular > std::max<int64_t>(16, ngrp / 1024)) return SPRS_OK;     // (each run of irregular groups costs one small blocking copy)
+    blk.clear(); blk_pa.clear(); eq.clear();
+    blk.reserve((size_t)ngrp + 64); blk_pa.reserve((size_t)ngrp + 65); eq.reserve((size_t)ngrp + 64);
+    std::vector<int32_t> rows;                                               // row_ptr of one run of irregular groups
+    for (int64_t q = 0; q < ngrp;) {
+        const GroupSummary &S = sum[(size_t)q];
+        const int64_t nxt = q + 1 < ngrp ? sum[(size_t)q + 1].first : A->nnz;
+        if (S.maxlen <= LONG_ROW && nxt - S.first <= cap) {
+            blk.push_back((int32_t)(q * ROWS_CAP)); blk_pa.push_back(S.first);
+            eq.push_back(S.minlen == S.maxlen && S.maxlen >= 1 && S.maxlen <= 0x7fff);
+            ++q;
+            continue;
+        }
+        int64_t q1 = q;                                                      // the run of irregular groups [q, q1)
+        while (q1 < ngrp) {
+            const int64_t nx2 = q1 + 1 < ngrp ? sum[(size_t)q1 + 1].first : A->nnz;
+            if (sum[(size_t)q1].maxlen <= LONG_ROW && nx2 - sum[(size_t)q1].first <= cap) break;
+            ++q1;
+        }
+        const int64_t r0 = q * ROWS_CAP, r1 = std::min<int64_t>(q1 * ROWS_CAP, n);
+        rows.resize((size_t)(r1 - r0 + 1));
+        SPRS_HIP_TRY(c, hipMemcpyAsync(rows.data(), A->row_ptr + r0, sizeof(int32_t) * rows.size(), hipMemcpyDeviceToHost, c->stream));
+        SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const int32_t *rp = rows.data() - r0;                                // rp[r] for r in [r0, r1]
+        for (int64_t r = r0; r < r1;) {                                      // the row-by-row walk of build_rowblocks, inside the run
+            const int64_t len = (int64_t)rp[r + 1] - rp[r];
+            if (len > LONG_ROW) { blk.push_back((int32_t)((uint32_t)r | VEC_FLAG)); blk_pa.push_back(rp[r]); eq.push_back(0); ++r; continue; }
+            int64_t e = r + 1;
+            const int64_t base = rp[r];
+            bool same = true;
+            while (e < r1 && e - r < ROWS_CAP) {
+                const int64_t l2 = (int64_t)rp[e + 1] - rp[e];
+                if (l2 > LONG_ROW || (int64_t)rp[e + 1] - base > cap) break;
+                same = same && l2 == len;
+                ++e;
+            }
+            blk.push_back((int32_t)r); blk_pa.push_back(rp[r]); eq.push_back(same && len >= 1 && len <= 0x7fff);
+            r = e;
+        }
+        q = q1;
+    }
+    blk.push_back((int32_t)n); blk_pa.push_back((int32_t)A->nnz);
+    *done = true;
+    return SPRS_OK;
+}
+
+// Host-side analysis: greedy partition of the rows into blocks (see header comment).  rp: the host's copy of row_ptr, or
+// null for a matrix built in HBM (the blocks then come from per-group summaries where the matrix is regular enough, and
+// row_ptr is copied to the host only where it is not).
 int build_rowblocks(sprs_csr *A, const int32_t *rp) {
     // f64: 4 entries less than the kernels' LDS slice, so that a block's 16-byte-aligned window (up to 3 entries of the
     // previous block in front) still fits two 16-byte loads per lane (spmv_wide_kernel)
     const int cap = A->dtype == DT_D ? nnz_cap_of(A->dtype) - 4 : nnz_cap_of(A->dtype);
     CreateTrace tr;
-    std::vector<int32_t> blk;
+    sprs_ctx *c = A->ctx;
+    std::vector<int32_t> blk, blk_pa;
+    std::vector<uint8_t> eqv;
+    const int64_t n = A->nrows;
+    bool from_summaries = false;
+    std::unique_ptr<int32_t[]> rp_own;
+    if (rp == nullptr && n >= (1 << 16)) {
+        int32_t last = -1;          // row_ptr[n] must be nnz before anything walks the arrays by it (the summaries check the rest)
+        SPRS_HIP_TRY(c, hipMemcpyAsync(&last, A->row_ptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (last != A->nnz) return SPRS_INVALID_ARGUMENT;
+        SPRS_TRY(rowblocks_from_summaries(A, cap, blk, blk_pa, eqv, &from_summaries));
+        tr.lap(from_summaries ? "  row blocks from group summaries" : "  group summaries (matrix too irregular)");
+    }
+    if (!from_summaries && rp == nullptr) {
+        // (uninitialised storage: value-initialising 200 MB for 50 M rows cost 45 ms before the copy overwrote it)
+        rp_own.reset(new int32_t[(size_t)n + 1]);
+        SPRS_HIP_TRY(c, hipMemcpyAsync(rp_own.get(), A->row_ptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, c->stream));
+        SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        rp = rp_own.get();
+        if (rp[0] != 0 || rp[(size_t)n] != A->nnz) return SPRS_INVALID_ARGUMENT;
+        int worst = 0;           // (vectorisable: no early exit)
+        for (int64_t i = 0; i < n; ++i) worst |= rp[i + 1] < rp[i] ? 1 : 0;
+        if (worst) return SPRS_INVALID_ARGUMENT;
+        tr.lap("  row_ptr to host + check");
+    }
+    if (!from_summaries) {
     blk.reserve((size_t)(A->nrows / ROWS_CAP + 16));
     int64_t r = 0;
-    const int64_t n = A->nrows;
     // Handle creation should stay cheap next to the solve it prepares (50 M rows: the per-row host loops were ~100 ms).
     // Which 64-row groups hold a row longer than LONG_ROW is found by all host threads; the greedy walk then takes a whole
     // 64-row block in one step wherever no such row is near and the 64 rows fit the cap (every prefix of them fits too, so
@@ -93,15 +216,17 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
         }
     }
     blk.push_back((int32_t)n);
-    A->n_rowblk = (int32_t)blk.size() - 1;
+    blk_pa.resize(blk.size());
+    for (size_t b = 0; b < blk.size(); ++b) blk_pa[b] = rp[(size_t)((uint32_t)blk[b] & ~VEC_FLAG)];
     tr.lap("  row-block partition");
-    sprs_ctx *c = A->ctx;
+    }
+    A->n_rowblk = (int32_t)blk.size() - 1;
     {
         std::vector<BlkDescHost> desc((size_t)A->n_rowblk);
         for (int b = 0; b < A->n_rowblk; ++b) {
             const uint32_t r0 = (uint32_t)blk[b], r1 = (uint32_t)blk[b + 1];
             const int32_t ra = (int32_t)(r0 & ~VEC_FLAG), rbv = (int32_t)(r1 & ~VEC_FLAG);
-            desc[b] = BlkDescHost{ra, (int32_t)((uint32_t)rbv | (r0 & VEC_FLAG)), rp[ra], rp[rbv] - rp[ra]};
+            desc[b] = BlkDescHost{ra, (int32_t)((uint32_t)rbv | (r0 & VEC_FLAG)), blk_pa[b], blk_pa[b + 1] - blk_pa[b]};
         }
         SPRS_HIP_TRY(c, hipMalloc(&A->blk_desc, sizeof(BlkDescHost) * (desc.size() ? desc.size() : 1)));
         if (!desc.empty())
@@ -110,7 +235,15 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
         // The plain-CSR kernel's own copy: stream blocks whose rows all have the same length L are flagged (rb bit 30,
         // L in nn's upper half) — the kernel then takes the row extents from the descriptor (row i starts at i*L) and
         // does not read row_ptr for the block: 4 B/row less traffic on every stencil / band interior.
-        if (A->nrows < (1 << 30) && c->spmv_eqrows != 0) {
+        if (A->nrows < (1 << 30) && c->spmv_eqrows != 0 && from_summaries) {
+            for (int b = 0; b < A->n_rowblk; ++b) {
+                BlkDescHost &d = desc[(size_t)b];
+                if (d.rb < 0 || !eqv[(size_t)b]) continue;
+                const int rows = d.rb - d.ra;
+                const int L = d.nn / rows;                                   // all rows have this length (group summary / row walk)
+                d.rb = (int32_t)((uint32_t)d.rb | UNI2); d.nn = d.nn | (L << 16); A->n_eq_blocks++;
+            }
+        } else if (A->nrows < (1 << 30) && c->spmv_eqrows != 0) {
             std::vector<int32_t> neq(64, 0);
             host_parallel_for(A->n_rowblk, 1024, [&](int64_t b0, int64_t b1, int tid) {
                 int32_t cnt = 0;
@@ -153,7 +286,7 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
         SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     tr.lap("  rowblk upload + tail");
-    const int st = build_dict(A, has_vec, blk, rp);   // dictionary-compressed stream when the matrix qualifies (spmv_dict.hip)
+    const int st = build_dict(A, has_vec, blk, blk_pa);   // dictionary-compressed stream when the matrix qualifies (spmv_dict.hip)
     tr.lap("  build_dict total");
     return st;
 }

@@ -1022,7 +1022,7 @@ template <> struct has_val_dict<double> { static constexpr bool value = true; };
 template <> struct has_val_dict<float> { static constexpr bool value = true; };
 
 template <class T>
-int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp) {
+int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const std::vector<int32_t> &blk_pa) {
     sprs_ctx *c = A->ctx;
     constexpr bool VALS = has_val_dict<T>::value;
     CreateTrace tr;
@@ -1184,8 +1184,9 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const int32_t *rp
                 const int nb64 = A->n_rowblk, nw = (nb64 + 1) / 2;
                 std::vector<BlkDescHost2> wd((size_t)nw);
                 for (int j = 0; j < nw; ++j) {
-                    const int32_t ra = blk[(size_t)2 * j], rb = blk[(size_t)std::min(2 * j + 2, nb64)];
-                    wd[(size_t)j] = BlkDescHost2{ra, rb, rp[ra], rp[rb] - rp[ra]};
+                    const size_t b0 = (size_t)2 * j, b1 = (size_t)std::min(2 * j + 2, nb64);
+                    const int32_t ra = blk[b0], rb = blk[b1];
+                    wd[(size_t)j] = BlkDescHost2{ra, rb, blk_pa[b0], blk_pa[b1] - blk_pa[b0]};
                 }
                 DICT_TRY2(hipMalloc(&D->wide_desc, sizeof(BlkDescHost2) * (size_t)std::max(nw, 1)));
                 DICT_TRY2(hipMemcpyAsync(D->wide_desc, wd.data(), sizeof(BlkDescHost2) * (size_t)nw, hipMemcpyHostToDevice, c->stream));
@@ -1232,13 +1233,13 @@ void free_dict(sprs_csr *A) {
     A->dict = nullptr;
 }
 
-int build_dict(sprs_csr *A, bool has_vector_blocks, const std::vector<int32_t> &blk, const int32_t *rp) {
+int build_dict(sprs_csr *A, bool has_vector_blocks, const std::vector<int32_t> &blk, const std::vector<int32_t> &blk_pa) {
     if (A->ctx->spmv_dict == 0 || has_vector_blocks || A->nnz == 0 || A->nrows == 0) return SPRS_OK;
     switch (A->dtype) {
-        case DT_D: return build_dict_t<double>(A, blk, rp);
-        case DT_Z: return build_dict_t<cplx>(A, blk, rp);
-        case DT_S: return build_dict_t<float>(A, blk, rp);
-        default: return build_dict_t<cplxf>(A, blk, rp);
+        case DT_D: return build_dict_t<double>(A, blk, blk_pa);
+        case DT_Z: return build_dict_t<cplx>(A, blk, blk_pa);
+        case DT_S: return build_dict_t<float>(A, blk, blk_pa);
+        default: return build_dict_t<cplxf>(A, blk, blk_pa);
     }
 }
 

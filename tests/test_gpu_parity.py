@@ -678,6 +678,57 @@ def test_copy_and_zero_direct(sa, dtype):
         a.free(); b.free()
 
 
+def test_device_built_row_blocks_from_summaries(sa, oracle):
+    """A matrix built in HBM (sprs_csr_create_dev_*) of >= 65536 rows is cut into row blocks from per-64-row-group
+    summaries computed on the device (csrc/spmv.hip, rowblocks_from_summaries): row_ptr crosses PCIe only for the runs of
+    irregular groups (a row > 96 entries, or more entries than a block holds), or as a whole when there are many.
+    y must be bit-identical to the reference fold in every case, and a malformed row_ptr must be refused wherever the
+    flaw sits (inside a group, across groups, at either end)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx = sa.default_ctx()
+    rng = np.random.default_rng(77)
+    n = 200_003                                                     # last group partial
+    for case in ("regular", "few-irregular", "many-irregular"):
+        cnt = np.full(n, 5, dtype=np.int64)
+        cnt[::1000] = 3                                             # rows of another length: blocks that are not equal-length
+        if case != "regular":
+            cnt[12345] = 300; cnt[12346] = 120                      # two long rows: vector blocks inside one run
+            cnt[50_000:50_200] = 9                                  # 64 x 9 = 576 > 508: groups that do not fit one block
+            cnt[n - 30] = 0
+        if case == "many-irregular":
+            cnt[(np.arange(n) // 64) % 20 == 0] = 9                 # 5 % of the groups: the whole row_ptr goes to the host
+        indptr = np.zeros(n + 1, dtype=np.int64); np.cumsum(cnt, out=indptr[1:])
+        nnz = int(indptr[-1])
+        base = np.repeat(np.arange(n), cnt)
+        k_in_row = np.arange(nnz) - np.repeat(indptr[:-1], cnt)
+        indices = ((base + k_in_row * 37) % n).astype(np.int32)       # distinct columns within a row (37 k mod n, k < 300)
+        data = rng.uniform(-1, 1, nnz)
+        x = rng.uniform(-1, 1, n)
+        ref = oracle.spmv(indptr, indices, data, x)
+        ip_d = torch.from_numpy(indptr.astype(np.int32)).to(dev); ix_d = torch.from_numpy(indices).to(dev); dv_d = torch.from_numpy(data).to(dev)
+        xd = torch.from_numpy(x).to(dev); yd = torch.empty_like(xd)
+        for stream in (0, -1):
+            ctx.set("spmv_dict", stream)
+            try:
+                A = sa.HipCsr.from_device((n, n), nnz, ip_d, ix_d, dv_d, adopt=True)
+                A.mul_vec_unchecked(xd, yd)
+            finally:
+                ctx.set("spmv_dict", -1)
+            y = yd.cpu().numpy()
+            short = cnt <= 96
+            assert np.array_equal(bits(y[short]), bits(ref[short])), (case, stream)
+            assert np.all(np.abs(y[~short] - ref[~short]) <= RED_RTOL * 300)
+        if case == "regular":
+            nb, ne = (ctx.set("spmv_dict", 0), sa.HipCsr.from_device((n, n), nnz, ip_d, ix_d, dv_d, adopt=True).wide_blocks())[1]
+            ctx.set("spmv_dict", -1)
+            assert nb == (n + 63) // 64 and 0 < ne < nb               # equal-length flags straight from the summaries
+            for where, val in ((0, 1), (777, int(indptr[779]) + 1), (64 * 500, int(indptr[64 * 500 + 1]) + 5), (n, nnz + 1), (n, nnz - 1)):
+                bad = indptr.astype(np.int32).copy(); bad[where] = val
+                with pytest.raises(ValueError):
+                    sa.HipCsr.from_device((n, n), nnz, torch.from_numpy(bad).to(dev), ix_d, dv_d, adopt=True)
+
+
 def test_malformed_host_matrix_is_refused(sa):
     """A matrix whose arrays would make a kernel read outside x / val must be refused at creation with
     SPRS_INVALID_ARGUMENT — never reach a launch.  Covers the off-by-one that a page-boundary fault looks like
