@@ -141,6 +141,113 @@ void FN(diag_apply)(int64_t n, const void *dinv, int dinv_complex, const T *in, 
     FN(pc_apply)(n, dinv, dinv_complex, in, out);
 }
 
+/* ------------------------------------------------------------------ reductions as the SOLVERS call them
+ *
+ * orc_red_mode 0 (default): the reference's serial left folds above (vecalg.rs:563-568, 601-605).
+ * orc_red_mode 1: the SAME products, added in the order of libsprsolve_hip's stand-alone reduction kernels
+ * (sprsolve_amd/csrc/blas1.hip dot_kernel / nrm2sq_kernel / finalize_kernel, csrc/device.hpp block_sum): per thread
+ * a grid-stride fold over 16-byte packs, a 64-lane butterfly per wavefront (v[l] += v[l + off], off = 32 .. 1), the
+ * four wavefronts of a workgroup left to right, one partial per workgroup, the partials folded the same way by one
+ * workgroup.  Only the ORDER of additions differs from the reference; every product and every element-wise statement
+ * is unchanged.  Purpose (test infrastructure): with SpMV and the element-wise kernels bit-exact, the library's
+ * "literal" solver mode then has to reproduce this oracle's whole recurrence BIT FOR BIT — every scalar of every
+ * iteration, every restart / breakdown / convergence decision — which pins the host recurrences statement for
+ * statement instead of to a tolerance (tests/test_gpu_parity.py::test_literal_mode_is_the_oracle_bit_for_bit). */
+static T FN(tree256)(T *v) {                         /* block_sum over 256 threads; v is clobbered */
+    T w[4];
+    for (int wv = 0; wv < 4; ++wv) {
+        T *q = v + 64 * wv;
+        for (int off = 32; off > 0; off >>= 1)
+            for (int l = 0; l < off; ++l) q[l] = S(add)(q[l], q[l + off]);
+        w[wv] = q[0];
+    }
+    T acc = w[0];
+    for (int wv = 1; wv < 4; ++wv) acc = S(add)(acc, w[wv]);
+    return acc;
+}
+static R FN(tree256r)(R *v) {
+    R w[4];
+    for (int wv = 0; wv < 4; ++wv) {
+        R *q = v + 64 * wv;
+        for (int off = 32; off > 0; off >>= 1)
+            for (int l = 0; l < off; ++l) q[l] = q[l] + q[l + off];
+        w[wv] = q[0];
+    }
+    return ((w[0] + w[1]) + w[2]) + w[3];
+}
+static int64_t FN(red_grid)(int64_t n, int pk) {     /* blas1.hip red_grid -> internal.hpp balanced_grid */
+    const int64_t work = (n / pk + 255) / 256, g0 = orc_red_grid;
+    if (work <= g0) return work < 1 ? 1 : work;
+    const int64_t trips = (work + g0 - 1) / g0;
+    int64_t g = (work + trips - 1) / trips;
+    g = (g + 7) & ~(int64_t)7;
+    return g > g0 ? g0 : g;
+}
+static T FN(gpu_order_dot)(int64_t n, const T *x, const T *y, int conj) {
+    const int pk = sizeof(T) >= 16 ? 1 : (int)(16 / sizeof(T));
+    const int64_t g = FN(red_grid)(n, pk), np = n / pk, st = g * 256;
+    T *part = (T *)malloc(sizeof(T) * (size_t)g);
+    T v[256];
+    for (int64_t b = 0; b < g; ++b) {
+        for (int t = 0; t < 256; ++t) {
+            T acc = S(zero)();
+            for (int64_t i = b * 256 + t; i < np; i += st)
+                for (int e = 0; e < pk; ++e) {
+                    const int64_t k = i * pk + e;
+                    acc = S(add)(acc, S(mul)(conj ? S(conj)(x[k]) : x[k], y[k]));
+                }
+            if (pk > 1) {
+                const int64_t k = np * pk + b * 256 + t;
+                if (k < n) acc = S(add)(acc, S(mul)(conj ? S(conj)(x[k]) : x[k], y[k]));
+            }
+            v[t] = acc;
+        }
+        part[b] = FN(tree256)(v);
+    }
+    for (int t = 0; t < 256; ++t) {
+        T acc = S(zero)();
+        for (int64_t j = t; j < g; j += 256) acc = S(add)(acc, part[j]);
+        v[t] = acc;
+    }
+    free(part);
+    return FN(tree256)(v);
+}
+static R FN(gpu_order_norm2)(int64_t n, const T *x) {
+    const int pk = sizeof(T) >= 16 ? 1 : (int)(16 / sizeof(T));
+    const int64_t g = FN(red_grid)(n, pk), np = n / pk, st = g * 256;
+    R *part = (R *)malloc(sizeof(R) * (size_t)g);
+    R v[256];
+    for (int64_t b = 0; b < g; ++b) {
+        for (int t = 0; t < 256; ++t) {
+            R acc = 0;
+            for (int64_t i = b * 256 + t; i < np; i += st)
+                for (int e = 0; e < pk; ++e) acc = acc + S(sq)(x[i * pk + e]);
+            if (pk > 1) {
+                const int64_t k = np * pk + b * 256 + t;
+                if (k < n) acc = acc + S(sq)(x[k]);
+            }
+            v[t] = acc;
+        }
+        part[b] = FN(tree256r)(v);
+    }
+    for (int t = 0; t < 256; ++t) {
+        R acc = 0;
+        for (int64_t j = t; j < g; j += 256) acc = acc + part[j];
+        v[t] = acc;
+    }
+    free(part);
+    return R_SQRT(FN(tree256r)(v));                   /* vecalg.rs:604 */
+}
+static T FN(s_cdot)(int64_t n, const T *x, const T *y) {
+    return orc_red_mode == 1 ? FN(gpu_order_dot)(n, x, y, 1) : FN(conj_dot)(n, x, y);
+}
+static R FN(s_norm2)(int64_t n, const T *x) {
+    return orc_red_mode == 1 ? FN(gpu_order_norm2)(n, x) : FN(norm2)(n, x);
+}
+/* for tests of the emulation itself */
+T FN(conj_dot_gpu_order)(int64_t n, const T *x, const T *y) { return FN(gpu_order_dot)(n, x, y, 1); }
+R FN(norm2_gpu_order)(int64_t n, const T *x) { return FN(gpu_order_norm2)(n, x); }
+
 /* ------------------------------------------------------------------ bicg_stab.rs */
 
 static void FN(trace8)(double *trace, int64_t cap, int64_t *cnt, double a0, double a1, T b, T c, T d) {
@@ -166,7 +273,7 @@ int FN(bicgstab)(int64_t size, const int64_t *indptr, const int64_t *indices, co
     if (n != size) return ORC_INCOMPATIBLE_RHS;          /* :44-48 */
     if (n != x_len) return ORC_INCOMPATIBLE_X;           /* :49-53 */
 
-    R rhs_norm = FN(norm2)(n, rhs);                 /* :55 */
+    R rhs_norm = FN(s_norm2)(n, rhs);                 /* :55 */
     if (rhs_norm <= R_EPS) {                       /* :56-60 */
         for (int64_t i = 0; i < n; ++i) x[i] = S(zero)();
         *its_out = 0; *res_out = rhs_norm;
@@ -182,7 +289,7 @@ int FN(bicgstab)(int64_t size, const int64_t *indptr, const int64_t *indices, co
     FN(mv)(&A, x, r);                                    /* :73 */
     FN(axpy)(n, S(neg)(S(one)()), rhs, r);               /* :75  r = A x - rhs */
     memcpy(r0, r, (size_t)n * sizeof(T));                /* :78 */
-    R r0_norm = FN(norm2)(n, r0);                   /* :80 */
+    R r0_norm = FN(s_norm2)(n, r0);                   /* :80 */
     if (r0_norm <= tol2) {                               /* :81-83 */
         *its_out = 0; *res_out = r0_norm / rhs_norm;
         return ORC_OK;
@@ -198,14 +305,14 @@ int FN(bicgstab)(int64_t size, const int64_t *indptr, const int64_t *indices, co
         memcpy(y, r, (size_t)n * sizeof(T));             /* :91 */
     }
     FN(mv)(&A, y, v);                                    /* :93 / :263 */
-    T alpha = S(div)(rho, FN(conj_dot)(n, r0, v));       /* :96 */
+    T alpha = S(div)(rho, FN(s_cdot)(n, r0, v));       /* :96 */
     FN(axpy)(n, S(neg)(alpha), v, r);                    /* :100 */
     const T *sz = r;                                     /* \hat s: r (no precond) or z */
     if (pc) { FN(pc_apply)(n, pc, pc_complex, r, z); sz = z; }   /* :273 */
     FN(mv)(&A, sz, t);                                   /* :104 / :275 */
-    T tmp = FN(conj_dot)(n, t, t);                       /* :107 */
+    T tmp = FN(s_cdot)(n, t, t);                       /* :107 */
     T w;
-    if (S(re)(tmp) > 0.0) w = S(div)(FN(conj_dot)(n, t, r), tmp);   /* :108-110 */
+    if (S(re)(tmp) > 0.0) w = S(div)(FN(s_cdot)(n, t, r), tmp);   /* :108-110 */
     else w = S(zero)();                                  /* :112 */
     FN(axpy)(n, S(neg)(alpha), y, x);                    /* :115 */
     FN(axpy)(n, S(neg)(w), sz, x);                       /* :117 / :290 */
@@ -213,19 +320,19 @@ int FN(bicgstab)(int64_t size, const int64_t *indptr, const int64_t *indices, co
     FN(trace8)(trace, trace_cap, &tr, 0.0, r0_norm, rho, alpha, w);
 
     for (int64_t its = 1; its < max_iter; ++its) {       /* :122 */
-        R r_norm = FN(norm2)(n, r);                 /* :123 */
+        R r_norm = FN(s_norm2)(n, r);                 /* :123 */
         if (r_norm <= tol2) {                            /* :124-126 */
             *its_out = its; *res_out = r_norm / rhs_norm;
             if (trace_rows) *trace_rows = tr;
             return ORC_OK;
         }
         T rho_old = rho;                                 /* :127 */
-        rho = FN(conj_dot)(n, r0, r);                    /* :128 */
+        rho = FN(s_cdot)(n, r0, r);                    /* :128 */
         if (S(abs)(rho) < r0_norm_tol) {                 /* :131 restart */
             FN(mv)(&A, x, r);                            /* :134 */
             FN(axpy)(n, S(neg)(S(one)()), rhs, r);       /* :137 */
             memcpy(r0, r, (size_t)n * sizeof(T));        /* :140 */
-            R rn = FN(norm2)(n, r);                 /* :142 */
+            R rn = FN(s_norm2)(n, r);                 /* :142 */
             rho = S(fromr)(rn * rn);                     /* :143 */
             r0_norm_tol = S(re)(rho) * R_EPS * R_EPS;   /* :144 */
         }
@@ -235,7 +342,7 @@ int FN(bicgstab)(int64_t size, const int64_t *indptr, const int64_t *indices, co
         FN(axpy)(n, S(one)(), r, yp);                               /* :156 / :325 */
         if (pc) FN(pc_apply)(n, pc, pc_complex, p, y);              /* :328 */
         FN(mv)(&A, y, v);                                           /* :160 / :329 */
-        tmp = FN(conj_dot)(n, r0, v);                               /* :163 */
+        tmp = FN(s_cdot)(n, r0, v);                               /* :163 */
         if (S(abs)(tmp) <= 0.0) {                                   /* :164-167 */
             *its_out = its;
             if (trace_rows) *trace_rows = tr;
@@ -245,8 +352,8 @@ int FN(bicgstab)(int64_t size, const int64_t *indptr, const int64_t *indices, co
         FN(axpy)(n, S(neg)(alpha), v, r);                           /* :172 */
         if (pc) FN(pc_apply)(n, pc, pc_complex, r, z);              /* :343 */
         FN(mv)(&A, sz, t);                                          /* :175 / :344 */
-        tmp = FN(conj_dot)(n, t, t);                                /* :178 */
-        if (S(re)(tmp) > 0.0) w = S(div)(FN(conj_dot)(n, t, r), tmp);   /* :179-183 */
+        tmp = FN(s_cdot)(n, t, t);                                /* :178 */
+        if (S(re)(tmp) > 0.0) w = S(div)(FN(s_cdot)(n, t, r), tmp);   /* :179-183 */
         else w = S(zero)();
         FN(axpy)(n, S(neg)(alpha), y, x);                           /* :188 */
         FN(axpy)(n, S(neg)(w), sz, x);                              /* :191 / :357 */
@@ -275,7 +382,7 @@ int FN(minres)(int saunders, int64_t size, const int64_t *indptr, const int64_t 
     if (n != size) return ORC_INCOMPATIBLE_RHS;          /* minres.rs:40-44 */
     if (n != x_len) return ORC_INCOMPATIBLE_X;           /* :45-49 */
 
-    R rhs_norm = FN(norm2)(n, rhs);                 /* :51 */
+    R rhs_norm = FN(s_norm2)(n, rhs);                 /* :51 */
     if (rhs_norm <= R_EPS) {                       /* :52-56 */
         for (int64_t i = 0; i < n; ++i) x[i] = S(zero)();
         *its_out = 0; *res_out = rhs_norm;
@@ -295,11 +402,11 @@ int FN(minres)(int saunders, int64_t size, const int64_t *indptr, const int64_t 
     memcpy(v_new, rhs, (size_t)n * sizeof(T));           /* :77 */
     FN(mv)(&A, x, v_old);                                /* :78 */
     FN(axpy)(n, S(neg)(S(one)()), v_old, v_new);         /* :80  v_new = rhs - A x */
-    R res_norm = FN(norm2)(n, v_new);               /* :81 */
+    R res_norm = FN(s_norm2)(n, v_new);               /* :81 */
     R beta_new, beta_one;
     if (pc) {
         FN(pc_apply)(n, pc, pc_complex, v_new, w_new);   /* :233 */
-        T b2 = FN(conj_dot)(n, v_new, w_new);            /* :235 */
+        T b2 = FN(s_cdot)(n, v_new, w_new);            /* :235 */
         if (S(re)(b2) < R_EPS || S(im)(b2) > R_EPS * S(re)(b2)) {   /* :236-244 */
             *its_out = 0; *res_out = S(re)(b2);
             return ORC_INVALID_PRECOND;
@@ -326,23 +433,23 @@ int FN(minres)(int saunders, int64_t size, const int64_t *indptr, const int64_t 
         if (pc) {
             T *wt = w; w = w_new; w_new = wt;            /* :259,264-265 */
             FN(mv)(&A, w, v_new);                        /* :271 mul_vec_dot(w, v_new) */
-            alpha = FN(conj_dot)(n, w, v_new);
+            alpha = FN(s_cdot)(n, w, v_new);
             q = w;
         } else if (saunders) {
             FN(conj)(n, v, tvec);                        /* cs_minres.rs:99 */
             FN(mv)(&A, tvec, v_new);                     /* cs_minres.rs:101 */
-            alpha = FN(conj_dot)(n, v, v_new);           /* cs_minres.rs:103 */
+            alpha = FN(s_cdot)(n, v, v_new);           /* cs_minres.rs:103 */
             q = tvec;
         } else {
             FN(mv)(&A, v, v_new);                        /* :116 mul_vec_dot(v, v_new) */
-            alpha = FN(conj_dot)(n, v, v_new);
+            alpha = FN(s_cdot)(n, v, v_new);
             q = v;
         }
         FN(axpy)(n, S(fromr)(-beta), v_old, v_new);      /* :117 */
         FN(axpy)(n, S(neg)(alpha), v, v_new);            /* :118 */
         if (pc) {
             FN(pc_apply)(n, pc, pc_complex, v_new, w_new);   /* :276 */
-            T b2 = FN(conj_dot)(n, v_new, w_new);            /* :278 */
+            T b2 = FN(s_cdot)(n, v_new, w_new);            /* :278 */
             if (S(re)(b2) < R_EPS || S(im)(b2) > R_EPS * S(re)(b2)) {   /* :279-287 */
                 *its_out = its; *res_out = S(re)(b2);
                 if (trace_rows) *trace_rows = trn;
@@ -353,7 +460,7 @@ int FN(minres)(int saunders, int64_t size, const int64_t *indptr, const int64_t 
             FN(rscale)(n, ts, v_new);                    /* :290 */
             FN(rscale)(n, ts, w_new);                    /* :291 */
         } else {
-            beta_new = FN(norm2)(n, v_new);              /* :120 */
+            beta_new = FN(s_norm2)(n, v_new);              /* :120 */
             FN(rscale)(n, (R)1 / beta_new, v_new);        /* :121 */
         }
 
@@ -422,7 +529,7 @@ int FN(gauss_seidel)(int64_t size, const int64_t *indptr, const int64_t *indices
     const R tol2 = eps * R_SQRT(b_norm);                         /* :87 */
     FN(mv)(&A, x, work);                                         /* :90 */
     FN(axpy)(n, S(neg)(S(one)()), rhs, work);                    /* :97 */
-    R res = FN(norm2)(n, work);                                  /* :104 */
+    R res = FN(s_norm2)(n, work);                                  /* :104 */
     if (res <= tol2) { *its_out = 1; *res_out = res; return ORC_OK; }   /* :106-108 */
     for (int64_t it = 1; it < max_iter; ++it) {                  /* :110 */
         for (int64_t row = 0; row < n; ++row) {
@@ -433,7 +540,7 @@ int FN(gauss_seidel)(int64_t size, const int64_t *indptr, const int64_t *indices
         }
         FN(mv)(&A, x, work);                                     /* :128 */
         FN(axpy)(n, S(neg)(S(one)()), rhs, work);                /* :131 */
-        res = FN(norm2)(n, work);                                /* :133 */
+        res = FN(s_norm2)(n, work);                                /* :133 */
         if (res <= tol2) { *its_out = it; *res_out = res; return ORC_OK; }   /* :135-137 */
     }
     *its_out = max_iter;                                         /* :139 */

@@ -56,6 +56,9 @@ def lib():
         _lib.orc_dot_c.restype = _C32
         _lib.orc_conj_dot_c.restype = _C32
         _lib.orc_spmv_csr_dot_c.restype = _C32
+        for sfx, rt, ct in (("d", C.c_double, C.c_double), ("z", C.c_double, _C64), ("s", C.c_float, C.c_float), ("c", C.c_float, _C32)):
+            getattr(_lib, "orc_norm2_gpu_order_" + sfx).restype = rt
+            getattr(_lib, "orc_conj_dot_gpu_order_" + sfx).restype = ct
     return _lib
 
 
@@ -73,6 +76,24 @@ def set_threads(n):
 
 def max_threads():
     return int(lib().orc_max_threads())
+
+
+def set_reduction_order(mode, grid=512):
+    """Order in which the SOLVERS add the terms of their dot products / norms: "reference" = the serial left folds of
+    vecalg.rs:563-568,601-605 (default); "gpu" = the same terms in the order of libsprsolve_hip's stand-alone reduction
+    kernels with at most `grid` workgroups (the context knob "grid": 2 per CU).  The library's literal solver mode must
+    then reproduce the oracle's recurrence bit for bit."""
+    lib().orc_set_reduction_order(C.c_int({"reference": 0, "gpu": 1}[mode]), C.c_int(int(grid)))
+
+
+def conj_dot_gpu_order(x, y):
+    s = _sfx(x.dtype); x = _arr(x, x.dtype); y = _arr(y, x.dtype)
+    return _ret(getattr(lib(), "orc_conj_dot_gpu_order_" + s)(C.c_int64(x.size), _p(x), _p(y)), s)
+
+
+def norm2_gpu_order(x):
+    s = _sfx(x.dtype); x = _arr(x, x.dtype)
+    return float(getattr(lib(), "orc_norm2_gpu_order_" + s)(C.c_int64(x.size), _p(x)))
 
 
 def _sfx(dtype):

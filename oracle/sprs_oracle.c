@@ -18,6 +18,7 @@
  */
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <float.h>
@@ -56,6 +57,12 @@ int orc_max_threads(void) {
     return 1;
 #endif
 }
+
+/* summation order of the reductions inside the solver recurrences (krylov_tmpl.h): 0 = the reference's serial folds,
+ * 1 = the order of libsprsolve_hip's stand-alone reduction kernels with at most `grid` workgroups (ctx knob "grid") */
+static int orc_red_mode = 0;
+static int64_t orc_red_grid = 512;
+void orc_set_reduction_order(int mode, int grid) { orc_red_mode = mode; if (grid > 0) orc_red_grid = grid; }
 
 #define ORC_UNDEF_ALL
 /* f64 */

@@ -405,6 +405,125 @@ def test_solver_golden(sa, oracle, case, mode):
     assert res <= case["tol"]
 
 
+@pytest.mark.parametrize("dtype", ALL_DTYPES, ids=ALL_IDS)
+def test_reductions_in_the_oracles_emulated_gpu_order(sa, oracle, dtype):
+    """The oracle can add the terms of a dot product / norm in the order of the library's stand-alone reduction kernels
+    (oracle/krylov_tmpl.h, "reductions as the SOLVERS call them"): grid-stride fold per thread over 16-byte packs, wavefront
+    butterfly, the workgroup's four wavefronts left to right, one partial per workgroup, the partials folded the same
+    way.  The GPU's conj_dot / norm2 must then equal it BIT FOR BIT — the premise of the test below."""
+    grid = sa.default_ctx().get("grid")
+    oracle.set_reduction_order("gpu", grid)
+    try:
+        for n in (1, 3, 255, 256, 257, 511, 5000, 131072, 131075, 1_000_003):
+            x = rand_vec(n, dtype, 40 + n % 7); y = rand_vec(n, dtype, 50 + n % 5)
+            d = sa.vecalg.conj_dot(x, y); e = oracle.conj_dot_gpu_order(x, y)
+            assert np.array_equal(bits(np.array([d], dtype=dtype)), bits(np.array([e], dtype=dtype))), (n, d, e)
+            rdt = np.float32 if is_single(dtype) else np.float64
+            assert np.array_equal(bits(np.array([sa.vecalg.norm2(x)], dtype=rdt)), bits(np.array([oracle.norm2_gpu_order(x)], dtype=rdt))), n
+    finally:
+        oracle.set_reduction_order("reference")
+
+
+_BITWISE_CASES = [c for c in G.load("solver_kat.json")["cases"]]
+
+
+@pytest.mark.parametrize("case", _BITWISE_CASES, ids=lambda c: c["name"])
+def test_literal_mode_is_the_oracle_bit_for_bit(sa, oracle, case):
+    """The strongest statement about the host recurrences this repository can make: with SpMV and every element-wise
+    kernel bit-exact, and the oracle adding its dot products in the GPU kernels' order (the only freedom the parity
+    contract leaves), the library's LITERAL mode — one kernel per reference op, scalars consumed on the host where
+    bicg_stab.rs / minres.rs / cs_minres.rs consume them — must reproduce the oracle's restatement of the reference
+    recurrence BIT FOR BIT over the whole solve of the reference's own test problems: every traced scalar of every
+    iteration (so every restart, breakdown and convergence decision), the iteration count, the residual and x.
+    (The default fused mode regroups the same terms differently again and is compared with this one to rounding.)"""
+    p = G.solver_problem(case)
+    A, solver, pc = _make(sa, case, p)
+    solver.set_mode("literal")
+    K = 4096
+    solver.set_trace(K)
+    x = np.zeros_like(p["rhs"])
+    oracle.set_reduction_order("gpu", sa.default_ctx().get("grid"))
+    try:
+        ref = getattr(oracle, case["solver"])(p["indptr"], p["indices"], p["data"], p["rhs"], np.zeros_like(p["rhs"]),
+                                              case["max_iter"], case["tol"], precond_diag=p["diag"], trace_cap=K)
+    finally:
+        oracle.set_reduction_order("reference")
+    assert ref.status == oracle.OK
+    if pc is not None:
+        iters, res = solver.precond_solve(pc, p["rhs"], x, case["max_iter"], case["tol"])
+    else:
+        iters, res = solver.solve(p["rhs"], x, case["max_iter"], case["tol"])
+    tr = solver.trace()
+    assert iters == ref.its and res == ref.res, (iters, ref.its, res, ref.res)
+    assert tr.shape == ref.trace.shape and tr.shape[0] >= min(ref.its, 2)
+    assert np.array_equal(tr.view(np.uint64), ref.trace.view(np.uint64)), \
+        "first differing trace row: %d" % int(np.argmax(np.any(tr.view(np.uint64) != ref.trace.view(np.uint64), axis=1)))
+    assert np.array_equal(bits(x), bits(ref.x))
+
+
+def test_literal_mode_bit_for_bit_on_the_bench_problem_and_cfg2(sa, oracle):
+    """The same on the reference's own bench (benches/bicgstab.rs: 100 x 100 Dirichlet grid, tol 1e-16, max 1500 — about
+    900 iterations, the restart branch live) and on a cfg-2-shaped system (300 x 300, BiCGStab + Jacobi)."""
+    from sprsolve_amd import gen
+    oracle.set_reduction_order("gpu", sa.default_ctx().get("grid"))
+    try:
+        for R, jac, tol, mx in ((100, False, 1e-16, 1500), (300, True, 1e-12, 4000)):
+            indptr, indices, data = gen.grid_laplacian_dirichlet(R, R)
+            rhs = gen.dirichlet_rhs(R, R)
+            n = R * R
+            diag = np.where(np.diff(indptr) == 1, 1.0, -4.0) if jac else None
+            ref = oracle.bicgstab(indptr, indices, data, rhs, np.zeros(n), mx, tol, precond_diag=diag, trace_cap=mx + 1)
+            A = sa.HipCsr.new((n, n), indptr, indices, data)
+            s = sa.BiCGStab.new(A, n); s.set_mode("literal"); s.set_trace(mx + 1)
+            x = np.zeros(n)
+            try:
+                if jac:
+                    iters, res = s.precond_solve(sa.DiagPrecond.new(diag), rhs, x, mx, tol)
+                else:
+                    iters, res = s.solve(rhs, x, mx, tol)
+                status = oracle.OK
+            except sa.error.InsufficientIterNum as e:
+                iters, res, status = e.iters, 0.0, oracle.INSUFFICIENT_ITER
+            assert status == ref.status and iters == ref.its and (status != oracle.OK or res == ref.res), (R, iters, ref.its)
+            tr = s.trace()
+            assert tr.shape == ref.trace.shape and tr.shape[0] > 100
+            assert np.array_equal(tr.view(np.uint64), ref.trace.view(np.uint64)), (R, int(np.argmax(np.any(tr != ref.trace, axis=1))))
+            assert np.array_equal(bits(x), bits(ref.x))
+    finally:
+        oracle.set_reduction_order("reference")
+
+
+def test_literal_csminres_and_f32_bit_for_bit(sa, oracle):
+    """CSMINRES has no reference fixture (its complex branch stays "parity unpinned" against the REFERENCE), but the
+    library and the oracle's line-by-line restatement of cs_minres.rs:29-158 must agree bit for bit over a whole
+    complex-symmetric solve once the reductions share their order; likewise the f32 BiCGStab of the Dirichlet grid."""
+    from sprsolve_amd import gen
+    oracle.set_reduction_order("gpu", sa.default_ctx().get("grid"))
+    try:
+        for rows, cols in ((8, 8), (40, 60)):
+            indptr, indices, data, rhs, diag = gen.complex_symmetric_grid(rows, cols)
+            n = rows * cols
+            ref = oracle.csminres(indptr, indices, data, rhs, np.zeros(n, np.complex128), 2000, 1e-12, trace_cap=2001)
+            A = sa.HipCsr.new((n, n), indptr, indices, data)
+            s = sa.CSMinRes.new(A, n); s.set_mode("literal"); s.set_trace(2001)
+            x = np.zeros(n, np.complex128)
+            its, res = s.solve(rhs, x, 2000, 1e-12)
+            assert ref.status == oracle.OK and its == ref.its and res == ref.res
+            assert np.array_equal(s.trace().view(np.uint64), ref.trace.view(np.uint64)) and np.array_equal(bits(x), bits(ref.x))
+        indptr, indices, data = gen.grid_laplacian_dirichlet(40, 40)
+        rhs = gen.dirichlet_rhs(40, 40).astype(np.float32); data = data.astype(np.float32)
+        n = 1600
+        ref = oracle.bicgstab(indptr, indices, data, rhs, np.zeros(n, np.float32), 800, 1e-6, trace_cap=801)
+        A = sa.HipCsr.new((n, n), indptr, indices, data)
+        s = sa.BiCGStab.new(A, n); s.set_mode("literal"); s.set_trace(801)
+        x = np.zeros(n, np.float32)
+        its, res = s.solve(rhs, x, 800, 1e-6)
+        assert ref.status == oracle.OK and its == ref.its and np.float32(res) == np.float32(ref.res), (its, ref.its, res, ref.res)
+        assert np.array_equal(s.trace().view(np.uint64), ref.trace.view(np.uint64)) and np.array_equal(bits(x), bits(ref.x))
+    finally:
+        oracle.set_reduction_order("reference")
+
+
 @pytest.mark.parametrize("mode", ["fused", "literal"])
 @pytest.mark.parametrize("case", G.load("solver_kat.json")["cases"], ids=lambda c: c["name"])
 def test_solver_trace_lockstep(sa, oracle, case, mode):

@@ -118,3 +118,35 @@ def test_csminres_is_minres_for_real_scalars(oracle, name):
     b = oracle.csminres(p["indptr"], p["indices"], p["data"], p["rhs"], np.zeros_like(p["rhs"]), case["max_iter"], case["tol"])
     assert (a.status, a.its, a.res) == (b.status, b.its, b.res) and a.status == oracle.OK
     assert np.array_equal(a.x.view(np.uint64), b.x.view(np.uint64))
+
+
+def test_gpu_order_reductions_are_a_reordering_only(oracle):
+    """oracle/krylov_tmpl.h, "reductions as the SOLVERS call them": mode "gpu" adds the SAME terms in the order of the
+    library's reduction kernels.  On the CPU this can only be checked as a reordering: sums of exactly representable
+    terms are identical in any order; generic sums agree to rounding; one term or one workgroup's worth of terms folds
+    exactly as the serial loop does for the first lane; the solvers reach the same solutions; the default is the
+    reference's serial fold.  (Bit-for-bit equality with the GPU is tests/test_gpu_parity.py's business.)"""
+    rng = np.random.default_rng(3)
+    for dt in (np.float64, np.complex128, np.float32, np.complex64):
+        for n in (1, 2, 255, 256, 257, 4099, 131075, 300001):
+            x = rng.integers(-8, 9, n).astype(dt); y = rng.integers(-8, 9, n).astype(dt)
+            if np.dtype(dt).kind == "c":
+                x = x + 1j * rng.integers(-8, 9, n).astype(dt); y = y - 1j * rng.integers(-8, 9, n).astype(dt)
+            assert oracle.conj_dot_gpu_order(x, y) == oracle.conj_dot(x, y), (dt, n)        # small integers: exact in any order
+            assert oracle.norm2_gpu_order(x) == oracle.norm2(x)
+            xr = rng.uniform(-1, 1, n).astype(dt); yr = rng.uniform(-1, 1, n).astype(dt)
+            tol = (2e-4 if np.dtype(dt).itemsize in (4, 8) and np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64)) else 1e-12) * max(1.0, float(np.sum(np.abs(xr * yr))))
+            assert abs(oracle.conj_dot_gpu_order(xr, yr) - oracle.conj_dot(xr, yr)) <= tol
+    # the solvers: same solution either way, and the mode is off unless asked for
+    case = [c for c in G.load("solver_kat.json")["cases"] if c["name"] == "bench_laplacian_100"][0]
+    p = G.solver_problem(case)
+    a = oracle.bicgstab(p["indptr"], p["indices"], p["data"], p["rhs"], np.zeros_like(p["rhs"]), case["max_iter"], case["tol"], trace_cap=4)
+    oracle.set_reduction_order("gpu", 512)
+    try:
+        b = oracle.bicgstab(p["indptr"], p["indices"], p["data"], p["rhs"], np.zeros_like(p["rhs"]), case["max_iter"], case["tol"], trace_cap=4)
+    finally:
+        oracle.set_reduction_order("reference")
+    c = oracle.bicgstab(p["indptr"], p["indices"], p["data"], p["rhs"], np.zeros_like(p["rhs"]), case["max_iter"], case["tol"], trace_cap=4)
+    assert a.status == b.status == oracle.OK and np.max(np.abs(a.x - b.x)) < 1e-9 and np.max(np.abs(b.x - p["exact"])) < 1e-9
+    assert np.allclose(a.trace[0], b.trace[0], rtol=1e-12) and not np.array_equal(a.trace, b.trace)      # different order, same numbers
+    assert np.array_equal(a.trace, c.trace) and np.array_equal(a.x, c.x) and a.its == c.its               # the default is untouched
