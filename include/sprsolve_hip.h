@@ -141,6 +141,11 @@ int sprs_csr_stream_format(const sprs_csr *A, int *n_offsets, int *n_pairs);
  * 64-row blocks and how many of them hold rows of equal length (row extents from the descriptor, no row_ptr read).
  * Copies the descriptors to the host: not for hot paths. */
 int sprs_csr_wide_blocks(const sprs_csr *A, int64_t *n_blocks, int64_t *n_uniform);
+/* Diagnostics of the f64 pair-code stream's LDS-window tiles (ctx knob "spmv_tile", csrc/spmv_dict.hip): how many tiles
+ * the SpMV of this handle multiplies from an x window staged in LDS, how many 128-row blocks they cover, and how many
+ * 128-row blocks the same launch walks one by one.  All zero when the handle has no tile plan (other streams, matrices
+ * without long runs of one stencil pattern, cache-resident matrices under the automatic policy). */
+int sprs_csr_tile_plan(const sprs_csr *A, int64_t *n_tiles, int64_t *n_tile_blocks, int64_t *n_other_blocks);
 
 /* MatVecMul::mul_vec / mul_vec_dot (mat.rs:49-64): host slices, checked — returns
  * SPRS_DIM_MISMATCH where the reference panics.  y = A x ; *dot_out = conj(x) . y

@@ -113,6 +113,7 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     else if (k == "spmv_period") c->spmv_period = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_triple") c->spmv_triple = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_seam") c->spmv_seam = value < 0 ? -1 : (value ? 1 : 0);
+    else if (k == "spmv_tile") c->spmv_tile = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "ew_chunk") c->ew_chunk = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "stream_nt") c->stream_nt = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_eqrows") c->spmv_eqrows = value < 0 ? -1 : (value ? 1 : 0);
@@ -135,6 +136,7 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     if (k == "spmv_period") return c->spmv_period;
     if (k == "spmv_triple") return c->spmv_triple;
     if (k == "spmv_seam") return c->spmv_seam;
+    if (k == "spmv_tile") return c->spmv_tile;
     if (k == "ew_chunk") return c->ew_chunk;
     if (k == "stream_nt") return c->stream_nt;
     if (k == "spmv_eqrows") return c->spmv_eqrows;
@@ -577,6 +579,14 @@ int sprs_csr_wide_blocks(const sprs_csr *A, int64_t *n_blocks, int64_t *n_unifor
     SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     *n_blocks = nb;
     for (int64_t j = 0; j < nb; ++j) *n_uniform += ((uint32_t)d[(size_t)j * 4 + 1] & sprs::UNI2) != 0;
+    return SPRS_OK;
+}
+int sprs_csr_tile_plan(const sprs_csr *A, int64_t *n_tiles, int64_t *n_tile_blocks, int64_t *n_other_blocks) {
+    if (!A || !n_tiles || !n_tile_blocks || !n_other_blocks) return SPRS_INVALID_ARGUMENT;
+    *n_tiles = 0; *n_tile_blocks = 0; *n_other_blocks = 0;
+    const sprs_dict *D = A->dict;
+    if (!D || dict_mode(A) != 2 || D->n_tile <= 0 || A->ctx->spmv_tile == 0 || A->ctx->spmv_wide == 0) return SPRS_OK;
+    *n_tiles = D->n_tile; *n_tile_blocks = (int64_t)D->n_tile * sprs::tile_blocks(); *n_other_blocks = D->n_tile_left;
     return SPRS_OK;
 }
 int sprs_csr_stream_format(const sprs_csr *A, int *n_offsets, int *n_values) {

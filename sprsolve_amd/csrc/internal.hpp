@@ -57,6 +57,7 @@ struct sprs_ctx {
     int spmv_period = -1;  // XCD-period walk for matrices with a far band (3-D stencils): -1 automatic = the f64 pair-code stream only, 1 = the offset-code stream too, 0 = off.  Read at creation
     int spmv_triple = -1;  // f64 pair codes, uniform blocks: columns c - 1 and c + 1 read from column c's loads; 0 = off.  Read at creation
     int spmv_seam = -1;    // f64 pair codes: blocks that are uniform but for one or two adjacent rows lacking one slot run the uniform path; 0 = off.  Read at creation
+    int spmv_tile = -1;    // f64 pair codes: LDS x-window tiles for the near columns of uniform stencil runs (spmv_tile_kernel): -1 automatic = matrices whose vectors stream from HBM, 1 = every matrix that has such runs, 0 = off.  Read at creation
     int ew_chunk = -1;     // fused recurrence kernels walk one contiguous eighth of the vectors per XCD: -1 automatic (fused_chunked), 0 / 1
     int stream_nt = -1;    // fused recurrence kernels access their vectors with non-temporal loads / stores: -1 auto (by vector size), 0 / 1
     int spmv_uniform = -1; // ... and blocks whose rows all repeat one code sequence read neither codes nor row_ptr; read at creation
@@ -166,6 +167,16 @@ struct sprs_dict {
     int32_t *off_order = nullptr;  // device: the same schedule for the 64-row blocks of the offset-code stream
     int64_t period = 0;            // the far band it folds over (rows)
     int64_t max_off = -1;          // largest |col - row| of the matrix (-1: unknown)
+    // tile plan of spmv_tile_kernel (f64 pair codes, HBM-sized stencil-like matrices): runs of TILE_B consecutive full
+    // uniform 128-row blocks that share one pattern whose NEAR columns (|col - row| <= TILE_W - 2) are taken from an LDS
+    // window of x; the 128-row blocks outside those runs stay with the per-block walk (tile_left, same launch)
+    int32_t *tile_list = nullptr;  // device: {first 128-row block, first row} of each tile, eight per-XCD sections in row order
+    int32_t *tile_xstart = nullptr;// device, 9 entries: section bounds within tile_list
+    int32_t *tile_left = nullptr;  // device: the other 128-row blocks, in the walk order they had
+    int n_tile = 0, n_tile_left = 0;
+    int tile_ul = 0, tile_fl = 0, tile_fh = 0;   // pattern shape: slots, leading far slots, trailing far slots
+    int32_t tile_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double tile_val[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     void *off_desc = nullptr;      // device: copy of blk_desc for the offset-code stream with the uniform blocks flagged (bit 30, nn = row length)
     int n_off_uniform = 0;
 };
@@ -210,6 +221,7 @@ namespace sprs {
 template <class T>
 int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status,
                 bool conj_x = false, const Fin *fin = nullptr);
+int tile_blocks();   // 128-row blocks per LDS-window tile (spmv_dict.hip)
 int build_rowblocks(sprs_csr *A, const int32_t *host_row_ptr);   // host_row_ptr == null: row_ptr lives in HBM only (summaries first)
 int validate_cols_device(const sprs_csr *A);   // SPRS_INVALID_ARGUMENT if any col_idx is outside [0, ncols)
 int spmv_num_partials(const sprs_csr *A);  // workgroups launch_spmv uses == partials it writes

@@ -25,6 +25,7 @@
 // per-nnz instruction count down (immediate-offset LDS reads, no 64-bit address arithmetic).
 #include <algorithm>
 #include <cstring>
+#include <map>
 
 #include "device.hpp"
 
@@ -740,34 +741,24 @@ struct Blk2Loads {
     int di;                  // ... and the b128 slot they go to
 };
 
+// The walk of the two-rows-per-lane kernels over `n_wide` 128-row blocks (positions of `order`, or natural order): a
+// wavefront takes every (gridDim.x * NWAVE)-th position, the next block's loads are issued before this block's products.
+// Shared by spmv_pair2_kernel (the whole matrix) and spmv_tile_kernel (the blocks outside its tiles).  d0 / d1: the
+// lane's running dot partials (DOT as in launch_spmv).  s_pair: the staged (byte offset, value) table; s_c: NWAVE
+// zero-initialised code slices.
 // YNT: y is written with non-temporal stores (HBM-sized vectors: the result is not read again before it has been evicted)
 template <int DOT, bool YNT>
-__global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_chunk, const BlkDesc *__restrict__ desc,
-                                                           const int32_t *__restrict__ order,
-                                                           const int32_t *__restrict__ row_ptr,
-                                                           const uint8_t *__restrict__ code,
-                                                           const int32_t *__restrict__ off_tab,
-                                                           const double *__restrict__ val_tab, const double *__restrict__ x,
-                                                           double *__restrict__ y, const double *__restrict__ u,
-                                                           double *__restrict__ part0, double *__restrict__ part1,
-                                                           const int *__restrict__ status, int nrows, int ncols, const Fin fin) {
+__device__ __forceinline__ void pair2_walk(int n_wide, int xcd_chunk, const BlkDesc *__restrict__ desc,
+                                           const int32_t *__restrict__ order, const int32_t *__restrict__ row_ptr,
+                                           const uint8_t *__restrict__ code, const double *__restrict__ x,
+                                           double *__restrict__ y, const double *__restrict__ u, int nrows, int ncols,
+                                           const PairEnt<double> *s_pair, uint32_t (*s_c)[CW2], double &d0, double &d1) {
     using T = double;
-    __shared__ PairEnt<T> s_pair[TAB];
-    __shared__ __attribute__((aligned(16))) uint32_t s_c[NWAVE][CW2];
-    __shared__ T red[NWAVE];
-    const int run_state = status != nullptr ? *status : (int)ST_RUNNING;       // looked at after the table loads (one round trip)
-
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    s_pair[tid] = PairEnt<T>{off_tab[tid] * 8, val_tab[tid]};                  // BLOCK == TAB
-    for (int i = lane; i < CW2; i += WAVE) s_c[wv][i] = 0;                     // the pad is read (and ignored) before it is written
-    __syncthreads();
-    if (run_state != ST_RUNNING) return;
-
     const uint8_t *cb = reinterpret_cast<const uint8_t *>(s_c[wv]);
     const char *xbytes = reinterpret_cast<const char *>(x);
     const uint32_t xlast_pair = (uint32_t)(ncols - 2) * 8u;                    // last byte offset a 16-byte x load may start at
-    T d0 = 0.0, d1 = 0.0;
 
     int b, bstep, bend;
     if (xcd_chunk) {
@@ -977,6 +968,240 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
         if (more) stage(nxt);
         dn = uniform(dn2); o2 = __builtin_amdgcn_readfirstlane(o3);
     }
+}
+
+template <int DOT, bool YNT>
+__global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_chunk, const BlkDesc *__restrict__ desc,
+                                                           const int32_t *__restrict__ order,
+                                                           const int32_t *__restrict__ row_ptr,
+                                                           const uint8_t *__restrict__ code,
+                                                           const int32_t *__restrict__ off_tab,
+                                                           const double *__restrict__ val_tab, const double *__restrict__ x,
+                                                           double *__restrict__ y, const double *__restrict__ u,
+                                                           double *__restrict__ part0, double *__restrict__ part1,
+                                                           const int *__restrict__ status, int nrows, int ncols, const Fin fin) {
+    using T = double;
+    __shared__ PairEnt<T> s_pair[TAB];
+    __shared__ __attribute__((aligned(16))) uint32_t s_c[NWAVE][CW2];
+    __shared__ T red[NWAVE];
+    const int run_state = status != nullptr ? *status : (int)ST_RUNNING;       // looked at after the table loads (one round trip)
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    s_pair[tid] = PairEnt<T>{off_tab[tid] * 8, val_tab[tid]};                  // BLOCK == TAB
+    for (int i = lane; i < CW2; i += WAVE) s_c[wv][i] = 0;                     // the pad is read (and ignored) before it is written
+    __syncthreads();
+    if (run_state != ST_RUNNING) return;
+
+    T d0 = 0.0, d1 = 0.0;
+    pair2_walk<DOT, YNT>(n_wide, xcd_chunk, desc, order, row_ptr, code, x, y, u, nrows, ncols, s_pair, s_c, d0, d1);
+    if (DOT >= 1) {
+        d0 = block_sum(d0, red);
+        if (tid == 0) st_partial(fin, part0 + blockIdx.x, d0);
+    }
+    if (DOT == 2) {
+        d1 = block_sum(d1, red);
+        if (tid == 0) st_partial(fin, part1 + blockIdx.x, d1);
+    }
+    if (DOT >= 1 && fin.counter) finalize_last_block<T, T>(fin, DOT == 2, red, red);
+}
+
+// ---- LDS x-window tiles (knob "spmv_tile"; profiles/r03_tuning.md §8) -------------------------------------------------
+// The per-block walk above pulls every column window of a 128-row block through the vector L1 on its own: five 16-byte
+// loads per lane for a 7-point stencil, and the texture-address unit / L1 miss path is what the kernel waits for
+// (TA busy 78 %, 0.45 of the HBM rate).  Consecutive row blocks of a stencil overlap in all their NEAR windows: a
+// workgroup that owns TILE_ROWS consecutive rows needs x[ts - W, ts + TILE_ROWS + W) ONCE for every column within W of the
+// diagonal — (T + 2W) / T = 1.25 loads per lane and 128 rows instead of one per near window — and only the FAR windows
+// (the +-plane neighbours) one by one.  So: a tile = TILE_B consecutive FULL uniform 128-row blocks (plain or seam,
+// mark_uniform_kernel) that share one pattern whose slots are, in row order, FL far slots, UL - FL - FH near slots, FH
+// far slots (sorted columns give exactly that).  The workgroup stages the window in LDS with 16-byte loads, issues the far
+// pair loads of all its rows, and every lane folds its two rows' slots left to right — the same products in the same order
+// as full_uniform_block, x taken from LDS for the near slots: y bit-identical.  Tiles are dealt to the XCDs by their
+// phase within the far period (tile_plan below) so that a far window was some tile's near window on the same L2.  The
+// 128-row blocks outside the tiles (boundary planes, the tiles a boundary line cuts, the matrix ends) are walked by the
+// same launch afterwards (pair2_walk), so the launch writes all of y and one partial per workgroup.
+constexpr int TILE_ROWS = 4096, TILE_W = 512, TILE_B = TILE_ROWS / (2 * WAVE);
+struct TilePat { int32_t off[8]; double val[8]; };
+
+// one thread per candidate tile (blocks [t TILE_B, (t + 1) TILE_B)): its pattern (up to 8 codes, low byte first) and
+// length, or length 0 when the blocks are not TILE_B consecutive full uniform blocks of one pattern
+__global__ __launch_bounds__(BLOCK) void tile_mark_kernel(int n_cand, const BlkDesc *__restrict__ desc, const uint8_t *__restrict__ code,
+                                                          unsigned long long *__restrict__ pat_out, int *__restrict__ len_out) {
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_cand) return;
+    unsigned long long pat0 = 0;
+    int L0 = 0, ra0 = 0;
+    bool ok = true;
+    for (int i = 0; i < TILE_B && ok; ++i) {
+        const BlkDesc d = desc[t * TILE_B + i];
+        const uint32_t rb = (uint32_t)d.rb;
+        ok = (rb & UNI2) != 0;
+        if (!ok) break;
+        const bool seam = (rb & SEAM2) != 0;
+        const int L = d.nn & 0xff;
+        const int nr = seam ? 2 * WAVE : (int)(rb & ~UNI2) - d.ra;
+        unsigned long long pat = 0;
+        for (int j = 0; j < L && j < 8; ++j) pat |= (unsigned long long)code[d.pa + j] << (8 * j);
+        if (i == 0) { pat0 = pat; L0 = L; ra0 = d.ra; }
+        ok = nr == 2 * WAVE && L == L0 && L >= 1 && L <= 8 && pat == pat0 && d.ra == ra0 + i * 2 * WAVE;
+    }
+    pat_out[t] = ok ? pat0 : 0ull;
+    len_out[t] = ok ? L0 : 0;
+}
+
+// UX: the dot operand of DOT == 2 is the input vector itself (K4 without a preconditioner): taken from the window
+template <int DOT, bool UX, int UL, int FL, int FH>
+__global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(const int2 *__restrict__ tile_list, const int32_t *__restrict__ xstart,
+                                                          const BlkDesc *__restrict__ desc, const TilePat pat,
+                                                          int n_left, const int32_t *__restrict__ left_order,
+                                                          const int32_t *__restrict__ row_ptr, const uint8_t *__restrict__ code,
+                                                          const int32_t *__restrict__ off_tab, const double *__restrict__ val_tab,
+                                                          const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ u,
+                                                          double *__restrict__ part0, double *__restrict__ part1,
+                                                          const int *__restrict__ status, int nrows, int ncols, const Fin fin) {
+    using T = double;
+    constexpr int TR = TILE_ROWS, W = TILE_W;
+    constexpr int NW = (TR + 2 * W) / 2 / BLOCK;        // 16-byte window pieces per lane
+    constexpr int NQ = TILE_B / NWAVE;                  // 128-row blocks per wavefront and tile
+    constexpr int NN = UL - FL - FH;                    // near slots
+    static_assert((TR + 2 * W) % (2 * BLOCK) == 0 && TILE_B % NWAVE == 0 && NN >= 1 && UL <= 8, "tile shape");
+    __shared__ __attribute__((aligned(16))) T win[TR + 2 * W];
+    __shared__ PairEnt<T> s_pair[TAB];
+    __shared__ __attribute__((aligned(16))) uint32_t s_c[NWAVE][CW2];
+    __shared__ T red[NWAVE];
+    const int run_state = status != nullptr ? *status : (int)ST_RUNNING;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    s_pair[tid] = PairEnt<T>{off_tab[tid] * 8, val_tab[tid]};                  // BLOCK == TAB (the seam rows' own values; the walk below)
+    for (int i = lane; i < CW2; i += WAVE) s_c[wv][i] = 0;
+    __syncthreads();
+    if (run_state != ST_RUNNING) return;
+    T d0 = 0.0, d1 = 0.0;
+
+    const int xcd = blockIdx.x & 7;
+    const int sstep = gridDim.x >> 3;
+    const int send = xstart[xcd + 1];
+    int s = xstart[xcd] + (blockIdx.x >> 3);
+    // tile_list entries: {first 128-row block, first row}; the next tile's entry is requested a tile ahead
+    // ... and the seam words of its blocks (wave-uniform: scalar loads) are read a tile ahead too
+    int2 ent = s < send ? tile_list[s] : int2{0, 0};
+    int2 ent1 = s + sstep < send ? tile_list[s + sstep] : int2{0, 0};
+    uint32_t rbw[NQ]; int nnw[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const BlkDesc d = desc[__builtin_amdgcn_readfirstlane(ent.x) + q * NWAVE + wv]; rbw[q] = (uint32_t)d.rb; nnw[q] = d.nn; }
+    for (; s < send; s += sstep) {
+        const int ts = __builtin_amdgcn_readfirstlane(ent.y);
+        ent = ent1;
+        if (s + 2 * sstep < send) ent1 = tile_list[s + 2 * sstep];
+        uint32_t rbc[NQ]; int nnc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { rbc[q] = rbw[q]; nnc[q] = nnw[q]; }
+        // ---- loads: the window, then the far pairs (and dot operands) of the lane's NQ row pairs
+        u4v wreg[NW];
+        const T *wbase = x + (ts - W);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) wreg[i] = *reinterpret_cast<const u4v *>(wbase + 2 * (tid + i * BLOCK));
+        D2 far[NQ][FL + FH > 0 ? FL + FH : 1];
+        D2 uu[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const T *xr = x + (ts + ((q * NWAVE + wv) << 7) + 2 * lane);
+#pragma unroll
+            for (int k = 0; k < FL; ++k) far[q][k] = *reinterpret_cast<const D2 *>(xr + pat.off[k]);
+#pragma unroll
+            for (int k = 0; k < FH; ++k) far[q][FL + k] = *reinterpret_cast<const D2 *>(xr + pat.off[UL - FH + k]);
+            if (DOT == 1 || (DOT == 2 && !UX)) uu[q] = *reinterpret_cast<const D2 *>(u + (ts + ((q * NWAVE + wv) << 7) + 2 * lane));
+        }
+        if (s + sstep < send) {
+            const int b1 = __builtin_amdgcn_readfirstlane(ent.x);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { const BlkDesc d = desc[b1 + q * NWAVE + wv]; rbw[q] = (uint32_t)d.rb; nnw[q] = d.nn; }
+        }
+        __syncthreads();                                                        // the previous tile's window has been read
+#pragma unroll
+        for (int i = 0; i < NW; ++i) *reinterpret_cast<u4v *>(&win[2 * (tid + i * BLOCK)]) = wreg[i];
+        __syncthreads();
+        // near slots from the window; the reads of block q + 1 are issued before block q is folded (the seam branch
+        // below keeps the compiler from doing that itself, and a fold behind an exposed LDS round trip eight times per
+        // tile is 10 % of the launch)
+        T npl[NN], nph[NN];
+        auto read_near = [&](int q) {
+            const int li = W + ((q * NWAVE + wv) << 7) + 2 * lane;
+#pragma unroll
+            for (int t = 0; t < NN; ++t) { npl[t] = win[li + pat.off[FL + t]]; nph[t] = win[li + pat.off[FL + t] + 1]; }
+        };
+        read_near(0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const uint32_t rbq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rbc[q]);
+            const bool seam = (rbq & SEAM2) != 0;
+            const int li = W + ((q * NWAVE + wv) << 7) + 2 * lane;              // window index of x[r0]
+            T pl[UL], ph[UL];
+#pragma unroll
+            for (int t = 0; t < UL; ++t) {
+                if (t < FL) { pl[t] = far[q][t].lo; ph[t] = far[q][t].hi; }
+                else if (t >= UL - FH) { pl[t] = far[q][t - (UL - FH) + FL].lo; ph[t] = far[q][t - (UL - FH) + FL].hi; }
+                else { pl[t] = npl[t - FL]; ph[t] = nph[t - FL]; }
+            }
+            T ux0 = 0.0, ux1 = 0.0;
+            if (DOT == 2 && UX) { ux0 = win[li]; ux1 = win[li + 1]; }
+            if (q + 1 < NQ) read_near(q + 1);
+            T acc0 = 0.0, acc1 = 0.0;
+            if (!seam) {
+#pragma unroll
+                for (int t = 0; t < UL; ++t) {
+                    acc0 = acc0 + pl[t] * pat.val[t];
+                    acc1 = acc1 + ph[t] * pat.val[t];
+                }
+            } else {
+                // (full_uniform_block's seam fold) local rows k and k + 1 fold only the slots of their masks, with their
+                // own value where they carry one.  A slot BOTH of them have is a plain step for the whole wavefront (a
+                // scalar test): a stencil's line seam costs two masked steps, not UL
+                const int seam1 = __builtin_amdgcn_readfirstlane(nnc[q]) >> 16, seam2 = (int)(rbq & 0x3ffffffu);
+                const int k = seam1 & 127, maskA = (seam1 >> 7) & 255, maskB = seam2 & 255;
+                const bool a0 = 2 * lane == k, a1 = 2 * lane + 1 == k, b0s = 2 * lane == k + 1, b1s = 2 * lane + 1 == k + 1;
+                if ((seam2 & 0x3000000) == 0) {
+                    // no row with a value of its own (a stencil's line seam): a step is plain unless row k or k + 1 lacks
+                    // the slot (scalar tests), and then those lanes alone keep their sum
+#pragma unroll
+                    for (int t = 0; t < UL; ++t) {
+                        const bool am = ((maskA >> t) & 1) == 0, bm = ((maskB >> t) & 1) == 0;       // scalar
+                        const T n0 = acc0 + pl[t] * pat.val[t], n1 = acc1 + ph[t] * pat.val[t];
+                        if (!am && !bm) { acc0 = n0; acc1 = n1; }
+                        else {
+                            acc0 = ((am && a0) || (bm && b0s)) ? acc0 : n0;
+                            acc1 = ((am && a1) || (bm && b1s)) ? acc1 : n1;
+                        }
+                    }
+                } else {
+                    const T valA = s_pair[(seam2 >> 8) & 255].val, valB = s_pair[(seam2 >> 16) & 255].val;
+                    const bool ovA = ((seam2 >> 24) & 1) != 0, ovB = ((seam2 >> 25) & 1) != 0;
+                    const int pm0 = a0 ? maskA : (b0s ? maskB : 255), pm1 = a1 ? maskA : (b1s ? maskB : 255);
+                    const bool o0 = (a0 && ovA) || (b0s && ovB), o1 = (a1 && ovA) || (b1s && ovB);
+                    const T v0 = a0 ? valA : valB, v1 = a1 ? valA : valB;
+#pragma unroll
+                    for (int t = 0; t < UL; ++t) {
+                        const T n0 = acc0 + pl[t] * (o0 ? v0 : pat.val[t]), n1 = acc1 + ph[t] * (o1 ? v1 : pat.val[t]);
+                        acc0 = ((pm0 >> t) & 1) ? n0 : acc0;
+                        acc1 = ((pm1 >> t) & 1) ? n1 : acc1;
+                    }
+                }
+            }
+            const D2 yy{acc0, acc1};
+            u4v qv;
+            __builtin_memcpy(&qv, &yy, 16);
+            __builtin_nontemporal_store(qv, reinterpret_cast<u4v *>(y + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
+            if (DOT == 1) { d0 = d0 + uu[q].lo * acc0; d0 = d0 + uu[q].hi * acc1; }
+            if (DOT == 2) {
+                const T u0 = UX ? ux0 : uu[q].lo, u1 = UX ? ux1 : uu[q].hi;
+                d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * u0; d0 = d0 + acc1 * acc1; d1 = d1 + acc1 * u1;
+            }
+        }
+    }
+    if (n_left > 0) {
+        __syncthreads();
+        pair2_walk<DOT, true>(n_left, 0, desc, left_order, row_ptr, code, x, y, u, nrows, ncols, s_pair, s_c, d0, d1);
+    }
     if (DOT >= 1) {
         d0 = block_sum(d0, red);
         if (tid == 0) st_partial(fin, part0 + blockIdx.x, d0);
@@ -1014,6 +1239,16 @@ static std::vector<int32_t> xcd_period_order(int nblk, int64_t G, FirstRow first
         }
     }
     return ord;
+}
+
+// (UL, FL, FH) shapes spmv_tile_kernel is built for: 7-point 3-D, 5-point 2-D with a far or a near line band, 3-point 1-D, and
+// bands with two far diagonals
+#define SPRS_TILE_SHAPES(X) X(7, 1, 1) X(5, 1, 1) X(5, 0, 0) X(3, 0, 0) X(3, 1, 1) X(7, 0, 0)
+static bool tile_shape_built(int ul, int fl, int fh) {
+#define SPRS_TILE_HAS(U, L, H) if (ul == U && fl == L && fh == H) return true;
+    SPRS_TILE_SHAPES(SPRS_TILE_HAS)
+#undef SPRS_TILE_HAS
+    return false;
 }
 
 struct BlkDescHost2 { int32_t ra, rb, pa, nn; };
@@ -1205,17 +1440,105 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const std::vector
                 int64_t P = 0;
                 for (const auto &o : offs) P = std::max<int64_t>(P, std::llabs((long long)o.first));
                 const int64_t G = P / 8;
+                std::vector<int32_t> ord;
                 if (c->spmv_period != 0 && G >= 16 * 128 && P * 4 <= A->nrows && nw >= 8 * NWAVE * 8) {      // automatic (-1): on
-                    const std::vector<int32_t> ord = xcd_period_order(nw, G, [&](int j) { return (int64_t)wd[(size_t)j].ra; });
+                    ord = xcd_period_order(nw, G, [&](int j) { return (int64_t)wd[(size_t)j].ra; });
                     DICT_TRY2(hipMalloc((void **)&D->wide_order, sizeof(int32_t) * (size_t)nw));
                     DICT_TRY2(hipMemcpyAsync(D->wide_order, ord.data(), sizeof(int32_t) * (size_t)nw, hipMemcpyHostToDevice, c->stream));
                     DICT_TRY2(hipStreamSynchronize(c->stream));
                     D->period = P;
                 }
+                tr.lap("    wide descriptors, marks, period order");
+                // ---- tile plan (spmv_tile_kernel): runs of TILE_B full uniform blocks with the matrix's most frequent pattern
+                const int n_cand = nw / TILE_B;
+                const bool tile_wanted = c->spmv_tile > 0 || (c->spmv_tile < 0 && stream_loads_nt(c, (size_t)A->nrows * sizeof(T)));
+                if (tile_wanted && c->spmv_uniform != 0 && c->spmv_wide != 0 && n_cand >= 16 && A->ncols >= TILE_ROWS + 2 * TILE_W) {
+                    unsigned long long *pat_d = nullptr; int *len_d = nullptr;
+                    auto drop = [&]() { if (pat_d) (void)hipFree(pat_d); if (len_d) (void)hipFree(len_d); pat_d = nullptr; len_d = nullptr; };
+#define TILE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { snprintf(c->err, sizeof(c->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); drop(); cleanup2(); free_dict(A); return SPRS_ERR_HIP; } } while (0)
+                    TILE_TRY(hipMalloc((void **)&pat_d, sizeof(unsigned long long) * (size_t)n_cand));
+                    TILE_TRY(hipMalloc((void **)&len_d, sizeof(int) * (size_t)n_cand));
+                    hipLaunchKernelGGL(tile_mark_kernel, dim3((n_cand + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n_cand,
+                                       reinterpret_cast<const BlkDesc *>(D->wide_desc), (const uint8_t *)D->pair_code, pat_d, len_d);
+                    TILE_TRY(hipGetLastError());
+                    std::vector<unsigned long long> h_pat((size_t)n_cand);
+                    std::vector<int> h_len((size_t)n_cand);
+                    TILE_TRY(hipMemcpyAsync(h_pat.data(), pat_d, sizeof(unsigned long long) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
+                    TILE_TRY(hipMemcpyAsync(h_len.data(), len_d, sizeof(int) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
+                    TILE_TRY(hipStreamSynchronize(c->stream));
+                    std::map<std::pair<unsigned long long, int>, int> hist;
+                    for (int t = 0; t < n_cand; ++t) if (h_len[(size_t)t] > 0) ++hist[{h_pat[(size_t)t], h_len[(size_t)t]}];
+                    std::pair<unsigned long long, int> canon{0ull, 0};
+                    int best = 0;
+                    for (const auto &kv : hist) if (kv.second > best) { best = kv.second; canon = kv.first; }
+                    const int UL = canon.second;
+                    int FL = 0, FH = 0;
+                    bool shape_ok = best >= 8 && UL >= 1;
+                    int64_t far_band = 0;
+                    if (shape_ok) {
+                        int32_t o[8];
+                        for (int t = 0; t < UL; ++t) {
+                            const int cd = (int)((canon.first >> (8 * t)) & 255u);
+                            o[t] = pair_off[(size_t)cd];
+                            D->tile_off[t] = o[t];
+                            if constexpr (sizeof(T) == 8 && !is_complex<T>::value) D->tile_val[t] = pair_val[(size_t)cd];
+                        }
+                        const int NEAR = TILE_W - 2;
+                        while (FL < UL && o[FL] < -NEAR) ++FL;
+                        while (FH < UL - FL && o[UL - 1 - FH] > NEAR) ++FH;
+                        for (int t = FL; t < UL - FH; ++t) shape_ok = shape_ok && o[t] >= -NEAR && o[t] <= NEAR;
+                        shape_ok = shape_ok && UL - FL - FH >= 1 && tile_shape_built(UL, FL, FH);
+                        for (int t = 0; t < FL; ++t) far_band = std::max<int64_t>(far_band, std::llabs((long long)o[t]));
+                        for (int t = UL - FH; t < UL; ++t) far_band = std::max<int64_t>(far_band, std::llabs((long long)o[t]));
+                    }
+                    if (shape_ok) {
+                        std::vector<char> elig((size_t)n_cand, 0);
+                        int n_elig = 0;
+                        for (int t = 0; t < n_cand; ++t) {
+                            const int64_t ts = wd[(size_t)t * TILE_B].ra;
+                            if (h_len[(size_t)t] == UL && h_pat[(size_t)t] == canon.first && ts - TILE_W >= 0 && ts + TILE_ROWS + TILE_W <= A->ncols) { elig[(size_t)t] = 1; ++n_elig; }
+                        }
+                        // XCD sections: by the tile's phase within the far period (rows r and r +- far_band on one XCD, a near
+                        // window apart in its walk), or plain eighths where no far slot exists / the band does not repeat
+                        const bool periodic = far_band >= 8 * (int64_t)TILE_ROWS && far_band * 4 <= A->nrows && c->spmv_period != 0;
+                        std::vector<std::vector<int32_t>> sec(8);
+                        int seen_e = 0;
+                        for (int t = 0; t < n_cand; ++t) {
+                            if (!elig[(size_t)t]) continue;
+                            const int64_t ts = wd[(size_t)t * TILE_B].ra;
+                            const int xs = periodic ? (int)(((ts % far_band) * 8) / far_band) : (int)(((int64_t)seen_e * 8) / std::max(n_elig, 1));
+                            sec[(size_t)std::min(std::max(xs, 0), 7)].push_back(t * TILE_B);     // (the row goes in below)
+                            ++seen_e;
+                        }
+                        std::vector<int32_t> list, xstart(9, 0), left;
+                        for (int xq = 0; xq < 8; ++xq) {
+                            xstart[(size_t)xq] = (int32_t)(list.size() / 2);
+                            for (int32_t b0 : sec[(size_t)xq]) { list.push_back(b0); list.push_back(wd[(size_t)b0].ra); }      // {first block, first row}
+                        }
+                        xstart[8] = (int32_t)(list.size() / 2);
+                        for (int pos = 0; pos < nw; ++pos) {
+                            const int j = ord.empty() ? pos : ord[(size_t)pos];
+                            if (!(j / TILE_B < n_cand && elig[(size_t)(j / TILE_B)])) left.push_back(j);
+                        }
+                        if (n_elig >= 8) {
+                            TILE_TRY(hipMalloc((void **)&D->tile_list, sizeof(int32_t) * list.size()));
+                            TILE_TRY(hipMalloc((void **)&D->tile_xstart, sizeof(int32_t) * 9));
+                            TILE_TRY(hipMalloc((void **)&D->tile_left, sizeof(int32_t) * std::max<size_t>(left.size(), 1)));
+                            TILE_TRY(hipMemcpyAsync(D->tile_list, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice, c->stream));
+                            TILE_TRY(hipMemcpyAsync(D->tile_xstart, xstart.data(), sizeof(int32_t) * 9, hipMemcpyHostToDevice, c->stream));
+                            if (!left.empty()) TILE_TRY(hipMemcpyAsync(D->tile_left, left.data(), sizeof(int32_t) * left.size(), hipMemcpyHostToDevice, c->stream));
+                            TILE_TRY(hipStreamSynchronize(c->stream));
+                            D->n_tile = n_elig; D->n_tile_left = (int)left.size();
+                            D->tile_ul = UL; D->tile_fl = FL; D->tile_fh = FH;
+                        }
+                    }
+                    drop();
+#undef TILE_TRY
+                    tr.lap("    tile plan");
+                }
             }
         }
     }
-    tr.lap("    wide descriptors, marks, period order");
     cleanup2();
     return SPRS_OK;
 #undef DICT_TRY
@@ -1224,10 +1547,13 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const std::vector
 
 }  // namespace
 
+int tile_blocks() { return TILE_B; }
+
 void free_dict(sprs_csr *A) {
     if (!A || !A->dict) return;
     sprs_dict *D = A->dict;
-    for (void *q : {(void *)D->idx_code, (void *)D->pair_code, (void *)D->off_tab, (void *)D->pair_off, D->pair_val, D->wide_desc, D->off_desc, (void *)D->wide_order, (void *)D->off_order})
+    for (void *q : {(void *)D->idx_code, (void *)D->pair_code, (void *)D->off_tab, (void *)D->pair_off, D->pair_val, D->wide_desc, D->off_desc, (void *)D->wide_order, (void *)D->off_order,
+                    (void *)D->tile_list, (void *)D->tile_xstart, (void *)D->tile_left})
         if (q) (void)hipFree(q);
     delete D;
     A->dict = nullptr;
@@ -1275,6 +1601,26 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
         if (order == nullptr && count == A->n_rowblk) { count_w = D->n_wide; order_w = c->spmv_period != 0 ? D->wide_order : nullptr; if (order_w) xcd_chunk = 0; }   // the period order encodes its XCD placement for the round-robin walk
         else if (A->dist && A->dist->order_int_w && order == A->dist->order_int && count == A->dist->n_int) { order_w = A->dist->order_int_w; count_w = A->dist->n_int_w; }
         else if (A->dist && A->dist->order_bnd_w && order == A->dist->order_bnd && count == A->dist->n_bnd) { order_w = A->dist->order_bnd_w; count_w = A->dist->n_bnd_w; }
+        if (pair && D->n_tile > 0 && c->spmv_tile != 0 && c->spmv_wide != 0 && order == nullptr && count == A->n_rowblk && g % 8 == 0) {
+            // LDS x-window tiles + the per-block walk over the blocks outside them, one launch
+            const BlkDesc *wd = reinterpret_cast<const BlkDesc *>(D->wide_desc);
+            const double *pvd = reinterpret_cast<const double *>(D->pair_val);
+            TilePat tp;
+            for (int t = 0; t < 8; ++t) { tp.off[t] = D->tile_off[t]; tp.val[t] = D->tile_val[t]; }
+            const bool ux = dot_mode == 2 && u == x;
+#define SPRS_TSPMV(DM, UXV, U, L, H) SPRS_LAUNCH_SPMV(c, (spmv_tile_kernel<DM, UXV, U, L, H>), g, reinterpret_cast<const int2 *>(D->tile_list), D->tile_xstart, wd, tp, D->n_tile_left, \
+                                                      D->tile_left, A->row_ptr, D->pair_code, D->pair_off, pvd, x, y, u, part0, part1, status, (int)A->nrows, (int)A->ncols, fin)
+#define SPRS_TSHAPE(U, L, H)                                                                                             \
+            if (D->tile_ul == U && D->tile_fl == L && D->tile_fh == H) {                                                 \
+                if (dot_mode == 0) SPRS_TSPMV(0, false, U, L, H); else if (dot_mode == 1) SPRS_TSPMV(1, false, U, L, H);   \
+                else if (ux) SPRS_TSPMV(2, true, U, L, H); else SPRS_TSPMV(2, false, U, L, H);                           \
+            }
+            SPRS_TILE_SHAPES(SPRS_TSHAPE)
+#undef SPRS_TSHAPE
+#undef SPRS_TSPMV
+            SPRS_HIP_TRY(c, hipGetLastError());
+            return SPRS_OK;
+        }
         if (pair && D->wide_desc && c->spmv_wide != 0 && count_w >= 0 && A->nrows >= 2 && A->ncols >= 2) {
             const int gw = g;     // same grid as the 64-row kernel: the consumers reduce exactly spmv_num_partials(A) partials
             const BlkDesc *wd = reinterpret_cast<const BlkDesc *>(D->wide_desc);

@@ -104,6 +104,12 @@ class HipCsr(MatVecMul):
         check(_lib.lib().sprs_csr_wide_blocks(self.h, C.byref(nb), C.byref(nu)), self.ctx.h)
         return nb.value, nu.value
 
+    def tile_plan(self):
+        """(n_tiles, n_tile_blocks, n_other_blocks) of the f64 pair-code stream's LDS-window tiles (knob spmv_tile), else zeros."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(_lib.lib().sprs_csr_tile_plan(self.h, C.byref(a), C.byref(b), C.byref(c)), self.ctx.h)
+        return a.value, b.value, c.value
+
     # -------------------------------------------------------------- MatVecMul
     def _s(self):
         return sfx(self.dtype)

@@ -24,6 +24,7 @@ def _restore_knob(sa):
     sa.default_ctx(0).set("spmv_wide", -1)
     sa.default_ctx(0).set("spmv_triple", -1)
     sa.default_ctx(0).set("spmv_seam", -1)
+    sa.default_ctx(0).set("spmv_tile", -1)
 
 
 def bits(a):
@@ -629,3 +630,105 @@ def test_xcd_period_schedule_is_a_pure_reordering(sa, oracle):
     finally:
         ctx.set("spmv_period", -1)
         ctx.set("spmv_triple", -1)
+
+
+
+def _tile_cases():
+    from sprsolve_amd import gen
+    def p3(nx, ny, nz):
+        ip, ix, d, rhs = gen.poisson3d(nx, ny, nz)
+        return ip, ix, d, rhs, 1.0
+    def dirichlet(r):
+        ip, ix, d = gen.grid_laplacian_dirichlet(r, r)
+        return ip, ix, d, (gen.dirichlet_rhs(r, r) if r <= 300 else None), None      # (the 1000 x 1000 solve needs > 3000 iterations)
+    def tridiag(n):
+        ip = np.concatenate([[0], np.cumsum(np.r_[2, np.full(n - 2, 3), 2])]).astype(np.int32)
+        ix = np.concatenate([[0, 1]] + [np.arange(i - 1, i + 2) for i in range(1, n - 1)] + [[n - 2, n - 1]]).astype(np.int32)
+        d = np.concatenate([[2.5, -1.0]] + [np.array([-1.0, 2.5, -1.0])] * (n - 2) + [[-1.0, 2.5]])
+        return ip, ix, d, None, None
+    return {
+        "p3_160x128x12_eighths": lambda: p3(160, 128, 12),        # shape (7, 1, 1); plane = 5 tiles: dealt in eighths
+        "p3_160x256x8_period": lambda: p3(160, 256, 8),           # far band 40960 = 10 tiles: the period sections
+        "p3_500x100x8_seams": lambda: p3(500, 100, 8),            # cfg 5's line length: 8 seams per tile
+        "p2_dirichlet_1000_far_lines": lambda: dirichlet(1000),   # (5, 1, 1): +-1000 are far; identity rows with their own value
+        "p2_dirichlet_300_near_lines": lambda: dirichlet(300),    # (5, 0, 0): everything from the window
+        "tridiagonal_200k": lambda: tridiag(200_000),             # (3, 0, 0)
+    }
+
+
+@pytest.mark.parametrize("name", list(_tile_cases()))
+def test_lds_window_tiles_bit_identical(sa, oracle, name):
+    """Knob spmv_tile (csrc/spmv_dict.hip, spmv_tile_kernel): runs of 32 full uniform 128-row blocks of one stencil pattern are
+    multiplied from an x window staged in LDS (near columns) plus per-row-pair far loads; the remaining blocks by the
+    per-block walk inside the SAME launch.  Same products, same left-to-right fold per row: y bit-identical to the oracle,
+    to the per-block kernel and in all three launch flavours (plain, fused dot, fused double dot inside a solve)."""
+    ctx = sa.default_ctx(0)
+    indptr, cols, data, rhs, exact = _tile_cases()[name]()
+    n = indptr.size - 1
+    x = rand_vec(n, np.float64, 77)
+    ref = oracle.spmv(indptr, cols, data, x)
+    e = oracle.conj_dot(x, ref)
+    plans = {}
+    try:
+        for tile in (0, 1):
+            ctx.set("spmv_tile", tile)
+            A = sa.HipCsr.new((n, n), indptr, cols, data)
+            assert A.stream_format()[0] == 2
+            plans[tile] = A.tile_plan()
+            y = np.full(n, 9.0)
+            A.mul_vec(x, y)
+            assert np.array_equal(bits(y), bits(ref)), (tile, int(np.argmax(y != ref)))
+            y2 = np.full(n, -3.0)
+            d = A.mul_vec_dot(x, y2)
+            assert np.array_equal(bits(y2), bits(ref))
+            assert abs(d - e) <= 1e-12 * max(1.0, float(np.sum(np.abs(x * ref))))
+            if rhs is not None:
+                s = sa.BiCGStab.new(A, n)
+                sol = np.zeros(n)
+                its, res = s.solve(rhs, sol, 3000, 1e-9)
+                r = rhs - oracle.spmv(indptr, cols, data, sol)
+                assert np.linalg.norm(r) <= 1e-8 * np.linalg.norm(rhs) + 1e-9, (tile, its, res)
+                if exact is not None:
+                    assert np.max(np.abs(sol - exact)) < 1e-6
+        assert plans[0] == (0, 0, 0)
+        nt, ntb, nob = plans[1]
+        nb, nu = A.wide_blocks()
+        assert nt >= 8 and ntb == 32 * nt and ntb + nob == nb, (plans, nb)
+        assert ntb >= 0.3 * nb, (plans, nb)                               # a good part of the matrix runs through tiles
+    finally:
+        ctx.set("spmv_tile", -1)
+
+
+def test_lds_window_tiles_policy_and_fallbacks(sa, oracle):
+    """Automatic policy: cache-resident matrices keep the per-block kernel (no plan); patterns the kernel is not built for
+    (near slots beyond the window, unsorted far / near order, more than 8 slots) get no plan under spmv_tile = 1 either and
+    stay bit-exact; a preconditioned solve (the double dot's operand is NOT the input vector) agrees with the per-block one."""
+    from sprsolve_amd import gen
+    ctx = sa.default_ctx(0)
+    ip, ix, d, rhs = gen.poisson3d(160, 128, 12)
+    n = rhs.size
+    A = sa.HipCsr.new((n, n), ip, ix, d)
+    assert A.tile_plan() == (0, 0, 0)                                      # automatic: 2 MB vectors
+    try:
+        ctx.set("spmv_tile", 1)
+        # two far bands on each side (nx = 600 > window): shape (7, 2, 2) is not built
+        ip2, ix2, d2, _ = gen.poisson3d(600, 20, 20)
+        n2 = ip2.size - 1
+        A2 = sa.HipCsr.new((n2, n2), ip2, ix2, d2)
+        assert A2.stream_format()[0] == 2 and A2.tile_plan() == (0, 0, 0)
+        x2 = rand_vec(n2, np.float64, 5); y2 = np.zeros(n2); A2.mul_vec(x2, y2)
+        assert np.array_equal(bits(y2), bits(oracle.spmv(ip2, ix2, d2, x2)))
+        # Jacobi-preconditioned BiCGStab: K4's operand differs from its input
+        A = sa.HipCsr.new((n, n), ip, ix, d)
+        assert A.tile_plan()[0] >= 8
+        diag = np.full(n, 6.0)
+        out = []
+        for tile in (1, 0):
+            ctx.set("spmv_tile", tile)          # the launch honours the knob at run time too
+            s = sa.BiCGStab.new(A, n); sol = np.zeros(n)
+            its, res = s.precond_solve(sa.DiagPrecond.new(diag), rhs, sol, 2000, 1e-10)
+            assert np.max(np.abs(sol - 1.0)) < 1e-7
+            out.append(its)
+        assert abs(out[0] - out[1]) <= max(3, out[0] // 10)
+    finally:
+        ctx.set("spmv_tile", -1)
