@@ -56,7 +56,10 @@ STREAM_NAMES = {0: "csr", 1: "offset-codes", 2: "pair-codes"}
 KERNEL_NAMES = {0: "spmv_kernel<double> (plain CSR stream, wavefront-private LDS products, fused dot epilogue; csrc/spmv.hip)",
                 1: "spmv_dict_kernel<double, PAIR=false> (one-byte column-offset codes + 8-byte values; csrc/spmv_dict.hip)",
                 2: "spmv_pair2_kernel<DOT> (one-byte (offset, value) pair codes, two rows per lane, uniform blocks from a scalar "
-                   "pattern; csrc/spmv_dict.hip)"}
+                   "pattern; csrc/spmv_dict.hip)",
+                3: "spmv_tile_kernel<DOT> (pair codes; runs of 4096 rows of one stencil pattern multiplied from an x window staged in "
+                   "LDS + per-row-pair far loads, tiles dealt to the XCDs by the far period; the other 128-row blocks by the "
+                   "per-block walk of the same launch; csrc/spmv_dict.hip)"}
 
 
 def parse():
@@ -132,16 +135,20 @@ def stream_info(A, n, nnz, s):
     uf = nu / nb if nb else 0.0
     code_b = 0 if mode == 0 else 1
     moved = int(nnz * (per_nnz - code_b) + (1.0 - uf) * (nnz * code_b + (n + 1) * 4) + 2 * n * s)
-    return dict(stream=STREAM_NAMES[mode], mode=mode, distinct_offsets=n_off, distinct_pairs=n_pair,
-                bytes_per_nnz=per_nnz, format_bytes_per_launch=nnz * per_nnz + (n + 1) * 4 + 2 * n * s,
-                row_blocks=nb, descriptor_only_blocks=nu, bytes_moved_per_launch=moved)
+    tiles = A.tile_plan() if hasattr(A, "tile_plan") else (0, 0, 0)
+    out = dict(stream=STREAM_NAMES[mode], mode=mode, distinct_offsets=n_off, distinct_pairs=n_pair,
+               bytes_per_nnz=per_nnz, format_bytes_per_launch=nnz * per_nnz + (n + 1) * 4 + 2 * n * s,
+               row_blocks=nb, descriptor_only_blocks=nu, bytes_moved_per_launch=moved)
+    if tiles[0] > 0:        # same bytes: a tile reads x once per window instead of once per column, all of it on chip
+        out.update(kernel_id=3, lds_window_tiles=tiles[0], blocks_in_tiles=tiles[1], blocks_walked_singly=tiles[2])
+    return out
 
 
 def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8, dot_launches=0):
     """The roofline object of one measured SpMV kernel: fraction of the HBM peak on the bytes it READS AND WRITES.
     dot_launches: how many of the `launches` read a dot operand that is not their input vector (n*s bytes each)."""
     moved = sinfo["bytes_moved_per_launch"] + (n * s * dot_launches / launches if launches else 0.0)
-    r = dict(bound="hbm", kernel=KERNEL_NAMES[sinfo["mode"]], achieved=moved / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+    r = dict(bound="hbm", kernel=KERNEL_NAMES[sinfo.get("kernel_id", sinfo["mode"])], achieved=moved / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
              frac=moved / t_spmv / 1e9 / HBM_PEAK_GBS, traffic=None, stream=sinfo["stream"], bytes_per_nnz=sinfo["bytes_per_nnz"],
              algorithmic_bytes_per_launch=moved, bytes_moved_per_launch=moved,
              bytes_note=("mean over the %d timed launches of what a launch reads and writes: x, y, the stream (%d B/nnz), row_ptr%s of the "

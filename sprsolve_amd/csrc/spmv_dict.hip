@@ -1049,6 +1049,24 @@ __global__ __launch_bounds__(BLOCK) void tile_mark_kernel(int n_cand, const BlkD
     len_out[t] = ok ? L0 : 0;
 }
 
+// one thread per 128-row block: 1 = a full uniform block (plain or seam) of exactly the pattern (pat, L)
+__global__ __launch_bounds__(BLOCK) void tile_flag_kernel(int n_wide, const BlkDesc *__restrict__ desc, const uint8_t *__restrict__ code,
+                                                          unsigned long long pat, int L, uint8_t *__restrict__ flag) {
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= n_wide) return;
+    const BlkDesc d = desc[j];
+    const uint32_t rb = (uint32_t)d.rb;
+    bool ok = (rb & UNI2) != 0 && (d.nn & 0xff) == L;
+    if (ok) {
+        const bool seam = (rb & SEAM2) != 0;
+        ok = seam || (int)(rb & ~UNI2) - d.ra == 2 * WAVE;
+        unsigned long long p = 0;
+        for (int t = 0; t < L && t < 8; ++t) p |= (unsigned long long)code[d.pa + t] << (8 * t);
+        ok = ok && p == pat;
+    }
+    flag[j] = ok ? 1 : 0;
+}
+
 // UX: the dot operand of DOT == 2 is the input vector itself (K4 without a preconditioner): taken from the window
 template <int DOT, bool UX, int UL, int FL, int FH>
 __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(const int2 *__restrict__ tile_list, const int32_t *__restrict__ xstart,
@@ -1492,23 +1510,47 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const std::vector
                         for (int t = UL - FH; t < UL; ++t) far_band = std::max<int64_t>(far_band, std::llabs((long long)o[t]));
                     }
                     if (shape_ok) {
-                        std::vector<char> elig((size_t)n_cand, 0);
-                        int n_elig = 0;
-                        for (int t = 0; t < n_cand; ++t) {
-                            const int64_t ts = wd[(size_t)t * TILE_B].ra;
-                            if (h_len[(size_t)t] == UL && h_pat[(size_t)t] == canon.first && ts - TILE_W >= 0 && ts + TILE_ROWS + TILE_W <= A->ncols) { elig[(size_t)t] = 1; ++n_elig; }
+                        // tiles are placed greedily on the runs of consecutive blocks of that pattern (a run ends where a
+                        // boundary line or plane changes the pattern; aligned tiles would lose a whole tile per break)
+                        uint8_t *flag_d = nullptr;
+                        TILE_TRY(hipMalloc((void **)&flag_d, (size_t)nw));
+                        hipLaunchKernelGGL(tile_flag_kernel, dim3((nw + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, nw,
+                                           reinterpret_cast<const BlkDesc *>(D->wide_desc), (const uint8_t *)D->pair_code, canon.first, UL, flag_d);
+                        std::vector<uint8_t> flag((size_t)nw);
+                        hipError_t fe = hipGetLastError();
+                        if (fe == hipSuccess) fe = hipMemcpyAsync(flag.data(), flag_d, (size_t)nw, hipMemcpyDeviceToHost, c->stream);
+                        if (fe == hipSuccess) fe = hipStreamSynchronize(c->stream);
+                        (void)hipFree(flag_d);
+                        TILE_TRY(fe);
+                        std::vector<int32_t> starts;                            // first block of each tile, in row order
+                        std::vector<char> in_tile((size_t)nw, 0);
+                        for (int j = 0; j < nw;) {
+                            if (!flag[(size_t)j]) { ++j; continue; }
+                            int e = j + 1;
+                            while (e < nw && flag[(size_t)e] && wd[(size_t)e].ra == wd[(size_t)e - 1].ra + 2 * WAVE) ++e;
+                            int b = j;
+                            while (b < e && (int64_t)wd[(size_t)b].ra - TILE_W < 0) ++b;                 // the window starts inside x
+                            for (; b + TILE_B <= e; b += TILE_B) {
+                                if ((int64_t)wd[(size_t)b].ra + TILE_ROWS + TILE_W > A->ncols) break;     // ... and ends inside it
+                                starts.push_back(b);
+                                for (int q = 0; q < TILE_B; ++q) in_tile[(size_t)(b + q)] = 1;
+                            }
+                            j = e;
                         }
+                        const int n_elig = (int)starts.size();
                         // XCD sections: by the tile's phase within the far period (rows r and r +- far_band on one XCD, a near
                         // window apart in its walk), or plain eighths where no far slot exists / the band does not repeat
                         const bool periodic = far_band >= 8 * (int64_t)TILE_ROWS && far_band * 4 <= A->nrows && c->spmv_period != 0;
+                        // (equal COUNTS per XCD: a plane of 60 tiles cut by phase alone gives four XCDs 8 tiles a plane and four 7)
                         std::vector<std::vector<int32_t>> sec(8);
-                        int seen_e = 0;
-                        for (int t = 0; t < n_cand; ++t) {
-                            if (!elig[(size_t)t]) continue;
-                            const int64_t ts = wd[(size_t)t * TILE_B].ra;
-                            const int xs = periodic ? (int)(((ts % far_band) * 8) / far_band) : (int)(((int64_t)seen_e * 8) / std::max(n_elig, 1));
-                            sec[(size_t)std::min(std::max(xs, 0), 7)].push_back(t * TILE_B);     // (the row goes in below)
-                            ++seen_e;
+                        {
+                            std::vector<int32_t> by_phase((size_t)n_elig);
+                            for (int i = 0; i < n_elig; ++i) by_phase[(size_t)i] = i;
+                            if (periodic)
+                                std::stable_sort(by_phase.begin(), by_phase.end(), [&](int32_t a, int32_t b) {
+                                    return (int64_t)wd[(size_t)starts[(size_t)a]].ra % far_band < (int64_t)wd[(size_t)starts[(size_t)b]].ra % far_band; });
+                            for (int i = 0; i < n_elig; ++i) sec[(size_t)(((int64_t)i * 8) / std::max(n_elig, 1))].push_back(starts[(size_t)by_phase[(size_t)i]]);
+                            for (auto &v : sec) std::sort(v.begin(), v.end());      // each XCD walks its tiles in row order
                         }
                         std::vector<int32_t> list, xstart(9, 0), left;
                         for (int xq = 0; xq < 8; ++xq) {
@@ -1518,7 +1560,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const std::vector
                         xstart[8] = (int32_t)(list.size() / 2);
                         for (int pos = 0; pos < nw; ++pos) {
                             const int j = ord.empty() ? pos : ord[(size_t)pos];
-                            if (!(j / TILE_B < n_cand && elig[(size_t)(j / TILE_B)])) left.push_back(j);
+                            if (!in_tile[(size_t)j]) left.push_back(j);
                         }
                         if (n_elig >= 8) {
                             TILE_TRY(hipMalloc((void **)&D->tile_list, sizeof(int32_t) * list.size()));
