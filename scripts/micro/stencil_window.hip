@@ -118,7 +118,8 @@ __global__ __launch_bounds__(BLOCK) void k_win(long r_begin, long r_end, int nx,
     const long ntile = (r_end - r_begin) / T;
     double d0 = 0.0;
     struct Far { D2 m[NQ], p[NQ], uu[NQ]; };
-    D2 wreg[NW];
+    typedef unsigned u4w __attribute__((ext_vector_type(4)));
+    u4w wreg[NW];
     Far f;
     auto issue = [&](long t) {
         const long ts = r_begin + t * T;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(BLOCK) void k_win(long r_begin, long r_end, int nx,
         for (int i = 0; i < NW; ++i) {
             long g = ts - W + 2 * (long)(tid + i * BLOCK);
             g = g > n - 2 ? n - 2 : g;                                   // the last tile's window may pass the end of x
-            wreg[i] = ldg2(x + g);
+            wreg[i] = *reinterpret_cast<const u4w *>(x + g);
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(BLOCK) void k_win(long r_begin, long r_end, int nx,
         const long ts = r_begin + t * T;
         __syncthreads();                                                // the previous tile's LDS reads are done
 #pragma unroll
-        for (int i = 0; i < NW; ++i) *reinterpret_cast<D2 *>(&win[2 * (tid + i * BLOCK)]) = wreg[i];
+        for (int i = 0; i < NW; ++i) *reinterpret_cast<u4w *>(&win[2 * (tid + i * BLOCK)]) = wreg[i];
         __syncthreads();
         Far g = f;
         if (PRE && s + sstep < send) issue(order ? order[s + sstep] : s + sstep);         // next tile's loads fly over this tile's products
@@ -163,6 +164,91 @@ __global__ __launch_bounds__(BLOCK) void k_win(long r_begin, long r_end, int nx,
             stnt2(y + ts + ((q * 4 + wv) << 7) + 2 * lane, o);
             if (DOT == 1) { d0 = d0 + o.lo * g.uu[q].lo; d0 = d0 + o.hi * g.uu[q].hi; }
             if (DOT == 2) { d0 = d0 + o.lo * cc.lo; d0 = d0 + o.hi * cc.hi; }
+        }
+    }
+    if (DOT) {
+        for (int o = 32; o > 0; o >>= 1) d0 += __shfl_xor(d0, o, 64);
+        if (lane == 0) part[blockIdx.x * 4 + wv] = d0;
+    }
+}
+
+// ---- winv: the same with a value PER ENTRY (variable coefficients: 7 doubles per row streamed from val[], row-major):
+// a wavefront loads the 896 values of its 128-row block with seven 16-byte loads, passes them through its LDS slice
+// (stream order in, row order out) one block ahead of the fold
+__global__ void fill_vals(long n, double *v) {
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < n; g += (long)gridDim.x * blockDim.x) v[g] = hval(g * 5 + 11);
+}
+__global__ void refv_kernel(long r0, long r1, int nx, long P, const double *val, const double *x, double *y) {
+    for (long r = r0 + blockIdx.x * (long)blockDim.x + threadIdx.x; r < r1; r += (long)gridDim.x * blockDim.x) {
+        const double *v = val + (r - r0) * 7;
+        double acc = 0.0;
+        acc = acc + x[r - P] * v[0]; acc = acc + x[r - nx] * v[1]; acc = acc + x[r - 1] * v[2]; acc = acc + x[r] * v[3];
+        acc = acc + x[r + 1] * v[4]; acc = acc + x[r + nx] * v[5]; acc = acc + x[r + P] * v[6];
+        y[r] = acc;
+    }
+}
+// gather version of the product's offset-code kernel shape: lane = row of a 64-row block, 7 8-byte gathers, values via LDS
+template <int T, int W, int DOT>
+__global__ __launch_bounds__(BLOCK) void k_winv(long r_begin, long r_end, int nx, long P, long n, const double *__restrict__ val, const double *__restrict__ x,
+                                                double *__restrict__ y, const double *__restrict__ u, double *__restrict__ part,
+                                                const int *__restrict__ order, const int *__restrict__ xstart) {
+    constexpr int NW = (T + 2 * W) / 2 / BLOCK, NQ = T / 512;
+    typedef unsigned u4w __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) double win[T + 2 * W];
+    __shared__ __attribute__((aligned(16))) double vs[4][896 + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double d0 = 0.0;
+    long s = order ? xstart[blockIdx.x & 7] + (blockIdx.x >> 3) : blockIdx.x;
+    const long ntile = (r_end - r_begin) / T;
+    const long send = order ? xstart[(blockIdx.x & 7) + 1] : ntile, sstep = order ? gridDim.x >> 3 : gridDim.x;
+    for (; s < send; s += sstep) {
+        const long t = order ? order[s] : s;
+        const long ts = r_begin + t * T;
+        u4w wreg[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) wreg[i] = *reinterpret_cast<const u4w *>(x + ts - W + 2 * (long)(tid + i * BLOCK));
+        D2 fm[NQ], fp[NQ], uu[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const long r0 = ts + ((q * 4 + wv) << 7) + 2 * lane;
+            fm[q] = ldg2(x + r0 - P); fp[q] = ldg2(x + r0 + P);
+            if (DOT == 1) uu[q] = ldg2(u + r0);
+        }
+        u4w vreg[7];
+        auto load_vals = [&](int q) {
+            const double *vb = val + (ts - r_begin + ((q * 4 + wv) << 7)) * 7;            // 896 doubles, 16-byte aligned (block starts are even)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) vreg[i] = *reinterpret_cast<const u4w *>(vb + 2 * (lane + i * 64));
+        };
+        load_vals(0);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) *reinterpret_cast<u4w *>(&win[2 * (tid + i * BLOCK)]) = wreg[i];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) *reinterpret_cast<u4w *>(&vs[wv][2 * (lane + i * 64)]) = vreg[i];
+            if (q + 1 < NQ) load_vals(q + 1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int li = W + ((q * 4 + wv) << 7) + 2 * lane;
+            const double *v0 = &vs[wv][14 * lane], *v1 = v0 + 7;
+            const D2 cc = *reinterpret_cast<const D2 *>(&win[li]);
+            const D2 a = *reinterpret_cast<const D2 *>(&win[li - nx]);
+            const D2 b = *reinterpret_cast<const D2 *>(&win[li + nx]);
+            const double xl = win[li - 1], xr = win[li + 2];
+            D2 o;
+            double acc = 0.0;
+            acc = acc + fm[q].lo * v0[0]; acc = acc + a.lo * v0[1]; acc = acc + xl * v0[2]; acc = acc + cc.lo * v0[3];
+            acc = acc + cc.hi * v0[4]; acc = acc + b.lo * v0[5]; acc = acc + fp[q].lo * v0[6];
+            o.lo = acc; acc = 0.0;
+            acc = acc + fm[q].hi * v1[0]; acc = acc + a.hi * v1[1]; acc = acc + cc.lo * v1[2]; acc = acc + cc.hi * v1[3];
+            acc = acc + xr * v1[4]; acc = acc + b.hi * v1[5]; acc = acc + fp[q].hi * v1[6];
+            o.hi = acc;
+            stnt2(y + ts + ((q * 4 + wv) << 7) + 2 * lane, o);
+            if (DOT == 1) { d0 = d0 + o.lo * uu[q].lo; d0 = d0 + o.hi * uu[q].hi; }
+            if (DOT == 2) { d0 = d0 + o.lo * cc.lo; d0 = d0 + o.hi * cc.hi; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
     if (DOT) {
@@ -212,6 +298,8 @@ int main(int argc, char **argv) {
         fflush(stdout);
     };
     (void)run;
+    double *val = nullptr, *yrv = nullptr;
+    const bool want_v = filt.empty() || filt.find("winv") != std::string::npos;
     auto make_order = [&](int T, int **d_order, int **d_xstart) {
         const long ntile = (r_end - r_begin) / T;
         std::vector<int> ord; std::vector<int> xs(9, 0);
@@ -239,6 +327,27 @@ int main(int argc, char **argv) {
         run("win" #T "w" #W SFX "-period/dot2" + g, 2, [&] { k_win<T, W, 2, PRE><<<grid, BLOCK>>>(r_begin, r_end, nx, P, n, c, x, y, u, part, o##T, x##T); });
         WIN(1024, 512, 0, "") WIN(2048, 512, 0, "") WIN(4096, 512, 0, "")
         WIN(1024, 512, 1, "pre") WIN(2048, 512, 1, "pre")
+    }
+    if (want_v) {
+        const long nv = (r_end - r_begin) * 7;
+        CK(hipMalloc(&val, nv * 8)); CK(hipMalloc(&yrv, n * 8)); CK(hipMemset(yrv, 0, n * 8));
+        fill_vals<<<4096, 256>>>(nv, val);
+        refv_kernel<<<4096, 256>>>(r_begin, r_end, nx, P, val, x, yrv);
+        CK(hipDeviceSynchronize());
+        std::swap(yr, yrv);                                  // run() compares with yr
+        const double vbytes = rows * 56;
+        printf("variable coefficients: + %.3f GB of values per launch\n", vbytes / 1e9);
+        for (int grid : {512, 768, 1024}) {
+            const std::string g = "/" + std::to_string(grid);
+            for (int per = 0; per < 2; ++per) {
+                int *o = per ? o4096 : nullptr, *xs = per ? x4096 : nullptr;
+                const std::string w = per ? "winv4096w512-period" : "winv4096w512";
+                run(w + "/dot0" + g, 0, [&] { k_winv<4096, 512, 0><<<grid, BLOCK>>>(r_begin, r_end, nx, P, n, val, x, y, u, part, o, xs); });
+                run(w + "/dot1" + g, 1, [&] { k_winv<4096, 512, 1><<<grid, BLOCK>>>(r_begin, r_end, nx, P, n, val, x, y, u, part, o, xs); });
+                run(w + "/dot2" + g, 2, [&] { k_winv<4096, 512, 2><<<grid, BLOCK>>>(r_begin, r_end, nx, P, n, val, x, y, u, part, o, xs); });
+            }
+        }
+        std::swap(yr, yrv);
     }
     return 0;
 }
