@@ -585,8 +585,13 @@ int sprs_csr_tile_plan(const sprs_csr *A, int64_t *n_tiles, int64_t *n_tile_bloc
     if (!A || !n_tiles || !n_tile_blocks || !n_other_blocks) return SPRS_INVALID_ARGUMENT;
     *n_tiles = 0; *n_tile_blocks = 0; *n_other_blocks = 0;
     const sprs_dict *D = A->dict;
-    if (!D || dict_mode(A) != 2 || D->n_tile <= 0 || A->ctx->spmv_tile == 0 || A->ctx->spmv_wide == 0) return SPRS_OK;
-    *n_tiles = D->n_tile; *n_tile_blocks = (int64_t)D->n_tile * sprs::tile_blocks(); *n_other_blocks = D->n_tile_left;
+    if (!D || A->ctx->spmv_tile == 0 || A->ctx->spmv_wide == 0) return SPRS_OK;
+    const int dm = dict_mode(A);
+    if (dm != 1 && dm != 2) return SPRS_OK;
+    const sprs_tile_plan &TP = dm == 2 ? D->tile_pair : D->tile_off;
+    if (TP.n_tile <= 0 || !sprs::tile_plan_used(A)) return SPRS_OK;
+    // the other blocks in 128-row units (the offset stream walks them as 64-row blocks)
+    *n_tiles = TP.n_tile; *n_tile_blocks = (int64_t)TP.n_tile * sprs::tile_blocks(); *n_other_blocks = dm == 2 ? TP.n_left : (TP.n_left + 1) / 2;
     return SPRS_OK;
 }
 int sprs_csr_stream_format(const sprs_csr *A, int *n_offsets, int *n_values) {

@@ -154,6 +154,18 @@ struct sprs_dist_info {
 // Dictionary-compressed copy of the (col_idx, val) stream (spmv_dict.hip): one byte per nnz indexing the
 // table of distinct (col - row) offsets or, for real matrices with few distinct values, the table of distinct
 // (offset, value) pairs.  Built at handle creation when the matrix qualifies.
+// Runs of TILE_B consecutive full uniform 128-row blocks that share one pattern whose NEAR columns (|col - row| <= TILE_W - 2)
+// are taken from an LDS window of x (spmv_dict.hip); the blocks outside those runs stay with the per-block walk (same launch)
+struct sprs_tile_plan {
+    int32_t *list = nullptr;       // device: {first 128-row block, first row} of each tile, eight per-XCD sections in row order
+    int32_t *xstart = nullptr;     // device, 9 entries: section bounds within list
+    int32_t *left = nullptr;       // device: the other blocks, in the walk order they had (128-row blocks: pair stream; 64-row blocks: offset stream)
+    int n_tile = 0, n_left = 0;
+    int ul = 0, fl = 0, fh = 0;    // pattern shape: slots, leading far slots, trailing far slots
+    int32_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double val[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // pair stream: the pattern's values
+};
+
 struct sprs_dict {
     uint8_t *idx_code = nullptr;   // device, nnz (+ pad): code of col - row
     uint8_t *pair_code = nullptr;  // device, nnz (+ pad): code of the (col - row, value) pair, or null
@@ -167,16 +179,11 @@ struct sprs_dict {
     int32_t *off_order = nullptr;  // device: the same schedule for the 64-row blocks of the offset-code stream
     int64_t period = 0;            // the far band it folds over (rows)
     int64_t max_off = -1;          // largest |col - row| of the matrix (-1: unknown)
-    // tile plan of spmv_tile_kernel (f64 pair codes, HBM-sized stencil-like matrices): runs of TILE_B consecutive full
-    // uniform 128-row blocks that share one pattern whose NEAR columns (|col - row| <= TILE_W - 2) are taken from an LDS
-    // window of x; the 128-row blocks outside those runs stay with the per-block walk (tile_left, same launch)
-    int32_t *tile_list = nullptr;  // device: {first 128-row block, first row} of each tile, eight per-XCD sections in row order
-    int32_t *tile_xstart = nullptr;// device, 9 entries: section bounds within tile_list
-    int32_t *tile_left = nullptr;  // device: the other 128-row blocks, in the walk order they had
-    int n_tile = 0, n_tile_left = 0;
-    int tile_ul = 0, tile_fl = 0, tile_fh = 0;   // pattern shape: slots, leading far slots, trailing far slots
-    int32_t tile_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double tile_val[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // tile plans of spmv_tile_kernel (f64, HBM-sized stencil-like matrices): one for the pair-code stream, one for the
+    // offset-code stream (values per entry) when that is the stream the handle multiplies with
+    sprs_tile_plan tile_pair, tile_off;
+    void *owide_desc = nullptr;    // device: 128-row descriptors of the offset-code stream (uniform / seam blocks marked on its codes)
+    int n_owide = 0;
     void *off_desc = nullptr;      // device: copy of blk_desc for the offset-code stream with the uniform blocks flagged (bit 30, nn = row length)
     int n_off_uniform = 0;
 };
@@ -222,6 +229,7 @@ template <class T>
 int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T *part0, T *part1, const int *status,
                 bool conj_x = false, const Fin *fin = nullptr);
 int tile_blocks();   // 128-row blocks per LDS-window tile (spmv_dict.hip)
+bool tile_plan_used(const sprs_csr *A);   // the SpMV of this handle runs through its tile plan
 int build_rowblocks(sprs_csr *A, const int32_t *host_row_ptr);   // host_row_ptr == null: row_ptr lives in HBM only (summaries first)
 int validate_cols_device(const sprs_csr *A);   // SPRS_INVALID_ARGUMENT if any col_idx is outside [0, ncols)
 int spmv_num_partials(const sprs_csr *A);  // workgroups launch_spmv uses == partials it writes

@@ -261,45 +261,25 @@ struct BlkLoads {
 // 2l, 2l + 1 of [pa - (pa & 1), ..) per load: 4 loads per 512 entries instead of 8) and staged to LDS with 16-byte stores;
 // the last 2-entry group of val, which may reach one entry past the array, comes from the handle's zero-padded tail copy.
 struct alignas(16) V2d { double a, b; };
-template <class T, int DOT, bool CONJX, bool PAIR, bool WV = false>
-__global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_chunk, const BlkDesc *__restrict__ desc,
-                                                          const int32_t *__restrict__ order,
-                                                          const int32_t *__restrict__ row_ptr,
-                                                          const uint8_t *__restrict__ code,       // offset or pair codes
-                                                          const int32_t *__restrict__ off_tab,    // per code: col - row
-                                                          const T *__restrict__ val_tab,          // per pair code: value
-                                                          const T *__restrict__ val, const T *__restrict__ x,
-                                                          T *__restrict__ y, const T *__restrict__ u, T *__restrict__ part0,
-                                                          T *__restrict__ part1, const int *__restrict__ status, const Fin fin,
-                                                          const V2d *__restrict__ tail2, int g2_last) {
-    static_assert(!WV || (sizeof(T) == 8 && !PAIR), "wide value loads: f64 offset-code stream");
+// The walk of the 64-row-block kernels of the compressed streams over `n_rowblk` blocks (positions of `order`, or natural
+// order), shared by spmv_dict_kernel (the whole matrix) and spmv_tile_kernel's offset-code flavour (the blocks outside its
+// tiles).  s_pair / s_off8: the staged tables; s_c: NWAVE zeroed code slices of CW dwords; s_v: NWAVE zeroed value slices of
+// s_v_stride (>= CAP + 16) entries, 16-byte aligned (offset-code stream).  d0 / d1: the lane's running dot partials.
+template <class T, int DOT, bool CONJX, bool PAIR, bool WV>
+__device__ __forceinline__ void dict_walk(int n_rowblk, int xcd_chunk, const BlkDesc *__restrict__ desc, const int32_t *__restrict__ order,
+                                          const int32_t *__restrict__ row_ptr, const uint8_t *__restrict__ code,
+                                          const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y, const T *__restrict__ u,
+                                          const V2d *__restrict__ tail2, int g2_last,
+                                          const PairEnt<T> *s_pair, const int32_t *s_off8, uint32_t (*s_c)[(nnz_cap<T>::value + 3 + CPAD + 3) / 4],
+                                          T *s_v, int s_v_stride, T &d0, T &d1) {
     constexpr int CAP = nnz_cap<T>::value;          // nnz per row block (per wavefront)
-    constexpr int CW = (CAP + 3 + CPAD + 3) / 4;    // dwords: CAP code bytes at any 4-byte phase + the readable pad
     constexpr int ITEMS = CAP / WAVE;
     using Loads = BlkLoads<T, PAIR, ITEMS>;
-    __shared__ PairEnt<T> s_pair[PAIR ? TAB : 1];
-    __shared__ int32_t s_off8[PAIR ? 1 : TAB];
-    __shared__ uint32_t s_c[NWAVE][CW];
-    __shared__ __attribute__((aligned(16))) T s_v[PAIR ? 1 : NWAVE][PAIR ? 1 : CAP + 16];
-    __shared__ T red[NWAVE];
-    // the solve's status word is requested first and looked at after the table loads: one memory round trip, not two
-    // (a kernel of a finished solve must not store anything; it may load)
-    const int run_state = status != nullptr ? *status : (int)ST_RUNNING;
-
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    // the wavefront index as a SCALAR: the block walk (b, loop branches) then lives in SGPRs
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if constexpr (PAIR) s_pair[tid] = PairEnt<T>{off_tab[tid] * (int32_t)sizeof(T), val_tab[tid]};    // BLOCK == TAB
-    else s_off8[tid] = off_tab[tid] * (int32_t)sizeof(T);
-    for (int i = lane; i < CW; i += WAVE) s_c[wv][i] = 0;       // the pad is read (and ignored) before it is ever written
-    if constexpr (!PAIR) for (int i = lane; i < CAP + 16; i += WAVE) s_v[wv][i] = szero<T>();
-    __syncthreads();                                // the only workgroup barrier: tables are read-only afterwards
-    if (run_state != ST_RUNNING) return;
-
     const uint8_t *cb = reinterpret_cast<const uint8_t *>(s_c[wv]);
-    [[maybe_unused]] T *vs = s_v[PAIR ? 0 : wv];
+    [[maybe_unused]] T *vs = s_v + (PAIR ? 0 : wv) * (size_t)s_v_stride;
     const char *xbytes = reinterpret_cast<const char *>(x);
-    T d0 = szero<T>(), d1 = szero<T>();
 
     int b, bstep, bend;                             // the persistent walk of spmv.hip
     if (xcd_chunk) {
@@ -488,6 +468,44 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
         if (more) { stage(nxt); adopt(nxt); }
         dn = uniform(dn2); o2 = __builtin_amdgcn_readfirstlane(o3);
     }
+}
+
+template <class T, int DOT, bool CONJX, bool PAIR, bool WV = false>
+__global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_chunk, const BlkDesc *__restrict__ desc,
+                                                          const int32_t *__restrict__ order,
+                                                          const int32_t *__restrict__ row_ptr,
+                                                          const uint8_t *__restrict__ code,       // offset or pair codes
+                                                          const int32_t *__restrict__ off_tab,    // per code: col - row
+                                                          const T *__restrict__ val_tab,          // per pair code: value
+                                                          const T *__restrict__ val, const T *__restrict__ x,
+                                                          T *__restrict__ y, const T *__restrict__ u, T *__restrict__ part0,
+                                                          T *__restrict__ part1, const int *__restrict__ status, const Fin fin,
+                                                          const V2d *__restrict__ tail2, int g2_last) {
+    static_assert(!WV || (sizeof(T) == 8 && !PAIR), "wide value loads: f64 offset-code stream");
+    constexpr int CAP = nnz_cap<T>::value;          // nnz per row block (per wavefront)
+    constexpr int CW = (CAP + 3 + CPAD + 3) / 4;    // dwords: CAP code bytes at any 4-byte phase + the readable pad
+    __shared__ PairEnt<T> s_pair[PAIR ? TAB : 1];
+    __shared__ int32_t s_off8[PAIR ? 1 : TAB];
+    __shared__ uint32_t s_c[NWAVE][CW];
+    __shared__ __attribute__((aligned(16))) T s_v[PAIR ? 1 : NWAVE][PAIR ? 1 : CAP + 16];
+    __shared__ T red[NWAVE];
+    // the solve's status word is requested first and looked at after the table loads: one memory round trip, not two
+    // (a kernel of a finished solve must not store anything; it may load)
+    const int run_state = status != nullptr ? *status : (int)ST_RUNNING;
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    // the wavefront index as a SCALAR: the block walk (b, loop branches) then lives in SGPRs
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (PAIR) s_pair[tid] = PairEnt<T>{off_tab[tid] * (int32_t)sizeof(T), val_tab[tid]};    // BLOCK == TAB
+    else s_off8[tid] = off_tab[tid] * (int32_t)sizeof(T);
+    for (int i = lane; i < CW; i += WAVE) s_c[wv][i] = 0;       // the pad is read (and ignored) before it is ever written
+    if constexpr (!PAIR) for (int i = lane; i < CAP + 16; i += WAVE) s_v[wv][i] = szero<T>();
+    __syncthreads();                                // the only workgroup barrier: tables are read-only afterwards
+    if (run_state != ST_RUNNING) return;
+
+    T d0 = szero<T>(), d1 = szero<T>();
+    dict_walk<T, DOT, CONJX, PAIR, WV>(n_rowblk, xcd_chunk, desc, order, row_ptr, code, val, x, y, u, tail2, g2_last, s_pair, s_off8, s_c,
+                                       &s_v[0][0], PAIR ? 0 : CAP + 16, d0, d1);
     if (DOT >= 1) {
         d0 = block_sum(d0, red);
         if (tid == 0) st_partial(fin, part0 + blockIdx.x, d0);
@@ -1231,6 +1249,182 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(const int2 *__restrict
     if (DOT >= 1 && fin.counter) finalize_last_block<T, T>(fin, DOT == 2, red, red);
 }
 
+// The same tiles for the OFFSET-CODE stream (a value per entry: any stencil or band with variable coefficients).  The 128-row
+// descriptors are the offset stream's own (owide_desc: uniform and seam blocks marked on the offset codes).  A full block's
+// 128 UL values are consecutive in val[]: the wavefront loads them with 16-byte loads (stream order), passes them through its
+// LDS slice one block ahead of the fold and reads them back by row — lane l's rows 2l, 2l + 1 sit at entries (2l) UL and
+// (2l + 1) UL behind the block's first one; in a seam block the rows behind the short ones move up by what those lack, and a
+// short row steps through its values only on the slots it has.  x as in spmv_tile_kernel.  The 64-row blocks outside the tiles
+// go through dict_walk in the same launch.
+template <int DOT, bool UX, int UL, int FL, int FH>
+__global__ __launch_bounds__(BLOCK) void spmv_tile_off_kernel(const int2 *__restrict__ tile_list, const int32_t *__restrict__ xstart,
+                                                              const BlkDesc *__restrict__ desc, const TilePat pat,
+                                                              int n_left, const int32_t *__restrict__ left_order, const BlkDesc *__restrict__ desc64,
+                                                              const int32_t *__restrict__ row_ptr, const uint8_t *__restrict__ code,
+                                                              const int32_t *__restrict__ off_tab, const double *__restrict__ val,
+                                                              const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ u,
+                                                              double *__restrict__ part0, double *__restrict__ part1,
+                                                              const int *__restrict__ status, const Fin fin, const V2d *__restrict__ tail2, int g2_last) {
+    using T = double;
+    constexpr int TR = TILE_ROWS, W = TILE_W;
+    constexpr int NW = (TR + 2 * W) / 2 / BLOCK;        // 16-byte window pieces per lane
+    constexpr int NQ = TILE_B / NWAVE;                  // 128-row blocks per wavefront and tile
+    constexpr int NN = UL - FL - FH;                    // near slots
+    constexpr int VROW = 2 * WAVE * UL;                 // values of a full block
+    constexpr int NV = (VROW / 2 + 1 + WAVE - 1) / WAVE;   // 16-byte value loads per lane and block (a block may start on an odd entry)
+    constexpr int CAPD = nnz_cap<T>::value;
+    constexpr int CWD = (CAPD + 3 + CPAD + 3) / 4;
+    constexpr int VS = (VROW + 2 + 15) / 16 * 16 > CAPD + 16 ? (VROW + 2 + 15) / 16 * 16 : CAPD + 16;    // slice stride: the tile phase's block, or dict_walk's
+    static_assert((TR + 2 * W) % (2 * BLOCK) == 0 && TILE_B % NWAVE == 0 && NN >= 1 && UL <= 8, "tile shape");
+    __shared__ __attribute__((aligned(16))) T win[TR + 2 * W];
+    __shared__ __attribute__((aligned(16))) T vsl[NWAVE][VS];
+    __shared__ int32_t s_off8[TAB];
+    __shared__ uint32_t s_c[NWAVE][CWD];
+    __shared__ T red[NWAVE];
+    const int run_state = status != nullptr ? *status : (int)ST_RUNNING;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    s_off8[tid] = off_tab[tid] * (int32_t)sizeof(T);                            // BLOCK == TAB
+    for (int i = lane; i < CWD; i += WAVE) s_c[wv][i] = 0;
+    for (int i = lane; i < VS; i += WAVE) vsl[wv][i] = 0.0;
+    __syncthreads();
+    if (run_state != ST_RUNNING) return;
+    T d0 = 0.0, d1 = 0.0;
+
+    const int xcd = blockIdx.x & 7;
+    const int sstep = gridDim.x >> 3;
+    const int send = xstart[xcd + 1];
+    int s = xstart[xcd] + (blockIdx.x >> 3);
+    // tile entries {first 128-row block, first row} and per block its seam words and its first entry: scalar loads a tile ahead
+    int2 ent = s < send ? tile_list[s] : int2{0, 0};
+    int2 ent1 = s + sstep < send ? tile_list[s + sstep] : int2{0, 0};
+    uint32_t rbw[NQ]; int nnw[NQ], vbw[NQ];
+    auto load_words = [&](int b0, int ts) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const BlkDesc d = desc[b0 + q * NWAVE + wv];
+            rbw[q] = (uint32_t)d.rb; nnw[q] = d.nn; vbw[q] = row_ptr[ts + ((q * NWAVE + wv) << 7)];
+        }
+    };
+    load_words(__builtin_amdgcn_readfirstlane(ent.x), __builtin_amdgcn_readfirstlane(ent.y));
+    T *vs = vsl[wv];
+    for (; s < send; s += sstep) {
+        const int ts = __builtin_amdgcn_readfirstlane(ent.y);
+        ent = ent1;
+        if (s + 2 * sstep < send) ent1 = tile_list[s + 2 * sstep];
+        uint32_t rbc[NQ]; int nnc[NQ], vbc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { rbc[q] = rbw[q]; nnc[q] = nnw[q]; vbc[q] = __builtin_amdgcn_readfirstlane(vbw[q]); }
+        // ---- loads: the window, the far pairs (and dot operands) of the lane's NQ row pairs, the first block's values
+        u4v wreg[NW];
+        const T *wbase = x + (ts - W);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) wreg[i] = *reinterpret_cast<const u4v *>(wbase + 2 * (tid + i * BLOCK));
+        D2 far[NQ][FL + FH > 0 ? FL + FH : 1];
+        D2 uu[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const T *xr = x + (ts + ((q * NWAVE + wv) << 7) + 2 * lane);
+#pragma unroll
+            for (int k = 0; k < FL; ++k) far[q][k] = *reinterpret_cast<const D2 *>(xr + pat.off[k]);
+#pragma unroll
+            for (int k = 0; k < FH; ++k) far[q][FL + k] = *reinterpret_cast<const D2 *>(xr + pat.off[UL - FH + k]);
+            if (DOT == 1 || (DOT == 2 && !UX)) uu[q] = *reinterpret_cast<const D2 *>(u + (ts + ((q * NWAVE + wv) << 7) + 2 * lane));
+        }
+        u4v vreg[NV];
+        auto load_vals = [&](int vb) {                  // chunks [vb >> 1, (vb >> 1) + VROW / 2]: the block's values from its 16-byte boundary
+            const u4v *v2 = reinterpret_cast<const u4v *>(val) + (vb >> 1);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) vreg[i] = v2[min(lane + i * WAVE, VROW / 2)];
+        };
+        load_vals(vbc[0]);
+        if (s + sstep < send) load_words(__builtin_amdgcn_readfirstlane(ent.x), __builtin_amdgcn_readfirstlane(ent.y));
+        __syncthreads();                                                        // the previous tile's window has been read
+#pragma unroll
+        for (int i = 0; i < NW; ++i) *reinterpret_cast<u4v *>(&win[2 * (tid + i * BLOCK)]) = wreg[i];
+        __syncthreads();
+        T npl[NN], nph[NN];
+        auto read_near = [&](int q) {
+            const int li = W + ((q * NWAVE + wv) << 7) + 2 * lane;
+#pragma unroll
+            for (int t = 0; t < NN; ++t) { npl[t] = win[li + pat.off[FL + t]]; nph[t] = win[li + pat.off[FL + t] + 1]; }
+        };
+        read_near(0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            // this block's values: registers -> the wavefront's slice (stream order), then the next block's loads go out
+#pragma unroll
+            for (int i = 0; i < NV; ++i) *reinterpret_cast<u4v *>(&vs[2 * min(lane + i * WAVE, VROW / 2)]) = vreg[i];
+            if (q + 1 < NQ) load_vals(vbc[q + 1 < NQ ? q + 1 : q]);
+            wave_lds_fence();
+            const uint32_t rbq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rbc[q]);
+            const bool seam = (rbq & SEAM2) != 0;
+            const int shift = vbc[q] & 1;
+            const int li = W + ((q * NWAVE + wv) << 7) + 2 * lane;              // window index of x[r0]
+            T pl[UL], ph[UL];
+#pragma unroll
+            for (int t = 0; t < UL; ++t) {
+                if (t < FL) { pl[t] = far[q][t].lo; ph[t] = far[q][t].hi; }
+                else if (t >= UL - FH) { pl[t] = far[q][t - (UL - FH) + FL].lo; ph[t] = far[q][t - (UL - FH) + FL].hi; }
+                else { pl[t] = npl[t - FL]; ph[t] = nph[t - FL]; }
+            }
+            T ux0 = 0.0, ux1 = 0.0;
+            if (DOT == 2 && UX) { ux0 = win[li]; ux1 = win[li + 1]; }
+            if (q + 1 < NQ) read_near(q + 1);
+            T acc0 = 0.0, acc1 = 0.0;
+            if (!seam) {
+                const T *v0 = vs + shift + 2 * lane * UL;
+#pragma unroll
+                for (int t = 0; t < UL; ++t) {
+                    acc0 = acc0 + pl[t] * v0[t];
+                    acc1 = acc1 + ph[t] * v0[UL + t];
+                }
+            } else {
+                // rows k, k + 1 (local) hold only the slots of their masks: their values are fewer, and the rows behind them
+                // start that much earlier in the slice
+                const int seam1 = __builtin_amdgcn_readfirstlane(nnc[q]) >> 16, seam2 = (int)(rbq & 0x3ffffffu);
+                const int k = seam1 & 127, full = (1 << UL) - 1, maskA = (seam1 >> 7) & full, maskB = seam2 & full;
+                const int cA = UL - __builtin_popcount(maskA), cB = UL - __builtin_popcount(maskB);
+                const int i0 = 2 * lane, i1 = i0 + 1;
+                int p0 = shift + i0 * UL - (i0 > k ? cA : 0) - (i0 > k + 1 ? cB : 0);
+                int p1 = shift + i1 * UL - (i1 > k ? cA : 0) - (i1 > k + 1 ? cB : 0);
+                const int pm0 = i0 == k ? maskA : (i0 == k + 1 ? maskB : full), pm1 = i1 == k ? maskA : (i1 == k + 1 ? maskB : full);
+#pragma unroll
+                for (int t = 0; t < UL; ++t) {
+                    const T n0 = acc0 + pl[t] * vs[p0], n1 = acc1 + ph[t] * vs[p1];
+                    const bool h0 = ((pm0 >> t) & 1) != 0, h1 = ((pm1 >> t) & 1) != 0;
+                    acc0 = h0 ? n0 : acc0; p0 += h0 ? 1 : 0;
+                    acc1 = h1 ? n1 : acc1; p1 += h1 ? 1 : 0;
+                }
+            }
+            const D2 yy{acc0, acc1};
+            u4v qv;
+            __builtin_memcpy(&qv, &yy, 16);
+            __builtin_nontemporal_store(qv, reinterpret_cast<u4v *>(y + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
+            if (DOT == 1) { d0 = d0 + uu[q].lo * acc0; d0 = d0 + uu[q].hi * acc1; }
+            if (DOT == 2) {
+                const T u0 = UX ? ux0 : uu[q].lo, u1 = UX ? ux1 : uu[q].hi;
+                d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * u0; d0 = d0 + acc1 * acc1; d1 = d1 + acc1 * u1;
+            }
+            wave_lds_fence();                                                   // the slice is free for the next block's values
+        }
+    }
+    if (n_left > 0) {
+        __syncthreads();
+        dict_walk<T, DOT, false, false, true>(n_left, 0, desc64, left_order, row_ptr, code, val, x, y, u, tail2, g2_last,
+                                             (const PairEnt<T> *)nullptr, s_off8, s_c, &vsl[0][0], VS, d0, d1);
+    }
+    if (DOT >= 1) {
+        d0 = block_sum(d0, red);
+        if (tid == 0) st_partial(fin, part0 + blockIdx.x, d0);
+    }
+    if (DOT == 2) {
+        d1 = block_sum(d1, red);
+        if (tid == 0) st_partial(fin, part1 + blockIdx.x, d1);
+    }
+    if (DOT >= 1 && fin.counter) finalize_last_block<T, T>(fin, DOT == 2, red, red);
+}
+
 // XCD-period schedule (knob "spmv_period") of a stream's row blocks.  With the far band P = max |col - row| (a 3-D
 // stencil's plane), rows are cut into chunks of P/8 and chunk c goes to XCD c mod 8: rows r and r +- P are multiplied on
 // the SAME XCD one chunk apart, so x[r + P] is fetched over the fabric once — when row r needs it — and hits that
@@ -1273,6 +1467,118 @@ struct BlkDescHost2 { int32_t ra, rb, pa, nn; };
 template <class T> struct has_val_dict { static constexpr bool value = false; };
 template <> struct has_val_dict<double> { static constexpr bool value = true; };
 template <> struct has_val_dict<float> { static constexpr bool value = true; };
+
+// Tile plan of a stream's 128-row descriptors `desc_dev` (marked by mark_uniform_kernel on the codes `code_dev`; host copy of
+// the unmarked descriptors: wd).  off_tab / val_tab: host tables per code (val_tab null: a stream whose values are per entry).
+// make_left(in_tile, left) lists the blocks the tiles do not cover, in the walk order of the stream's per-block kernel.
+template <class MakeLeft>
+static int build_tile_plan(sprs_csr *A, sprs_tile_plan &TP, const BlkDesc *desc_dev, const uint8_t *code_dev, const std::vector<BlkDescHost2> &wd,
+                           const int32_t *off_tab, const double *val_tab, MakeLeft &&make_left) {
+    sprs_ctx *c = A->ctx;
+    const int nw = (int)wd.size();
+    const int n_cand = nw / TILE_B;
+    const bool tile_wanted = c->spmv_tile > 0 || (c->spmv_tile < 0 && stream_loads_nt(c, (size_t)A->nrows * sizeof(double)));
+    if (!(tile_wanted && c->spmv_uniform != 0 && c->spmv_wide != 0 && n_cand >= 16 && A->ncols >= TILE_ROWS + 2 * TILE_W)) return SPRS_OK;
+    unsigned long long *pat_d = nullptr; int *len_d = nullptr; uint8_t *flag_d = nullptr;
+    auto drop = [&]() { for (void *q : {(void *)pat_d, (void *)len_d, (void *)flag_d}) if (q) (void)hipFree(q); pat_d = nullptr; len_d = nullptr; flag_d = nullptr; };
+#define TILE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { snprintf(c->err, sizeof(c->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); drop(); return SPRS_ERR_HIP; } } while (0)
+    TILE_TRY(hipMalloc((void **)&pat_d, sizeof(unsigned long long) * (size_t)n_cand));
+    TILE_TRY(hipMalloc((void **)&len_d, sizeof(int) * (size_t)n_cand));
+    hipLaunchKernelGGL(tile_mark_kernel, dim3((n_cand + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n_cand, desc_dev, code_dev, pat_d, len_d);
+    TILE_TRY(hipGetLastError());
+    std::vector<unsigned long long> h_pat((size_t)n_cand);
+    std::vector<int> h_len((size_t)n_cand);
+    TILE_TRY(hipMemcpyAsync(h_pat.data(), pat_d, sizeof(unsigned long long) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
+    TILE_TRY(hipMemcpyAsync(h_len.data(), len_d, sizeof(int) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
+    TILE_TRY(hipStreamSynchronize(c->stream));
+    // the pattern: the most frequent one among the aligned candidates
+    std::map<std::pair<unsigned long long, int>, int> hist;
+    for (int t = 0; t < n_cand; ++t) if (h_len[(size_t)t] > 0) ++hist[{h_pat[(size_t)t], h_len[(size_t)t]}];
+    std::pair<unsigned long long, int> canon{0ull, 0};
+    int best = 0;
+    for (const auto &kv : hist) if (kv.second > best) { best = kv.second; canon = kv.first; }
+    const int UL = canon.second;
+    int FL = 0, FH = 0;
+    bool shape_ok = best >= 8 && UL >= 1;
+    int64_t far_band = 0;
+    if (shape_ok) {
+        int32_t o[8];
+        for (int t = 0; t < UL; ++t) {
+            const int cd = (int)((canon.first >> (8 * t)) & 255u);
+            o[t] = off_tab[cd];
+            TP.off[t] = o[t];
+            TP.val[t] = val_tab ? val_tab[cd] : 0.0;
+        }
+        const int NEAR = TILE_W - 2;
+        while (FL < UL && o[FL] < -NEAR) ++FL;
+        while (FH < UL - FL && o[UL - 1 - FH] > NEAR) ++FH;
+        for (int t = FL; t < UL - FH; ++t) shape_ok = shape_ok && o[t] >= -NEAR && o[t] <= NEAR;
+        shape_ok = shape_ok && UL - FL - FH >= 1 && tile_shape_built(UL, FL, FH);
+        for (int t = 0; t < FL; ++t) far_band = std::max<int64_t>(far_band, std::llabs((long long)o[t]));
+        for (int t = UL - FH; t < UL; ++t) far_band = std::max<int64_t>(far_band, std::llabs((long long)o[t]));
+    }
+    if (!shape_ok) { drop(); return SPRS_OK; }
+    // tiles are placed greedily on the runs of consecutive blocks of that pattern (a run ends where a boundary line or plane
+    // changes the pattern; tiles on a fixed lattice would lose a whole tile per break)
+    TILE_TRY(hipMalloc((void **)&flag_d, (size_t)nw));
+    hipLaunchKernelGGL(tile_flag_kernel, dim3((nw + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, nw, desc_dev, code_dev, canon.first, UL, flag_d);
+    TILE_TRY(hipGetLastError());
+    std::vector<uint8_t> flag((size_t)nw);
+    TILE_TRY(hipMemcpyAsync(flag.data(), flag_d, (size_t)nw, hipMemcpyDeviceToHost, c->stream));
+    TILE_TRY(hipStreamSynchronize(c->stream));
+    if (!val_tab)      // values per entry: 16-byte value loads may reach one entry past a block's last one — keep the matrix's last entries out
+        for (int j = 0; j < nw; ++j) if ((int64_t)wd[(size_t)j].pa + 2 * WAVE * UL + 2 > A->nnz) flag[(size_t)j] = 0;
+    std::vector<int32_t> starts;                            // first block of each tile, in row order
+    std::vector<char> in_tile((size_t)nw, 0);
+    for (int j = 0; j < nw;) {
+        if (!flag[(size_t)j]) { ++j; continue; }
+        int e = j + 1;
+        while (e < nw && flag[(size_t)e] && wd[(size_t)e].ra == wd[(size_t)e - 1].ra + 2 * WAVE) ++e;
+        int b = j;
+        while (b < e && (int64_t)wd[(size_t)b].ra - TILE_W < 0) ++b;                 // the window starts inside x
+        for (; b + TILE_B <= e; b += TILE_B) {
+            if ((int64_t)wd[(size_t)b].ra + TILE_ROWS + TILE_W > A->ncols) break;     // ... and ends inside it
+            starts.push_back(b);
+            for (int q = 0; q < TILE_B; ++q) in_tile[(size_t)(b + q)] = 1;
+        }
+        j = e;
+    }
+    const int n_elig = (int)starts.size();
+    if (n_elig < 8) { drop(); return SPRS_OK; }
+    // XCD sections: tiles sorted by their phase within the far period (rows r and r +- far_band on one XCD, a near window
+    // apart in its walk) and cut into eight sections of equal COUNT (a plane of 60 tiles cut by phase alone gives four XCDs 8
+    // tiles a plane and four 7), or plain eighths where no far slot exists / the band does not repeat
+    const bool periodic = far_band >= 8 * (int64_t)TILE_ROWS && far_band * 4 <= A->nrows && c->spmv_period != 0;
+    std::vector<std::vector<int32_t>> sec(8);
+    {
+        std::vector<int32_t> by_phase((size_t)n_elig);
+        for (int i = 0; i < n_elig; ++i) by_phase[(size_t)i] = i;
+        if (periodic)
+            std::stable_sort(by_phase.begin(), by_phase.end(), [&](int32_t a, int32_t b) {
+                return (int64_t)wd[(size_t)starts[(size_t)a]].ra % far_band < (int64_t)wd[(size_t)starts[(size_t)b]].ra % far_band; });
+        for (int i = 0; i < n_elig; ++i) sec[(size_t)(((int64_t)i * 8) / n_elig)].push_back(starts[(size_t)by_phase[(size_t)i]]);
+        for (auto &v : sec) std::sort(v.begin(), v.end());      // each XCD walks its tiles in row order
+    }
+    std::vector<int32_t> list, xstart(9, 0), left;
+    for (int xq = 0; xq < 8; ++xq) {
+        xstart[(size_t)xq] = (int32_t)(list.size() / 2);
+        for (int32_t b0 : sec[(size_t)xq]) { list.push_back(b0); list.push_back(wd[(size_t)b0].ra); }      // {first block, first row}
+    }
+    xstart[8] = (int32_t)(list.size() / 2);
+    make_left(in_tile, left);
+    TILE_TRY(hipMalloc((void **)&TP.list, sizeof(int32_t) * list.size()));
+    TILE_TRY(hipMalloc((void **)&TP.xstart, sizeof(int32_t) * 9));
+    TILE_TRY(hipMalloc((void **)&TP.left, sizeof(int32_t) * std::max<size_t>(left.size(), 1)));
+    TILE_TRY(hipMemcpyAsync(TP.list, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice, c->stream));
+    TILE_TRY(hipMemcpyAsync(TP.xstart, xstart.data(), sizeof(int32_t) * 9, hipMemcpyHostToDevice, c->stream));
+    if (!left.empty()) TILE_TRY(hipMemcpyAsync(TP.left, left.data(), sizeof(int32_t) * left.size(), hipMemcpyHostToDevice, c->stream));
+    TILE_TRY(hipStreamSynchronize(c->stream));
+    TP.n_tile = n_elig; TP.n_left = (int)left.size();
+    TP.ul = UL; TP.fl = FL; TP.fh = FH;
+    drop();
+#undef TILE_TRY
+    return SPRS_OK;
+}
 
 template <class T>
 int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const std::vector<int32_t> &blk_pa) {
@@ -1468,117 +1774,49 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const std::vector
                 }
                 tr.lap("    wide descriptors, marks, period order");
                 // ---- tile plan (spmv_tile_kernel): runs of TILE_B full uniform blocks with the matrix's most frequent pattern
-                const int n_cand = nw / TILE_B;
-                const bool tile_wanted = c->spmv_tile > 0 || (c->spmv_tile < 0 && stream_loads_nt(c, (size_t)A->nrows * sizeof(T)));
-                if (tile_wanted && c->spmv_uniform != 0 && c->spmv_wide != 0 && n_cand >= 16 && A->ncols >= TILE_ROWS + 2 * TILE_W) {
-                    unsigned long long *pat_d = nullptr; int *len_d = nullptr;
-                    auto drop = [&]() { if (pat_d) (void)hipFree(pat_d); if (len_d) (void)hipFree(len_d); pat_d = nullptr; len_d = nullptr; };
-#define TILE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { snprintf(c->err, sizeof(c->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); drop(); cleanup2(); free_dict(A); return SPRS_ERR_HIP; } } while (0)
-                    TILE_TRY(hipMalloc((void **)&pat_d, sizeof(unsigned long long) * (size_t)n_cand));
-                    TILE_TRY(hipMalloc((void **)&len_d, sizeof(int) * (size_t)n_cand));
-                    hipLaunchKernelGGL(tile_mark_kernel, dim3((n_cand + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, n_cand,
-                                       reinterpret_cast<const BlkDesc *>(D->wide_desc), (const uint8_t *)D->pair_code, pat_d, len_d);
-                    TILE_TRY(hipGetLastError());
-                    std::vector<unsigned long long> h_pat((size_t)n_cand);
-                    std::vector<int> h_len((size_t)n_cand);
-                    TILE_TRY(hipMemcpyAsync(h_pat.data(), pat_d, sizeof(unsigned long long) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
-                    TILE_TRY(hipMemcpyAsync(h_len.data(), len_d, sizeof(int) * (size_t)n_cand, hipMemcpyDeviceToHost, c->stream));
-                    TILE_TRY(hipStreamSynchronize(c->stream));
-                    std::map<std::pair<unsigned long long, int>, int> hist;
-                    for (int t = 0; t < n_cand; ++t) if (h_len[(size_t)t] > 0) ++hist[{h_pat[(size_t)t], h_len[(size_t)t]}];
-                    std::pair<unsigned long long, int> canon{0ull, 0};
-                    int best = 0;
-                    for (const auto &kv : hist) if (kv.second > best) { best = kv.second; canon = kv.first; }
-                    const int UL = canon.second;
-                    int FL = 0, FH = 0;
-                    bool shape_ok = best >= 8 && UL >= 1;
-                    int64_t far_band = 0;
-                    if (shape_ok) {
-                        int32_t o[8];
-                        for (int t = 0; t < UL; ++t) {
-                            const int cd = (int)((canon.first >> (8 * t)) & 255u);
-                            o[t] = pair_off[(size_t)cd];
-                            D->tile_off[t] = o[t];
-                            if constexpr (sizeof(T) == 8 && !is_complex<T>::value) D->tile_val[t] = pair_val[(size_t)cd];
-                        }
-                        const int NEAR = TILE_W - 2;
-                        while (FL < UL && o[FL] < -NEAR) ++FL;
-                        while (FH < UL - FL && o[UL - 1 - FH] > NEAR) ++FH;
-                        for (int t = FL; t < UL - FH; ++t) shape_ok = shape_ok && o[t] >= -NEAR && o[t] <= NEAR;
-                        shape_ok = shape_ok && UL - FL - FH >= 1 && tile_shape_built(UL, FL, FH);
-                        for (int t = 0; t < FL; ++t) far_band = std::max<int64_t>(far_band, std::llabs((long long)o[t]));
-                        for (int t = UL - FH; t < UL; ++t) far_band = std::max<int64_t>(far_band, std::llabs((long long)o[t]));
-                    }
-                    if (shape_ok) {
-                        // tiles are placed greedily on the runs of consecutive blocks of that pattern (a run ends where a
-                        // boundary line or plane changes the pattern; aligned tiles would lose a whole tile per break)
-                        uint8_t *flag_d = nullptr;
-                        TILE_TRY(hipMalloc((void **)&flag_d, (size_t)nw));
-                        hipLaunchKernelGGL(tile_flag_kernel, dim3((nw + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, nw,
-                                           reinterpret_cast<const BlkDesc *>(D->wide_desc), (const uint8_t *)D->pair_code, canon.first, UL, flag_d);
-                        std::vector<uint8_t> flag((size_t)nw);
-                        hipError_t fe = hipGetLastError();
-                        if (fe == hipSuccess) fe = hipMemcpyAsync(flag.data(), flag_d, (size_t)nw, hipMemcpyDeviceToHost, c->stream);
-                        if (fe == hipSuccess) fe = hipStreamSynchronize(c->stream);
-                        (void)hipFree(flag_d);
-                        TILE_TRY(fe);
-                        std::vector<int32_t> starts;                            // first block of each tile, in row order
-                        std::vector<char> in_tile((size_t)nw, 0);
-                        for (int j = 0; j < nw;) {
-                            if (!flag[(size_t)j]) { ++j; continue; }
-                            int e = j + 1;
-                            while (e < nw && flag[(size_t)e] && wd[(size_t)e].ra == wd[(size_t)e - 1].ra + 2 * WAVE) ++e;
-                            int b = j;
-                            while (b < e && (int64_t)wd[(size_t)b].ra - TILE_W < 0) ++b;                 // the window starts inside x
-                            for (; b + TILE_B <= e; b += TILE_B) {
-                                if ((int64_t)wd[(size_t)b].ra + TILE_ROWS + TILE_W > A->ncols) break;     // ... and ends inside it
-                                starts.push_back(b);
-                                for (int q = 0; q < TILE_B; ++q) in_tile[(size_t)(b + q)] = 1;
+                {
+                    std::vector<int32_t> left_order;
+                    if (const int st = build_tile_plan(A, D->tile_pair, reinterpret_cast<const BlkDesc *>(D->wide_desc), (const uint8_t *)D->pair_code, wd,
+                                                       pair_off.data(), reinterpret_cast<const double *>(pair_val.data()), [&](std::vector<char> &in_tile, std::vector<int32_t> &left) {
+                            for (int pos = 0; pos < nw; ++pos) {
+                                const int j = ord.empty() ? pos : ord[(size_t)pos];
+                                if (!in_tile[(size_t)j]) left.push_back(j);
                             }
-                            j = e;
-                        }
-                        const int n_elig = (int)starts.size();
-                        // XCD sections: by the tile's phase within the far period (rows r and r +- far_band on one XCD, a near
-                        // window apart in its walk), or plain eighths where no far slot exists / the band does not repeat
-                        const bool periodic = far_band >= 8 * (int64_t)TILE_ROWS && far_band * 4 <= A->nrows && c->spmv_period != 0;
-                        // (equal COUNTS per XCD: a plane of 60 tiles cut by phase alone gives four XCDs 8 tiles a plane and four 7)
-                        std::vector<std::vector<int32_t>> sec(8);
-                        {
-                            std::vector<int32_t> by_phase((size_t)n_elig);
-                            for (int i = 0; i < n_elig; ++i) by_phase[(size_t)i] = i;
-                            if (periodic)
-                                std::stable_sort(by_phase.begin(), by_phase.end(), [&](int32_t a, int32_t b) {
-                                    return (int64_t)wd[(size_t)starts[(size_t)a]].ra % far_band < (int64_t)wd[(size_t)starts[(size_t)b]].ra % far_band; });
-                            for (int i = 0; i < n_elig; ++i) sec[(size_t)(((int64_t)i * 8) / std::max(n_elig, 1))].push_back(starts[(size_t)by_phase[(size_t)i]]);
-                            for (auto &v : sec) std::sort(v.begin(), v.end());      // each XCD walks its tiles in row order
-                        }
-                        std::vector<int32_t> list, xstart(9, 0), left;
-                        for (int xq = 0; xq < 8; ++xq) {
-                            xstart[(size_t)xq] = (int32_t)(list.size() / 2);
-                            for (int32_t b0 : sec[(size_t)xq]) { list.push_back(b0); list.push_back(wd[(size_t)b0].ra); }      // {first block, first row}
-                        }
-                        xstart[8] = (int32_t)(list.size() / 2);
-                        for (int pos = 0; pos < nw; ++pos) {
-                            const int j = ord.empty() ? pos : ord[(size_t)pos];
-                            if (!in_tile[(size_t)j]) left.push_back(j);
-                        }
-                        if (n_elig >= 8) {
-                            TILE_TRY(hipMalloc((void **)&D->tile_list, sizeof(int32_t) * list.size()));
-                            TILE_TRY(hipMalloc((void **)&D->tile_xstart, sizeof(int32_t) * 9));
-                            TILE_TRY(hipMalloc((void **)&D->tile_left, sizeof(int32_t) * std::max<size_t>(left.size(), 1)));
-                            TILE_TRY(hipMemcpyAsync(D->tile_list, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice, c->stream));
-                            TILE_TRY(hipMemcpyAsync(D->tile_xstart, xstart.data(), sizeof(int32_t) * 9, hipMemcpyHostToDevice, c->stream));
-                            if (!left.empty()) TILE_TRY(hipMemcpyAsync(D->tile_left, left.data(), sizeof(int32_t) * left.size(), hipMemcpyHostToDevice, c->stream));
-                            TILE_TRY(hipStreamSynchronize(c->stream));
-                            D->n_tile = n_elig; D->n_tile_left = (int)left.size();
-                            D->tile_ul = UL; D->tile_fl = FL; D->tile_fh = FH;
-                        }
-                    }
-                    drop();
-#undef TILE_TRY
+                        })) { cleanup2(); free_dict(A); return st; }
                     tr.lap("    tile plan");
                 }
             }
+        }
+    }
+    if constexpr (sizeof(T) == 8 && !is_complex<T>::value) {
+        // ---- tiles of the OFFSET-CODE stream (spmv_tile_off_kernel), where that is the stream the handle multiplies with:
+        // its own 128-row descriptors (pairs of the 64-row blocks), uniform and seam blocks marked on the offset codes
+        const bool tile_wanted = c->spmv_tile > 0 || (c->spmv_tile < 0 && stream_loads_nt(c, (size_t)A->nrows * sizeof(T)));
+        if (tile_wanted && (D->pair_code == nullptr || c->spmv_dict == 1) && c->spmv_uniform != 0 && c->spmv_wide != 0 && A->n_rowblk >= 2 * TILE_B * 16) {
+            const int nb64 = A->n_rowblk, nw = (nb64 + 1) / 2;
+            std::vector<BlkDescHost2> owd((size_t)nw);
+            for (int j = 0; j < nw; ++j) {
+                const size_t b0 = (size_t)2 * j, b1 = (size_t)std::min(2 * j + 2, nb64);
+                owd[(size_t)j] = BlkDescHost2{blk[b0], blk[b1], blk_pa[b0], blk_pa[b1] - blk_pa[b0]};
+            }
+            DICT_TRY2(hipMalloc(&D->owide_desc, sizeof(BlkDescHost2) * (size_t)nw));
+            DICT_TRY2(hipMemcpyAsync(D->owide_desc, owd.data(), sizeof(BlkDescHost2) * (size_t)nw, hipMemcpyHostToDevice, c->stream));
+            const int gu = std::max(1, std::min(c->num_cu * 8, (nw + NWAVE - 1) / NWAVE));
+            hipLaunchKernelGGL(mark_uniform_kernel, dim3(gu), dim3(BLOCK), 0, c->stream, nw, reinterpret_cast<BlkDesc *>(D->owide_desc), A->row_ptr,
+                               D->idx_code, UNI2_MAXLEN, (const int32_t *)D->off_tab, 0, c->spmv_seam != 0 ? 1 : 0, (int)A->ncols);
+            DICT_TRY2(hipGetLastError());
+            DICT_TRY2(hipStreamSynchronize(c->stream));
+            D->n_owide = nw;
+            if (const int st = build_tile_plan(A, D->tile_off, reinterpret_cast<const BlkDesc *>(D->owide_desc), (const uint8_t *)D->idx_code, owd,
+                                               off_tab.data(), (const double *)nullptr, [&](std::vector<char> &in_tile, std::vector<int32_t> &left) {
+                    for (int j = 0; j < nw; ++j) {          // the per-block kernel's 64-row blocks, natural order
+                        if (in_tile[(size_t)j]) continue;
+                        left.push_back(2 * j);
+                        if (2 * j + 1 < nb64) left.push_back(2 * j + 1);
+                    }
+                })) { cleanup2(); free_dict(A); return st; }
+            if (D->tile_off.n_tile == 0) { (void)hipFree(D->owide_desc); D->owide_desc = nullptr; D->n_owide = 0; }
+            tr.lap("    tile plan (offset stream)");
         }
     }
     cleanup2();
@@ -1590,12 +1828,20 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const std::vector
 }  // namespace
 
 int tile_blocks() { return TILE_B; }
+bool tile_plan_used(const sprs_csr *A) {
+    const sprs_ctx *c = A->ctx;
+    if (!A->dict || c->spmv_tile == 0 || c->spmv_wide == 0) return false;
+    const int dm = dict_mode(A);
+    if (dm == 2) return A->dict->tile_pair.n_tile > 0;
+    return dm == 1 && A->dict->tile_off.n_tile > 0 && A->tail != nullptr && c->spmv_wideload != 0 && c->spmv_uniform != 0;
+}
 
 void free_dict(sprs_csr *A) {
     if (!A || !A->dict) return;
     sprs_dict *D = A->dict;
     for (void *q : {(void *)D->idx_code, (void *)D->pair_code, (void *)D->off_tab, (void *)D->pair_off, D->pair_val, D->wide_desc, D->off_desc, (void *)D->wide_order, (void *)D->off_order,
-                    (void *)D->tile_list, (void *)D->tile_xstart, (void *)D->tile_left})
+                    (void *)D->tile_pair.list, (void *)D->tile_pair.xstart, (void *)D->tile_pair.left,
+                    (void *)D->tile_off.list, (void *)D->tile_off.xstart, (void *)D->tile_off.left, D->owide_desc})
         if (q) (void)hipFree(q);
     delete D;
     A->dict = nullptr;
@@ -1643,17 +1889,18 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
         if (order == nullptr && count == A->n_rowblk) { count_w = D->n_wide; order_w = c->spmv_period != 0 ? D->wide_order : nullptr; if (order_w) xcd_chunk = 0; }   // the period order encodes its XCD placement for the round-robin walk
         else if (A->dist && A->dist->order_int_w && order == A->dist->order_int && count == A->dist->n_int) { order_w = A->dist->order_int_w; count_w = A->dist->n_int_w; }
         else if (A->dist && A->dist->order_bnd_w && order == A->dist->order_bnd && count == A->dist->n_bnd) { order_w = A->dist->order_bnd_w; count_w = A->dist->n_bnd_w; }
-        if (pair && D->n_tile > 0 && c->spmv_tile != 0 && c->spmv_wide != 0 && order == nullptr && count == A->n_rowblk && g % 8 == 0) {
+        if (pair && D->tile_pair.n_tile > 0 && c->spmv_tile != 0 && c->spmv_wide != 0 && order == nullptr && count == A->n_rowblk && g % 8 == 0) {
             // LDS x-window tiles + the per-block walk over the blocks outside them, one launch
             const BlkDesc *wd = reinterpret_cast<const BlkDesc *>(D->wide_desc);
             const double *pvd = reinterpret_cast<const double *>(D->pair_val);
             TilePat tp;
-            for (int t = 0; t < 8; ++t) { tp.off[t] = D->tile_off[t]; tp.val[t] = D->tile_val[t]; }
+            const sprs_tile_plan &TP = D->tile_pair;
+            for (int t = 0; t < 8; ++t) { tp.off[t] = TP.off[t]; tp.val[t] = TP.val[t]; }
             const bool ux = dot_mode == 2 && u == x;
-#define SPRS_TSPMV(DM, UXV, U, L, H) SPRS_LAUNCH_SPMV(c, (spmv_tile_kernel<DM, UXV, U, L, H>), g, reinterpret_cast<const int2 *>(D->tile_list), D->tile_xstart, wd, tp, D->n_tile_left, \
-                                                      D->tile_left, A->row_ptr, D->pair_code, D->pair_off, pvd, x, y, u, part0, part1, status, (int)A->nrows, (int)A->ncols, fin)
+#define SPRS_TSPMV(DM, UXV, U, L, H) SPRS_LAUNCH_SPMV(c, (spmv_tile_kernel<DM, UXV, U, L, H>), g, reinterpret_cast<const int2 *>(TP.list), TP.xstart, wd, tp, TP.n_left, \
+                                                      TP.left, A->row_ptr, D->pair_code, D->pair_off, pvd, x, y, u, part0, part1, status, (int)A->nrows, (int)A->ncols, fin)
 #define SPRS_TSHAPE(U, L, H)                                                                                             \
-            if (D->tile_ul == U && D->tile_fl == L && D->tile_fh == H) {                                                 \
+            if (TP.ul == U && TP.fl == L && TP.fh == H) {                                                 \
                 if (dot_mode == 0) SPRS_TSPMV(0, false, U, L, H); else if (dot_mode == 1) SPRS_TSPMV(1, false, U, L, H);   \
                 else if (ux) SPRS_TSPMV(2, true, U, L, H); else SPRS_TSPMV(2, false, U, L, H);                           \
             }
@@ -1691,6 +1938,27 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
             // f64 offset codes: 16-byte value loads (the plain stream's measure, profiles/r03_tuning.md §2)
             g2_last = (int)((A->nnz - 1) >> 1);
             tail2 = reinterpret_cast<const V2d *>(reinterpret_cast<const char *>(A->tail) + 16) + (g2_last - 2 * (int)((A->nnz - 1) >> 2));
+            if (D->tile_off.n_tile > 0 && D->owide_desc && c->spmv_tile != 0 && c->spmv_wide != 0 && c->spmv_uniform != 0 && order == nullptr &&
+                count == A->n_rowblk && g % 8 == 0 && !conj_x) {
+                // LDS x-window tiles + the per-block walk over the 64-row blocks outside them, one launch
+                const sprs_tile_plan &TP = D->tile_off;
+                TilePat tp;
+                for (int t = 0; t < 8; ++t) { tp.off[t] = TP.off[t]; tp.val[t] = 0.0; }
+                const bool ux = dot_mode == 2 && u == x;
+                const BlkDesc *owd = reinterpret_cast<const BlkDesc *>(D->owide_desc);
+#define SPRS_TOSPMV(DM, UXV, U, L, H) SPRS_LAUNCH_SPMV(c, (spmv_tile_off_kernel<DM, UXV, U, L, H>), g, reinterpret_cast<const int2 *>(TP.list), TP.xstart, owd, tp, \
+                                                       TP.n_left, TP.left, dsc, A->row_ptr, code, otab, v, x, y, u, part0, part1, status, fin, tail2, g2_last)
+#define SPRS_TOSHAPE(U, L, H)                                                                                            \
+                if (TP.ul == U && TP.fl == L && TP.fh == H) {                                                            \
+                    if (dot_mode == 0) SPRS_TOSPMV(0, false, U, L, H); else if (dot_mode == 1) SPRS_TOSPMV(1, false, U, L, H); \
+                    else if (ux) SPRS_TOSPMV(2, true, U, L, H); else SPRS_TOSPMV(2, false, U, L, H);                     \
+                }
+                SPRS_TILE_SHAPES(SPRS_TOSHAPE)
+#undef SPRS_TOSHAPE
+#undef SPRS_TOSPMV
+                SPRS_HIP_TRY(c, hipGetLastError());
+                return SPRS_OK;
+            }
 #define SPRS_DSPMVW(DM) SPRS_LAUNCH_SPMV(c, (spmv_dict_kernel<T, DM, false, false, true>), g, count, xcd_chunk, dsc, order, A->row_ptr, \
                                          code, otab, pv, v, x, y, u, part0, part1, status, fin, tail2, g2_last)
             if (dot_mode == 0) SPRS_DSPMVW(0); else if (dot_mode == 1) SPRS_DSPMVW(1); else SPRS_DSPMVW(2);

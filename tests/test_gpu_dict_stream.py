@@ -732,3 +732,59 @@ def test_lds_window_tiles_policy_and_fallbacks(sa, oracle):
         assert abs(out[0] - out[1]) <= max(3, out[0] // 10)
     finally:
         ctx.set("spmv_tile", -1)
+
+
+@pytest.mark.parametrize("name", list(_tile_cases()))
+def test_lds_window_tiles_with_a_value_per_entry(sa, oracle, name):
+    """The same tiles on the OFFSET-CODE stream (spmv_tile_off_kernel): the patterns of `test_lds_window_tiles_bit_identical`
+    with a different value in every entry (no value dictionary, so the handle multiplies with one-byte offset codes + the
+    values).  A block's values are streamed through the wavefront's LDS slice; rows behind a short seam row start earlier.
+    y bit-identical to the oracle and to the per-block kernel; odd and even first entries of blocks both occur (seam rows
+    shift the parity), the last block of the matrix stays outside the tiles."""
+    ctx = sa.default_ctx(0)
+    indptr, cols, data, rhs, exact = _tile_cases()[name]()
+    n = indptr.size - 1
+    rng = np.random.default_rng(11)
+    vals = rng.uniform(0.5, 1.5, data.size) * np.where(data == 0, 1.0, np.sign(data))
+    x = rand_vec(n, np.float64, 78)
+    ref = oracle.spmv(indptr, cols, vals, x)
+    e = oracle.conj_dot(x, ref)
+    plans = {}
+    try:
+        for tile in (0, 1):
+            ctx.set("spmv_tile", tile)
+            A = sa.HipCsr.new((n, n), indptr, cols, vals)
+            assert A.stream_format()[0] == 1
+            plans[tile] = A.tile_plan()
+            y = np.full(n, 9.0)
+            A.mul_vec(x, y)
+            bad = np.flatnonzero(y != ref)
+            assert bad.size == 0, (tile, bad[:8], bad.size)
+            assert np.array_equal(bits(y), bits(ref))
+            y2 = np.full(n, -3.0)
+            d = A.mul_vec_dot(x, y2)
+            assert np.array_equal(bits(y2), bits(ref))
+            assert abs(d - e) <= 1e-12 * max(1.0, float(np.sum(np.abs(x * ref))))
+        assert plans[0] == (0, 0, 0)
+        nt, ntb, nob = plans[1]
+        nb = (n + 127) // 128
+        assert nt >= 8 and ntb == 32 * nt and ntb + nob == nb, (plans, nb)
+        assert ntb >= 0.3 * nb, (plans, nb)
+        # inside a solve (the fused double dot; Jacobi so that its operand is not the input vector, then plain)
+        diag = vals[np.flatnonzero(cols == np.repeat(np.arange(n), np.diff(indptr)))]
+        if diag.size == n:
+            b = oracle.spmv(indptr, cols, vals, np.ones(n))
+            dom = np.abs(diag) * 4.0 + 8.0                                   # make it solvable: a dominant diagonal
+            vals2 = vals.copy(); vals2[np.flatnonzero(cols == np.repeat(np.arange(n), np.diff(indptr)))] = dom
+            b = oracle.spmv(indptr, cols, vals2, np.ones(n))
+            A2 = sa.HipCsr.new((n, n), indptr, cols, vals2)
+            assert A2.tile_plan()[0] >= 8
+            for jac in (True, False):
+                s = sa.BiCGStab.new(A2, n); sol = np.zeros(n)
+                if jac:
+                    its, res = s.precond_solve(sa.DiagPrecond.new(dom), b, sol, 500, 1e-11)
+                else:
+                    its, res = s.solve(b, sol, 500, 1e-11)
+                assert np.max(np.abs(sol - 1.0)) < 1e-8, (jac, its, res)
+    finally:
+        ctx.set("spmv_tile", -1)
