@@ -57,6 +57,9 @@ KERNEL_NAMES = {0: "spmv_kernel<double> (plain CSR stream, wavefront-private LDS
                 1: "spmv_dict_kernel<double, PAIR=false> (one-byte column-offset codes + 8-byte values; csrc/spmv_dict.hip)",
                 2: "spmv_pair2_kernel<DOT> (one-byte (offset, value) pair codes, two rows per lane, uniform blocks from a scalar "
                    "pattern; csrc/spmv_dict.hip)",
+                4: "spmv_tile_off_kernel<DOT> (offset codes + 8-byte values; runs of 4096 rows of one stencil pattern: x from a window staged in "
+                   "LDS + per-row-pair far loads, the values streamed through the wavefront's LDS slice; the other 64-row blocks by the "
+                   "per-block walk of the same launch; csrc/spmv_dict.hip)",
                 3: "spmv_tile_kernel<DOT> (pair codes; runs of 4096 rows of one stencil pattern multiplied from an x window staged in "
                    "LDS + per-row-pair far loads, tiles dealt to the XCDs by the far period; the other 128-row blocks by the "
                    "per-block walk of the same launch; csrc/spmv_dict.hip)"}
@@ -136,11 +139,16 @@ def stream_info(A, n, nnz, s):
     code_b = 0 if mode == 0 else 1
     moved = int(nnz * (per_nnz - code_b) + (1.0 - uf) * (nnz * code_b + (n + 1) * 4) + 2 * n * s)
     tiles = A.tile_plan() if hasattr(A, "tile_plan") else (0, 0, 0)
+    if tiles[0] > 0 and mode == 1:
+        # offset-code tiles read neither codes nor row_ptr (seam blocks included); the 64-row blocks outside the tiles (a few
+        # per cent) are counted as if none of them did either — fewer bytes, i.e. the fraction errs on the low side
+        nu = nb
+        moved = int(nnz * (per_nnz - code_b) + 2 * n * s)
     out = dict(stream=STREAM_NAMES[mode], mode=mode, distinct_offsets=n_off, distinct_pairs=n_pair,
                bytes_per_nnz=per_nnz, format_bytes_per_launch=nnz * per_nnz + (n + 1) * 4 + 2 * n * s,
                row_blocks=nb, descriptor_only_blocks=nu, bytes_moved_per_launch=moved)
     if tiles[0] > 0:        # same bytes: a tile reads x once per window instead of once per column, all of it on chip
-        out.update(kernel_id=3, lds_window_tiles=tiles[0], blocks_in_tiles=tiles[1], blocks_walked_singly=tiles[2])
+        out.update(kernel_id=3 if mode == 2 else 4, lds_window_tiles=tiles[0], blocks_in_tiles=tiles[1], blocks_walked_singly=tiles[2])
     return out
 
 
@@ -655,7 +663,9 @@ def main():
         roof["note"] = ("per rank; `achieved` / `frac` = the bytes a launch reads and writes (bytes_note) / mean launch time (HIP events on the "
                         "solver's stream, inside the timed solve)"
                         + ("; this kernel is bound by the CUs' vector-memory path and gather latency, not by HBM (DESIGN.md §3): its fraction says "
-                           "how little of the HBM bandwidth it needs, BASELINE's CSR figure is roofline_plain_csr" if sinfo["mode"] == 2 else "")
+                           "how little of the HBM bandwidth it needs, BASELINE's CSR figure is roofline_plain_csr" if sinfo["mode"] == 2 and "kernel_id" not in sinfo else "")
+                        + ("; the tile kernel stages each near x window once per 4096 rows (DESIGN.md §3): what it moves crosses the fabric at the rate a "
+                           "pure read stream reaches on this chip (5.5 TB/s); BASELINE's CSR figure is roofline_plain_csr" if sinfo.get("kernel_id") == 3 else "")
                         + ("; N>1: the bracketed time includes the wait for the halo exchange of the boundary rows" if world > 1 else ""))
         out = dict(metric="BiCGStab iterations/s (f64, 50M-row 7-point 3-D Poisson) + CSR SpMV GB/s vs HBM roofline",
                    value=1e3 / ms_step, unit="iterations/s", n_gpus=world, steps=args.steps, warmup=args.warmup,

@@ -543,6 +543,7 @@ int sprs_csr_destroy(sprs_csr *A) {
         if (A->dist->ag_buf) (void)hipFree(A->dist->ag_buf);
         if (A->dist->order_int) (void)hipFree(A->dist->order_int);
         if (A->dist->order_bnd) (void)hipFree(A->dist->order_bnd);
+        for (void *q : {(void *)A->dist->tile_int.list, (void *)A->dist->tile_int.xstart, (void *)A->dist->tile_int.left}) if (q) (void)hipFree(q);
         if (A->dist->order_int_w) (void)hipFree(A->dist->order_int_w);
         if (A->dist->order_bnd_w) (void)hipFree(A->dist->order_bnd_w);
         if (A->dist->ev_pack) (void)hipEventDestroy(A->dist->ev_pack);
@@ -588,6 +589,14 @@ int sprs_csr_tile_plan(const sprs_csr *A, int64_t *n_tiles, int64_t *n_tile_bloc
     if (!D || A->ctx->spmv_tile == 0 || A->ctx->spmv_wide == 0) return SPRS_OK;
     const int dm = dict_mode(A);
     if (dm != 1 && dm != 2) return SPRS_OK;
+    if (A->dist && A->dist->order_int) {
+        // a distributed operator with an interior / boundary split: the interior launch's plan (boundary blocks are walked singly)
+        const sprs_tile_plan &TI = A->dist->tile_int;
+        if (TI.n_tile <= 0 || A->dist->tile_int_off != (dm == 1)) return SPRS_OK;
+        *n_tiles = TI.n_tile; *n_tile_blocks = (int64_t)TI.n_tile * sprs::tile_blocks();
+        *n_other_blocks = (A->n_rowblk + 1) / 2 - *n_tile_blocks;
+        return SPRS_OK;
+    }
     const sprs_tile_plan &TP = dm == 2 ? D->tile_pair : D->tile_off;
     if (TP.n_tile <= 0 || !sprs::tile_plan_used(A)) return SPRS_OK;
     // the other blocks in 128-row units (the offset stream walks them as 64-row blocks)

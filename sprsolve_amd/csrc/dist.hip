@@ -278,6 +278,48 @@ int dist_csr_create(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz
                       hipEventCreateWithFlags(&D->ev_halo, hipEventDisableTiming) == hipSuccess;
             if (!ok) { sprs_csr_destroy(A); return SPRS_ERR_HIP; }
             D->n_int = (int32_t)oi.size(); D->n_bnd = (int32_t)ob.size();
+            // LDS-window tiles (spmv_dict.hip) of the stream this handle multiplies with: the interior launch keeps the tiles
+            // that hold interior rows only (the last plane of a slab can look exactly like the stencil — its halo columns sit
+            // one plane behind the local rows — and must wait for the halo) and walks the other interior blocks one by one
+            if (A->dict && sprs::tile_plan_used(A)) {
+                const bool off_stream = sprs::dict_mode(A) == 1;
+                const sprs_tile_plan &TP = off_stream ? A->dict->tile_off : A->dict->tile_pair;
+                const int nw = (A->n_rowblk + 1) / 2, TB = sprs::tile_blocks();
+                std::vector<char> bnd128((size_t)nw, 0), in_int_tile((size_t)nw, 0);
+                for (int j = 0; j < nw; ++j) {
+                    const int b0 = 2 * j, b1 = std::min(2 * j + 1, A->n_rowblk - 1);
+                    bnd128[(size_t)j] = hi[b0] >= n_local || hi[b1] >= n_local;
+                }
+                std::vector<int32_t> list, xstart(9, 0), left;
+                for (int xq = 0; xq < 8; ++xq) {
+                    xstart[(size_t)xq] = (int32_t)(list.size() / 2);
+                    for (int t = TP.h_xstart[(size_t)xq]; t < TP.h_xstart[(size_t)xq + 1]; ++t) {
+                        const int b0 = TP.h_list[(size_t)2 * t];
+                        bool inside = true;
+                        for (int q = 0; q < TB; ++q) inside = inside && !bnd128[(size_t)(b0 + q)];
+                        if (!inside) continue;
+                        list.push_back(b0); list.push_back(TP.h_list[(size_t)2 * t + 1]);
+                        for (int q = 0; q < TB; ++q) in_int_tile[(size_t)(b0 + q)] = 1;
+                    }
+                }
+                xstart[8] = (int32_t)(list.size() / 2);
+                if (off_stream) { for (int32_t b : oi) if (!in_int_tile[(size_t)(b / 2)]) left.push_back(b); }
+                else { for (int32_t j : oiw) if (!in_int_tile[(size_t)j]) left.push_back(j); }
+                if (list.size() / 2 >= 8 && (off_stream || wide)) {
+                    sprs_tile_plan &TI = D->tile_int;
+                    bool okt = hipMalloc((void **)&TI.list, sizeof(int32_t) * list.size()) == hipSuccess &&
+                               hipMalloc((void **)&TI.xstart, sizeof(int32_t) * 9) == hipSuccess &&
+                               hipMalloc((void **)&TI.left, sizeof(int32_t) * std::max<size_t>(left.size(), 1)) == hipSuccess &&
+                               hipMemcpy(TI.list, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice) == hipSuccess &&
+                               hipMemcpy(TI.xstart, xstart.data(), sizeof(int32_t) * 9, hipMemcpyHostToDevice) == hipSuccess &&
+                               (left.empty() || hipMemcpy(TI.left, left.data(), sizeof(int32_t) * left.size(), hipMemcpyHostToDevice) == hipSuccess);
+                    if (!okt) { sprs_csr_destroy(A); return SPRS_ERR_HIP; }
+                    TI.n_tile = (int)(list.size() / 2); TI.n_left = (int)left.size();
+                    TI.ul = TP.ul; TI.fl = TP.fl; TI.fh = TP.fh;
+                    for (int t = 0; t < 8; ++t) { TI.off[t] = TP.off[t]; TI.val[t] = TP.val[t]; }
+                    D->tile_int_off = off_stream;
+                }
+            }
         }
     }
     *out = A;

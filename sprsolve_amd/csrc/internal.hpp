@@ -130,6 +130,19 @@ struct sprs_comm {
 // Row-partition metadata of a distributed CSR operator: which local x entries each peer needs
 // (packed and sent before every SpMV) and where the entries received from each peer land in
 // the halo tail [n_local, n_ext) of the extended x vector.
+// Runs of TILE_B consecutive full uniform 128-row blocks that share one pattern whose NEAR columns (|col - row| <= TILE_W - 2)
+// are taken from an LDS window of x (spmv_dict.hip); the blocks outside those runs stay with the per-block walk (same launch)
+struct sprs_tile_plan {
+    int32_t *list = nullptr;       // device: {first 128-row block, first row} of each tile, eight per-XCD sections in row order
+    int32_t *xstart = nullptr;     // device, 9 entries: section bounds within list
+    int32_t *left = nullptr;       // device: the other blocks, in the walk order they had (128-row blocks: pair stream; 64-row blocks: offset stream)
+    int n_tile = 0, n_left = 0;
+    int ul = 0, fl = 0, fh = 0;    // pattern shape: slots, leading far slots, trailing far slots
+    int32_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double val[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // pair stream: the pattern's values
+    std::vector<int32_t> h_list, h_xstart;         // host copies of list / xstart (the distributed operator cuts its interior plan from them)
+};
+
 struct sprs_dist_info {
     sprs_comm *comm = nullptr;
     int64_t n_local = 0, n_ext = 0;
@@ -146,6 +159,8 @@ struct sprs_dist_info {
     int32_t n_int = 0, n_bnd = 0;
     // the same split in units of the 128-row blocks of the two-rows-per-lane kernel (null when it does not apply)
     int32_t *order_int_w = nullptr, *order_bnd_w = nullptr;
+    sprs_tile_plan tile_int;       // LDS-window tiles that hold interior rows only + the interior blocks outside them (the interior launch)
+    bool tile_int_off = false;     // ... of the offset-code stream (else the pair-code stream)
     int32_t n_int_w = 0, n_bnd_w = 0;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
@@ -154,18 +169,6 @@ struct sprs_dist_info {
 // Dictionary-compressed copy of the (col_idx, val) stream (spmv_dict.hip): one byte per nnz indexing the
 // table of distinct (col - row) offsets or, for real matrices with few distinct values, the table of distinct
 // (offset, value) pairs.  Built at handle creation when the matrix qualifies.
-// Runs of TILE_B consecutive full uniform 128-row blocks that share one pattern whose NEAR columns (|col - row| <= TILE_W - 2)
-// are taken from an LDS window of x (spmv_dict.hip); the blocks outside those runs stay with the per-block walk (same launch)
-struct sprs_tile_plan {
-    int32_t *list = nullptr;       // device: {first 128-row block, first row} of each tile, eight per-XCD sections in row order
-    int32_t *xstart = nullptr;     // device, 9 entries: section bounds within list
-    int32_t *left = nullptr;       // device: the other blocks, in the walk order they had (128-row blocks: pair stream; 64-row blocks: offset stream)
-    int n_tile = 0, n_left = 0;
-    int ul = 0, fl = 0, fh = 0;    // pattern shape: slots, leading far slots, trailing far slots
-    int32_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double val[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // pair stream: the pattern's values
-};
-
 struct sprs_dict {
     uint8_t *idx_code = nullptr;   // device, nnz (+ pad): code of col - row
     uint8_t *pair_code = nullptr;  // device, nnz (+ pad): code of the (col - row, value) pair, or null

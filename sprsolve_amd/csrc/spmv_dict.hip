@@ -1557,7 +1557,7 @@ static int build_tile_plan(sprs_csr *A, sprs_tile_plan &TP, const BlkDesc *desc_
             std::stable_sort(by_phase.begin(), by_phase.end(), [&](int32_t a, int32_t b) {
                 return (int64_t)wd[(size_t)starts[(size_t)a]].ra % far_band < (int64_t)wd[(size_t)starts[(size_t)b]].ra % far_band; });
         for (int i = 0; i < n_elig; ++i) sec[(size_t)(((int64_t)i * 8) / n_elig)].push_back(starts[(size_t)by_phase[(size_t)i]]);
-        for (auto &v : sec) std::sort(v.begin(), v.end());      // each XCD walks its tiles in row order
+        for (auto &v : sec) std::sort(v.begin(), v.end());      // each XCD walks its tiles in row order (column by column through the planes: 17 % less fabric traffic, same time — profiles/r03_tuning.md §8)
     }
     std::vector<int32_t> list, xstart(9, 0), left;
     for (int xq = 0; xq < 8; ++xq) {
@@ -1575,6 +1575,7 @@ static int build_tile_plan(sprs_csr *A, sprs_tile_plan &TP, const BlkDesc *desc_
     TILE_TRY(hipStreamSynchronize(c->stream));
     TP.n_tile = n_elig; TP.n_left = (int)left.size();
     TP.ul = UL; TP.fl = FL; TP.fh = FH;
+    TP.h_list = list; TP.h_xstart = xstart;
     drop();
 #undef TILE_TRY
     return SPRS_OK;
@@ -1889,12 +1890,18 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
         if (order == nullptr && count == A->n_rowblk) { count_w = D->n_wide; order_w = c->spmv_period != 0 ? D->wide_order : nullptr; if (order_w) xcd_chunk = 0; }   // the period order encodes its XCD placement for the round-robin walk
         else if (A->dist && A->dist->order_int_w && order == A->dist->order_int && count == A->dist->n_int) { order_w = A->dist->order_int_w; count_w = A->dist->n_int_w; }
         else if (A->dist && A->dist->order_bnd_w && order == A->dist->order_bnd && count == A->dist->n_bnd) { order_w = A->dist->order_bnd_w; count_w = A->dist->n_bnd_w; }
-        if (pair && D->tile_pair.n_tile > 0 && c->spmv_tile != 0 && c->spmv_wide != 0 && order == nullptr && count == A->n_rowblk && g % 8 == 0) {
+        // which tile plan this launch runs through: the handle's (whole matrix) or the distributed operator's interior one
+        const bool whole = order == nullptr && count == A->n_rowblk;
+        const bool interior = A->dist && A->dist->order_int && order == A->dist->order_int && count == A->dist->n_int && A->dist->tile_int.n_tile > 0;
+        const sprs_tile_plan *tpp = nullptr;
+        if (pair && whole && D->tile_pair.n_tile > 0) tpp = &D->tile_pair;
+        else if (pair && interior && !A->dist->tile_int_off) tpp = &A->dist->tile_int;
+        if (tpp && c->spmv_tile != 0 && c->spmv_wide != 0 && g % 8 == 0) {
             // LDS x-window tiles + the per-block walk over the blocks outside them, one launch
             const BlkDesc *wd = reinterpret_cast<const BlkDesc *>(D->wide_desc);
             const double *pvd = reinterpret_cast<const double *>(D->pair_val);
             TilePat tp;
-            const sprs_tile_plan &TP = D->tile_pair;
+            const sprs_tile_plan &TP = *tpp;
             for (int t = 0; t < 8; ++t) { tp.off[t] = TP.off[t]; tp.val[t] = TP.val[t]; }
             const bool ux = dot_mode == 2 && u == x;
 #define SPRS_TSPMV(DM, UXV, U, L, H) SPRS_LAUNCH_SPMV(c, (spmv_tile_kernel<DM, UXV, U, L, H>), g, reinterpret_cast<const int2 *>(TP.list), TP.xstart, wd, tp, TP.n_left, \
@@ -1938,10 +1945,14 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
             // f64 offset codes: 16-byte value loads (the plain stream's measure, profiles/r03_tuning.md §2)
             g2_last = (int)((A->nnz - 1) >> 1);
             tail2 = reinterpret_cast<const V2d *>(reinterpret_cast<const char *>(A->tail) + 16) + (g2_last - 2 * (int)((A->nnz - 1) >> 2));
-            if (D->tile_off.n_tile > 0 && D->owide_desc && c->spmv_tile != 0 && c->spmv_wide != 0 && c->spmv_uniform != 0 && order == nullptr &&
-                count == A->n_rowblk && g % 8 == 0 && !conj_x) {
+            const bool whole = order == nullptr && count == A->n_rowblk;
+            const bool interior = A->dist && A->dist->order_int && order == A->dist->order_int && count == A->dist->n_int && A->dist->tile_int.n_tile > 0;
+            const sprs_tile_plan *tpp = nullptr;
+            if (whole && D->tile_off.n_tile > 0) tpp = &D->tile_off;
+            else if (interior && A->dist->tile_int_off) tpp = &A->dist->tile_int;
+            if (tpp && D->owide_desc && c->spmv_tile != 0 && c->spmv_wide != 0 && c->spmv_uniform != 0 && g % 8 == 0 && !conj_x) {
                 // LDS x-window tiles + the per-block walk over the 64-row blocks outside them, one launch
-                const sprs_tile_plan &TP = D->tile_off;
+                const sprs_tile_plan &TP = *tpp;
                 TilePat tp;
                 for (int t = 0; t < 8; ++t) { tp.off[t] = TP.off[t]; tp.val[t] = 0.0; }
                 const bool ux = dot_mode == 2 && u == x;

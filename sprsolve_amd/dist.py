@@ -194,6 +194,9 @@ def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, t
     code_b = 0 if mode == 0 else 1
     sinfo.update(row_blocks=nb, descriptor_only_blocks=nu,
                  bytes_moved_per_launch=int(nnz_loc * (per_nnz - code_b) + (1.0 - uf) * (nnz_loc * code_b + (n_loc + 1) * 4) + 2 * n_loc * 8))
+    tiles = A.tile_plan()        # the interior launch's LDS-window tiles (csrc/dist.hip), or the whole slab's at one rank
+    if tiles[0] > 0:
+        sinfo.update(kernel_id=3 if mode == 2 else 4, lds_window_tiles=tiles[0], blocks_in_tiles=tiles[1], blocks_walked_singly=tiles[2])
     # evidence that the collectives really span `world` ranks, and what each rank moves per SpMV
     halo_b = int(plan["recv_entries"]) * 8
     send_b = int(plan["send_entries"]) * 8

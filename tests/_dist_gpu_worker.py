@@ -19,10 +19,13 @@ def main(rank, world, port, kind, outdir, exchange="halo"):
     ctx = sa.default_ctx(0)
     if kind.startswith("poisson3d"):
         # "_long": x-lines of 272 rows hold full uniform 128-row blocks (scalar pattern, column triples) on every rank
-        nx, ny, nz = (272, 6, 8) if kind == "poisson3d_long" else (24, 20, 18)
+        nx, ny, nz = (272, 6, 8) if kind == "poisson3d_long" else ((160, 128, 24) if kind.startswith("poisson3d_tiles") else (24, 20, 18))
+        if kind.startswith("poisson3d_tiles"):
+            ctx.set("spmv_tile", 1)      # LDS-window tiles on every rank's slab (12 planes of 20480 rows): interior tiles + boundary blocks
         plane = nx * ny
         starts = partition.slab_starts(nz, plane, world)
-        ip, ix, d, rhs = gen.poisson3d(nx, ny, nz, int(starts[rank] // plane), int(starts[rank + 1] // plane))
+        ip, ix, d, rhs = gen.poisson3d(nx, ny, nz, int(starts[rank] // plane), int(starts[rank + 1] // plane),
+                                       values="random" if kind.endswith("_rand") else "poisson")
         n = nx * ny * nz
         solver_cls, pdiag = sa.BiCGStab, np.full(rhs.size, 6.0)
     else:   # symmetric banded, MINRES, rows split unevenly
@@ -108,7 +111,7 @@ def main(rank, world, port, kind, outdir, exchange="halo"):
              x_fused=res["fused"][2], its_fused=res["fused"][0], res_fused=res["fused"][1], trace_fused=res["fused"][3],
              x_lit=res["literal"][2], its_lit=res["literal"][0], trace_lit=res["literal"][3],
              x_pc=extra[2] if extra else np.zeros(0), its_pc=extra[0] if extra else -1,
-             n_ext=plan["n_ext"], n_loc=n_loc, overlap=int(A.h is not None))
+             n_ext=plan["n_ext"], n_loc=n_loc, overlap=int(A.h is not None), tiles=np.array(A.tile_plan() if hasattr(A, "tile_plan") else (0, 0, 0)))
     tdist.barrier()
     comm.close()
     tdist.destroy_process_group()

@@ -23,6 +23,9 @@ class FakeCsr:
     def wide_blocks(self):
         return self._blk
 
+    def tile_plan(self):
+        return getattr(self, "_tiles", (0, 0, 0))
+
 
 N, NNZ = 50_000_000, 349_100_000          # BASELINE cfg 5
 
@@ -87,3 +90,19 @@ def test_marginal_timing_arithmetic(monkeypatch):
     calls.clear()
     ms, dt, prof, rec = bench.time_marginal(None, None, None, None, None, None, 200, 20, 1)
     assert calls == [(200, 20)] and abs(ms - (0.010 + 0.3) / 200 * 1e3) < 1e-9 and rec["ms_per_step_from"] == "timed_region"
+
+
+def test_tile_plans_name_their_kernel_and_count_no_more_bytes():
+    """A handle with an LDS-window tile plan is timed on spmv_tile_kernel / spmv_tile_off_kernel: the roofline names it; the
+    bytes a launch moves do not grow (a window is read once from HBM however often the CUs reuse it) — for the offset stream
+    they are counted WITHOUT any code or row_ptr bytes, which errs on the low side of the fraction."""
+    pair = FakeCsr(2, 7, 7, 390625, 390048); pair._tiles = (11880, 380160, 10465)
+    s = bench.stream_info(pair, N, NNZ, 8)
+    plain = bench.stream_info(FakeCsr(2, 7, 7, 390625, 390048), N, NNZ, 8)
+    assert s["bytes_moved_per_launch"] == plain["bytes_moved_per_launch"] and s["kernel_id"] == 3 and s["lds_window_tiles"] == 11880
+    assert "spmv_tile_kernel" in bench.roofline_of(s, 213e-6, 201, N, NNZ, 8, 100)["kernel"]
+    off = FakeCsr(1, 7, 0, 781250, 675000); off._tiles = (11880, 380160, 10465)
+    s = bench.stream_info(off, N, NNZ, 8)
+    assert s["bytes_moved_per_launch"] == NNZ * 8 + 2 * N * 8 and s["kernel_id"] == 4
+    assert s["bytes_moved_per_launch"] < bench.stream_info(FakeCsr(1, 7, 0, 781250, 675000), N, NNZ, 8)["bytes_moved_per_launch"]
+    assert "spmv_tile_off_kernel" in bench.roofline_of(s, 740e-6, 201, N, NNZ, 8, 100)["kernel"]

@@ -41,11 +41,13 @@ def _run(world, kind, mock_lib, exchange="halo"):
                                                  (3, "poisson3d", "allgather"), (2, "banded", "allgather"),
                                                  (3, "poisson3d", "halo_c"), (2, "banded", "halo_c"), (3, "banded", "halo_c"),
                                                  (2, "poisson3d", "allgather_c"), (2, "poisson3d_long", "halo"),
-                                                 (3, "poisson3d_long", "halo_c")])
+                                                 (3, "poisson3d_long", "halo_c"), (2, "poisson3d_tiles", "halo"),
+                                                 (2, "poisson3d_tiles_rand", "halo_c")])
 def test_real_ranks_match_single_process(oracle, mock_lib, world, kind, exchange):
     from sprsolve_amd import gen
     if kind.startswith("poisson3d"):
-        ip, ix, d, rhs = gen.poisson3d(*((272, 6, 8) if kind == "poisson3d_long" else (24, 20, 18)))
+        ip, ix, d, rhs = gen.poisson3d(*((272, 6, 8) if kind == "poisson3d_long" else ((160, 128, 24) if kind.startswith("poisson3d_tiles") else (24, 20, 18))),
+                                       values="random" if kind.endswith("_rand") else "poisson")
         ref = oracle.bicgstab(ip, ix, d, rhs, np.zeros(rhs.size), 3000, 1e-10, trace_cap=6)
         refpc = oracle.bicgstab(ip, ix, d, rhs, np.zeros(rhs.size), 3000, 1e-10, precond_diag=np.full(rhs.size, 6.0))
     else:
@@ -55,6 +57,10 @@ def test_real_ranks_match_single_process(oracle, mock_lib, world, kind, exchange
     assert ref.status == oracle.OK
     n = rhs.size
     res = _run(world, kind, mock_lib, exchange)
+    if kind.startswith("poisson3d_tiles"):
+        # every rank's interior launch ran through LDS-window tiles (csrc/dist.hip cuts the interior plan from the handle's)
+        for r in res:
+            assert int(r["tiles"][0]) >= 8, r["tiles"]
     # SpMV through the real halo exchange: bit-identical to the reference fold on the global matrix
     xg = np.linspace(-1.0, 1.0, n) ** 3
     y = np.concatenate([r["y"] for r in res])
@@ -63,7 +69,8 @@ def test_real_ranks_match_single_process(oracle, mock_lib, world, kind, exchange
     for key in ("fused", "lit"):
         its = [int(r["its_" + key]) for r in res]
         assert len(set(its)) == 1, "ranks disagree on the iteration count: %s" % its
-        assert abs(its[0] - ref.its) <= max(3, ref.its // 10), (its, ref.its)
+        # (BiCGStab's count at 1e-10 is reduction-order noise: SURVEY §6; it grows with the problem — half a million rows here)
+        assert abs(its[0] - ref.its) <= max(3, ref.its // (4 if kind.startswith("poisson3d_tiles") else 10)), (its, ref.its)
         x = np.concatenate([r["x_" + key] for r in res])
         assert np.max(np.abs(x - ref.x)) <= 1e-7 * max(1.0, np.max(np.abs(ref.x)))
         tr = res[0]["trace_" + key]
