@@ -788,3 +788,75 @@ def test_lds_window_tiles_with_a_value_per_entry(sa, oracle, name):
                 assert np.max(np.abs(sol - 1.0)) < 1e-8, (jac, its, res)
     finally:
         ctx.set("spmv_tile", -1)
+
+
+def _banded_with_defects(rng, n, offs, vals_per_diag, n_defects):
+    """CSR of the band matrix with diagonals `offs` (sorted), truncated at the matrix ends, with `n_defects` random rows
+    damaged: one entry removed, or the row replaced by a single diagonal entry, or a pair of adjacent rows both damaged."""
+    offs = np.asarray(offs, dtype=np.int64)
+    rows = np.arange(n, dtype=np.int64)
+    cols = rows[:, None] + offs[None, :]
+    ok = (cols >= 0) & (cols < n)
+    vals = np.broadcast_to(np.asarray(vals_per_diag, dtype=np.float64)[None, :], cols.shape).copy()
+    pick = rng.choice(n, size=n_defects, replace=False)
+    for r in pick:
+        kind = rng.integers(0, 3)
+        for rr in ((r, r + 1) if kind == 2 and r + 1 < n else (r,)):
+            have = np.flatnonzero(ok[rr])
+            if have.size < 2:
+                continue
+            if kind == 1:
+                d = int(np.flatnonzero(offs == 0)[0]) if 0 in offs else int(have[0])
+                ok[rr, :] = False; ok[rr, d] = True; vals[rr, d] = 1.0
+            else:
+                ok[rr, rng.choice(have)] = False
+    cnt = ok.sum(axis=1)
+    indptr = np.zeros(n + 1, dtype=np.int64); np.cumsum(cnt, out=indptr[1:])
+    return indptr.astype(np.int32), cols[ok].astype(np.int32), vals[ok]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_lds_window_tiles_randomised_bands(sa, oracle, seed):
+    """Random band patterns of every tile shape the kernels are built for — (3,0,0) (3,1,1) (5,0,0) (5,1,1) (7,0,0) (7,1,1):
+    near diagonals anywhere within +-510, far ones beyond — on 100-300 k rows, with random damaged rows (an entry missing, a
+    row reduced to its diagonal with a value of its own, adjacent pairs of those) that cut the runs of the pattern in random
+    places, in both streams (constant diagonals: pair codes; a value per entry: offset codes).  Tile plan or not, whatever the
+    plan builder made of the runs: y bit-identical to the oracle, with and without the fused dot."""
+    rng = np.random.default_rng(1000 + seed)
+    ctx = sa.default_ctx(0)
+    shapes = [(3, 0, 0), (3, 1, 1), (5, 0, 0), (5, 1, 1), (7, 0, 0), (7, 1, 1)]
+    ul, fl, fh = shapes[seed % 6]
+    n = int(rng.integers(100_000, 300_000))
+    near = sorted(set([0] + [int(v) for v in rng.integers(-510, 511, size=4 * ul)]))
+    nn = ul - fl - fh
+    while len(near) > nn:
+        near.pop(int(rng.integers(0, len(near))))
+    if 0 not in near:
+        near[len(near) // 2] = 0
+    near = sorted(set(near))
+    assert len(near) <= nn
+    far_lo = [-int(rng.integers(2_000, 40_000))] if fl else []
+    far_hi = [int(rng.integers(2_000, 40_000))] if fh else []
+    offs = far_lo + near + far_hi
+    diag_vals = rng.integers(-3, 4, size=len(offs)).astype(np.float64); diag_vals[diag_vals == 0] = 2.0
+    indptr, cols, data = _banded_with_defects(rng, n, offs, diag_vals, n_defects=int(rng.integers(0, 60)))
+    x = rand_vec(n, np.float64, 500 + seed)
+    try:
+        ctx.set("spmv_tile", 1)
+        for stream in ("pair", "offsets"):
+            vals = data if stream == "pair" else data * rng.uniform(0.5, 1.5, data.size)
+            ref = oracle.spmv(indptr, cols, vals, x)
+            A = sa.HipCsr.new((n, n), indptr, cols, vals)
+            assert A.stream_format()[0] == (2 if stream == "pair" else 1), (stream, A.stream_format())
+            y = np.full(n, 7.0); A.mul_vec(x, y)
+            bad = np.flatnonzero(y != ref)
+            assert bad.size == 0, (stream, offs, A.tile_plan(), bad[:6], bad.size)
+            assert np.array_equal(bits(y), bits(ref))
+            y2 = np.full(n, 7.0); d = A.mul_vec_dot(x, y2)
+            assert np.array_equal(bits(y2), bits(ref))
+            e = oracle.conj_dot(x, ref)
+            assert abs(d - e) <= 1e-12 * max(1.0, float(np.sum(np.abs(x * ref))))
+            if len(near) == nn and len(offs) == ul:
+                assert A.tile_plan()[0] >= 8, (stream, offs, A.tile_plan())      # long runs survive ~60 damaged rows in 100 k+
+    finally:
+        ctx.set("spmv_tile", -1)
