@@ -84,9 +84,9 @@ int sprs_version(void);
  *   "spmv_triple"   ... and read columns c - 1, c + 1 of a column triple from column c's loads           (creation)
  *   "spmv_seam"     ... and so are blocks that are uniform but for one row, or two adjacent ones, holding only
  *                   part of the pattern or one entry of their own (line seams of truncated / Dirichlet grids) (creation)
- *   "spmv_tile"     f64 pair codes: runs of 4096 rows of one stencil pattern are multiplied from an x window staged
- *                   in LDS (near columns) + per-row-pair far loads, one launch with the remaining blocks: -1 automatic
- *                   = matrices whose vectors stream from HBM, 1 = every matrix with such runs, 0 = off
+ *   "spmv_tile"     f64 compressed streams: runs of 4096 rows of one stencil pattern are multiplied from an x window
+ *                   staged in LDS (near columns) + per-row-pair far loads, one launch with the remaining blocks:
+ *                   -1 automatic = vectors of 44 MiB and more, 1 = every matrix with such runs, 0 = off
  *                   (sprs_csr_tile_plan reports what a handle got)                       (creation; 0 also at launch)
  *   "spmv_eqrows"   plain CSR: blocks of equal-length rows do not read row_ptr                           (creation)
  *   "spmv_wideload" plain CSR, f64: 16-byte stream loads (4 entries per lane), 3 workgroups per CU on HBM-sized

@@ -57,7 +57,7 @@ struct sprs_ctx {
     int spmv_period = -1;  // XCD-period walk for matrices with a far band (3-D stencils): -1 automatic = the f64 pair-code stream only, 1 = the offset-code stream too, 0 = off.  Read at creation
     int spmv_triple = -1;  // f64 pair codes, uniform blocks: columns c - 1 and c + 1 read from column c's loads; 0 = off.  Read at creation
     int spmv_seam = -1;    // f64 pair codes: blocks that are uniform but for one or two adjacent rows lacking one slot run the uniform path; 0 = off.  Read at creation
-    int spmv_tile = -1;    // f64 pair codes: LDS x-window tiles for the near columns of uniform stencil runs (spmv_tile_kernel): -1 automatic = matrices whose vectors stream from HBM, 1 = every matrix that has such runs, 0 = off.  Read at creation
+    int spmv_tile = -1;    // f64 compressed streams: LDS x-window tiles for the near columns of uniform stencil runs (spmv_tile_kernel, spmv_tile_off_kernel): -1 automatic = vectors of 44 MiB and more (tile_wanted), 1 = every matrix that has such runs, 0 = off.  Read at creation; 0 also at launch
     int ew_chunk = -1;     // fused recurrence kernels walk one contiguous eighth of the vectors per XCD: -1 automatic (fused_chunked), 0 / 1
     int stream_nt = -1;    // fused recurrence kernels access their vectors with non-temporal loads / stores: -1 auto (by vector size), 0 / 1
     int spmv_uniform = -1; // ... and blocks whose rows all repeat one code sequence read neither codes nor row_ptr; read at creation
@@ -296,6 +296,14 @@ inline int grid_for(const sprs_ctx *c) {
 inline bool stream_loads_nt(const sprs_ctx *c, size_t vector_bytes) {
     if (c->stream_nt >= 0) return c->stream_nt != 0;
     return vector_bytes >= (size_t)72 << 20;
+}
+
+// LDS-window tiles of the compressed-stream SpMVs (spmv_dict.hip): knob "spmv_tile" 1 / 0, automatic (-1) from the size of one
+// vector.  Measured cross-over on 500 x 500 x nz slabs (per-block kernel -> tiles, SpMV us in the solve; profiles/r03_tuning.md
+// §9): 16 MB 15.6 -> 31.9, 32 MB 22.1 -> 30.3, 50 MB 36.5 -> 33.6, 100 MB 71.8 -> 64.6, 200 MB 139 -> 110, 400 MB 278 -> 213.
+inline bool tile_wanted(const sprs_ctx *c, size_t vector_bytes) {
+    if (c->spmv_tile >= 0) return c->spmv_tile != 0;
+    return vector_bytes >= (size_t)44 << 20;
 }
 
 // Grid of a grid-stride streaming pass over `work` tiles: no more workgroups than the context's grid, and as few as make

@@ -620,7 +620,15 @@ static inline int base_grid(const sprs_csr *A) {
     // three streams alike (the pair-code kernel runs its stand-alone best at 6 per CU but loses that inside the
     // solve, where it alternates with the BLAS-1 kernels) — except the 16-byte-per-lane plain kernel on an HBM-sized
     // stream: 3 per CU (profiles/r03_tuning.md §2; only multiples of the CU count spread evenly)
-    if (g <= 0) g = A->ctx->num_cu * ((wide_loads(A) && !is_cache_resident(A)) ? 3 : 4);
+    if (g <= 0) {
+        g = A->ctx->num_cu * ((wide_loads(A) && !is_cache_resident(A)) ? 3 : 4);
+        // LDS-window tiles are coarse work items (4096 rows): a matrix with few of them gets fewer workgroups, about three
+        // tiles each, rather than 1024 workgroups with one or two (the N = 8 slab: 1525 tiles; profiles/r03_tuning.md §9)
+        if (tile_plan_used(A)) {
+            const int nt = dict_mode(A) == 2 ? A->dict->tile_pair.n_tile : A->dict->tile_off.n_tile;
+            g = std::min(g, std::max(64, (nt / 3) & ~7));
+        }
+    }
     if (g < 8) g = 8;
     if (g > MAX_GRID / 2) g = MAX_GRID / 2;
     return g & ~7;

@@ -1477,8 +1477,7 @@ static int build_tile_plan(sprs_csr *A, sprs_tile_plan &TP, const BlkDesc *desc_
     sprs_ctx *c = A->ctx;
     const int nw = (int)wd.size();
     const int n_cand = nw / TILE_B;
-    const bool tile_wanted = c->spmv_tile > 0 || (c->spmv_tile < 0 && stream_loads_nt(c, (size_t)A->nrows * sizeof(double)));
-    if (!(tile_wanted && c->spmv_uniform != 0 && c->spmv_wide != 0 && n_cand >= 16 && A->ncols >= TILE_ROWS + 2 * TILE_W)) return SPRS_OK;
+    if (!(tile_wanted(c, (size_t)A->nrows * sizeof(double)) && c->spmv_uniform != 0 && c->spmv_wide != 0 && n_cand >= 16 && A->ncols >= TILE_ROWS + 2 * TILE_W)) return SPRS_OK;
     unsigned long long *pat_d = nullptr; int *len_d = nullptr; uint8_t *flag_d = nullptr;
     auto drop = [&]() { for (void *q : {(void *)pat_d, (void *)len_d, (void *)flag_d}) if (q) (void)hipFree(q); pat_d = nullptr; len_d = nullptr; flag_d = nullptr; };
 #define TILE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { snprintf(c->err, sizeof(c->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); drop(); return SPRS_ERR_HIP; } } while (0)
@@ -1792,8 +1791,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const std::vector
     if constexpr (sizeof(T) == 8 && !is_complex<T>::value) {
         // ---- tiles of the OFFSET-CODE stream (spmv_tile_off_kernel), where that is the stream the handle multiplies with:
         // its own 128-row descriptors (pairs of the 64-row blocks), uniform and seam blocks marked on the offset codes
-        const bool tile_wanted = c->spmv_tile > 0 || (c->spmv_tile < 0 && stream_loads_nt(c, (size_t)A->nrows * sizeof(T)));
-        if (tile_wanted && (D->pair_code == nullptr || c->spmv_dict == 1) && c->spmv_uniform != 0 && c->spmv_wide != 0 && A->n_rowblk >= 2 * TILE_B * 16) {
+        if (tile_wanted(c, (size_t)A->nrows * sizeof(T)) && (D->pair_code == nullptr || c->spmv_dict == 1) && c->spmv_uniform != 0 && c->spmv_wide != 0 && A->n_rowblk >= 2 * TILE_B * 16) {
             const int nb64 = A->n_rowblk, nw = (nb64 + 1) / 2;
             std::vector<BlkDescHost2> owd((size_t)nw);
             for (int j = 0; j < nw; ++j) {
