@@ -71,6 +71,7 @@ pub mod sys {
             col_idx: *const i64, val: *const Complex64, storage_csc: c_int, out: *mut *mut sprs_csr) -> c_int;
         pub fn sprs_csr_destroy(a: *mut sprs_csr) -> c_int;
         pub fn sprs_csr_stream_format(a: *const sprs_csr, n_offsets: *mut c_int, n_pairs: *mut c_int) -> c_int;
+        pub fn sprs_csr_tile_plan(a: *const sprs_csr, n_tiles: *mut i64, n_tile_blocks: *mut i64, n_other_blocks: *mut i64) -> c_int;
 
         pub fn sprs_mul_vec_d(a: *const sprs_csr, x: *const f64, x_len: usize, y: *mut f64, y_len: usize) -> c_int;
         pub fn sprs_mul_vec_z(a: *const sprs_csr, x: *const Complex64, x_len: usize, y: *mut Complex64, y_len: usize) -> c_int;
@@ -380,6 +381,13 @@ impl<T: HipScalar> HipCsr<T> {
         let (mut no, mut np) = (0 as c_int, 0 as c_int);
         let m = unsafe { sys::sprs_csr_stream_format(self.handle, &mut no, &mut np) };
         (m, no, np)
+    }
+    /// LDS-window tiles the SpMV of this handle runs through: (tiles, 128-row blocks in them, 128-row blocks walked singly);
+    /// zeros for handles without a tile plan.  Backend detail (csrc/spmv_dict.hip, ctx knob "spmv_tile").
+    pub fn tile_plan(&self) -> (i64, i64, i64) {
+        let (mut t, mut b, mut o) = (0i64, 0i64, 0i64);
+        ok_or_panic(unsafe { sys::sprs_csr_tile_plan(self.handle, &mut t, &mut b, &mut o) });
+        (t, b, o)
     }
     /// `mul_vec_unchecked` on vectors that live in HBM (nothing crosses PCIe; asynchronous on the context's stream).
     pub fn mul_vec_dev(&self, v_in: &DevVec<T>, v_out: &mut DevVec<T>) {
