@@ -23,6 +23,18 @@
 // coalesced.  Products are added left to right from zero.  Once the stream is this small the kernel is
 // bound by the CU's vector-ALU and vector-memory issue, not by HBM: the loop is written to keep the
 // per-nnz instruction count down (immediate-offset LDS reads, no 64-bit address arithmetic).
+// For HBM-sized stencil-like matrices the LDS x-window TILE kernels take over (one staged window of x per 4096 rows
+// for all near columns): those run at the memory system's rate again.
+//
+// In this file, in order:
+//   dict_collect_kernel / dict_encode_kernel / dict_pair_*      the dictionaries and the code streams (creation)
+//   dict_walk, spmv_dict_kernel                                 64-row blocks, lane per row: offset codes (all types), pair codes (c64 / f32 / c32)
+//   mark_uniform_kernel                                         uniform and seam blocks (creation)
+//   full_uniform_block, pair2_walk, spmv_pair2_kernel           128-row blocks, two rows per lane: f64 pair codes
+//   tile_mark_kernel / tile_flag_kernel                         runs of one pattern (creation)
+//   spmv_tile_kernel, spmv_tile_off_kernel                      LDS x-window tiles: f64 pair codes / f64 offset codes + values
+//   xcd_period_order, build_tile_plan, build_dict_t             schedules, tile plans, the creation driver
+//   launch_spmv_dict                                            which kernel a launch takes
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -1146,7 +1158,10 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(const int2 *__restrict
             for (int k = 0; k < FL; ++k) far[q][k] = *reinterpret_cast<const D2 *>(xr + pat.off[k]);
 #pragma unroll
             for (int k = 0; k < FH; ++k) far[q][FL + k] = *reinterpret_cast<const D2 *>(xr + pat.off[UL - FH + k]);
-            if (DOT == 1 || (DOT == 2 && !UX)) uu[q] = *reinterpret_cast<const D2 *>(u + (ts + ((q * NWAVE + wv) << 7) + 2 * lane));
+            if (DOT == 1 || (DOT == 2 && !UX)) {
+                const u4v w4 = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(u + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
+                __builtin_memcpy(&uu[q], &w4, 16);
+            }
         }
         if (s + sstep < send) {
             const int b1 = __builtin_amdgcn_readfirstlane(ent.x);
@@ -1329,13 +1344,16 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_off_kernel(const int2 *__rest
             for (int k = 0; k < FL; ++k) far[q][k] = *reinterpret_cast<const D2 *>(xr + pat.off[k]);
 #pragma unroll
             for (int k = 0; k < FH; ++k) far[q][FL + k] = *reinterpret_cast<const D2 *>(xr + pat.off[UL - FH + k]);
-            if (DOT == 1 || (DOT == 2 && !UX)) uu[q] = *reinterpret_cast<const D2 *>(u + (ts + ((q * NWAVE + wv) << 7) + 2 * lane));
+            if (DOT == 1 || (DOT == 2 && !UX)) {
+                const u4v w4 = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(u + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
+                __builtin_memcpy(&uu[q], &w4, 16);
+            }
         }
         u4v vreg[NV];
         auto load_vals = [&](int vb) {                  // chunks [vb >> 1, (vb >> 1) + VROW / 2]: the block's values from its 16-byte boundary
             const u4v *v2 = reinterpret_cast<const u4v *>(val) + (vb >> 1);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) vreg[i] = v2[min(lane + i * WAVE, VROW / 2)];
+            for (int i = 0; i < NV; ++i) vreg[i] = __builtin_nontemporal_load(v2 + min(lane + i * WAVE, VROW / 2));      // read once: 720 -> 674 us (profiles/r03_tuning.md §9)
         };
         load_vals(vbc[0]);
         if (s + sstep < send) load_words(__builtin_amdgcn_readfirstlane(ent.x), __builtin_amdgcn_readfirstlane(ent.y));
