@@ -322,10 +322,11 @@ def warm_create():
     ip, ix, d, _ = gen.poisson3d(160, 128, 16)
     n = ip.size - 1
     t0 = time.perf_counter()
+    keep = ctx.get("spmv_tile")                            # (a --set spmv_tile=... of the caller stays in force afterwards)
     for vals in (d, d * (1.0 + 1e-3 * (ix % 7))):         # pair codes, then offset codes + values
         ctx.set("spmv_tile", 1)
         A = sa.HipCsr.new((n, n), ip, ix, vals, ctx=ctx)
-        ctx.set("spmv_tile", -1)
+        ctx.set("spmv_tile", keep)
         del A
     ctx.sync()
     _CREATE_WARM["ms"] = (time.perf_counter() - t0) * 1e3
