@@ -22,8 +22,8 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint8)
 
 
-def make(n):
-    kind = rng.integers(0, 7)
+def make(n, kinds=None):
+    kind = rng.integers(0, 7) if kinds is None else int(rng.choice(kinds))
     nb = int(rng.integers(1, 9))
     offs = np.unique(np.concatenate([[0], rng.integers(-min(n - 1, 40), min(n - 1, 40) + 1, size=nb)]))
     if kind >= 5 and n > 8:         # stencil-like: runs of consecutive columns (column triples), at most 8 per row
@@ -31,6 +31,10 @@ def make(n):
         offs = np.unique(np.concatenate([offs[:int(rng.integers(0, 4))], o0 + np.arange(int(rng.integers(3, 6)))]))[:8]
     if kind == 3 and n > 600:       # far band (period schedule, plane-like)
         offs = np.unique(np.concatenate([offs, [-(n // 5), n // 5]]))
+    if kinds is not None:           # big stencil-like matrices for the LDS-window tiles: at most 8 slots, at most one far band a side
+        near = [int(o) for o in offs if abs(o) <= 40][:6]
+        offs = np.unique(np.array(([-(n // int(rng.integers(4, 9)))] if rng.uniform() < 0.7 else []) + near +
+                                  ([n // int(rng.integers(4, 9))] if rng.uniform() < 0.7 else [])))
     line = int(rng.integers(130, 700)) if kind == 6 else 0
     seam_kind = int(rng.integers(0, 3))
     rows = []
@@ -65,13 +69,20 @@ def make(n):
 
 
 t_end = time.time() + budget
-count = combos = 0
+count = combos = tiled = 0
 while time.time() < t_end:
-    n = int(rng.choice([rng.integers(1, 400), rng.integers(400, 6000), rng.integers(6000, 40000)]))
-    indptr, cols, vals = make(n)
+    big = rng.uniform() < 0.04          # now and then a matrix long enough for tiles (knob spmv_tile), f64
+    if big:
+        n = int(rng.integers(70_000, 160_000))
+        indptr, cols, vals = make(n, kinds=(5, 6))
+        if rng.uniform() < 0.5:
+            vals = vals * rng.uniform(0.5, 1.5, vals.size)           # a value per entry: the offset-code tiles
+    else:
+        n = int(rng.choice([rng.integers(1, 400), rng.integers(400, 6000), rng.integers(6000, 40000)]))
+        indptr, cols, vals = make(n)
     if indptr[-1] == 0:
         continue
-    dtype = DT[int(rng.integers(0, 4))]
+    dtype = np.float64 if big else DT[int(rng.integers(0, 4))]
     d = vals.astype(dtype)
     if np.dtype(dtype).kind == "c":
         d = d * (1 + 0.25j)
@@ -79,11 +90,15 @@ while time.time() < t_end:
     if np.dtype(dtype).kind == "c":
         x = x + 1j * rng.uniform(-1, 1, n).astype(x.real.dtype)
     ref = oracle.spmv(indptr, cols, d, x)
-    for knob, wide, uni, eq, period, tri, seam, wl in itertools.product((0, 1, 2), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1)):
-        if (knob != 2 and (wide or period)) or (knob == 0 and uni) or (knob != 0 and eq == 0) or (not tri and not wide) or (not seam and not (wide and uni)) or (knob != 0 and wl == 0):
+    grid = (itertools.product((1, 2), (1,), (1,), (1,), (0, 1), (1,), (0, 1), (1,), (0, 1)) if big else
+            itertools.product((0, 1, 2), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1), (-1,)))
+    for knob, wide, uni, eq, period, tri, seam, wl, tile in grid:
+        if (knob != 2 and (wide or period)) and not big:
+            continue
+        if (knob == 0 and uni) or (knob != 0 and eq == 0) or (not tri and not wide) or (not seam and not (wide and uni)) or (knob != 0 and wl == 0):
             continue
         for k, v in (("spmv_dict", knob), ("spmv_wide", wide), ("spmv_uniform", uni), ("spmv_eqrows", eq), ("spmv_period", period),
-                     ("spmv_triple", tri), ("spmv_seam", seam), ("spmv_wideload", wl)):
+                     ("spmv_triple", tri), ("spmv_seam", seam), ("spmv_wideload", wl), ("spmv_tile", tile)):
             ctx.set(k, v)
         A = sa.HipCsr.new((n, n), indptr, cols, d)
         y = np.full(n, 7.0, dtype=dtype)
@@ -91,9 +106,10 @@ while time.time() < t_end:
         y2 = np.zeros(n, dtype=dtype)
         A.mul_vec_dot(x, y2)
         combos += 1
+        tiled += A.tile_plan()[0] > 0
         if not (np.array_equal(bits(y), bits(ref)) and np.array_equal(bits(y2), bits(ref))):
-            print("MISMATCH n=%d dtype=%s knobs dict=%d wide=%d uniform=%d eqrows=%d period=%d triple=%d seam=%d wideload=%d stream=%s bad=%d" % (
-                n, np.dtype(dtype).name, knob, wide, uni, eq, period, tri, seam, wl, A.stream_format(), int(np.sum(bits(y) != bits(ref)))))
+            print("MISMATCH n=%d dtype=%s knobs dict=%d wide=%d uniform=%d eqrows=%d period=%d triple=%d seam=%d wideload=%d tile=%d stream=%s plan=%s bad=%d" % (
+                n, np.dtype(dtype).name, knob, wide, uni, eq, period, tri, seam, wl, tile, A.stream_format(), A.tile_plan(), int(np.sum(bits(y) != bits(ref)))))
             np.savez("gpurun_out/fuzz_fail.npz", indptr=indptr, cols=cols, d=d, x=x)
             sys.exit(1)
     count += 1
@@ -102,4 +118,5 @@ for k in ("spmv_dict", "spmv_wide", "spmv_uniform", "spmv_eqrows", "spmv_wideloa
 ctx.set("spmv_period", -1)
 ctx.set("spmv_triple", -1)
 ctx.set("spmv_seam", -1)
-print("fuzz ok: %d matrices, %d (matrix, knob) combinations, all y bit-identical to the reference fold" % (count, combos))
+ctx.set("spmv_tile", -1)
+print("fuzz ok: %d matrices, %d (matrix, knob) combinations (%d of them through LDS-window tiles), all y bit-identical to the reference fold" % (count, combos, tiled))
