@@ -860,3 +860,38 @@ def test_lds_window_tiles_randomised_bands(sa, oracle, seed):
                 assert A.tile_plan()[0] >= 8, (stream, offs, A.tile_plan())      # long runs survive ~60 damaged rows in 100 k+
     finally:
         ctx.set("spmv_tile", -1)
+
+
+@pytest.mark.parametrize("stream", ["pair", "offsets"])
+def test_lds_window_tiles_unaligned_device_vectors(sa, oracle, stream):
+    """x, y (and the dot operand) as device views that start 8 bytes into an allocation: the tile kernels' 16-byte window / far /
+    operand loads and y stores then sit on 8-byte boundaries only.  Same bits."""
+    import torch
+    from sprsolve_amd import gen
+    ctx = sa.default_ctx(0)
+    ip, ix, d, _ = gen.poisson3d(160, 128, 12)
+    n = ip.size - 1
+    if stream == "offsets":
+        d = d * np.random.default_rng(5).uniform(0.5, 1.5, d.size)
+    xh = rand_vec(n, np.float64, 91)
+    ref = oracle.spmv(ip, ix, d, xh)
+    dev = torch.device("cuda", 0)
+    try:
+        ctx.set("spmv_tile", 1)
+        A = sa.HipCsr.new((n, n), ip, ix, d)
+        assert A.tile_plan()[0] >= 8 and A.stream_format()[0] == (2 if stream == "pair" else 1)
+        for off in (1, 3):
+            bx = torch.zeros(n + 8, dtype=torch.float64, device=dev); by = torch.full((n + 8,), 5.0, dtype=torch.float64, device=dev)
+            x = bx[off:off + n]; y = by[off:off + n]
+            x.copy_(torch.from_numpy(xh))
+            assert x.data_ptr() % 16 == 8
+            A.mul_vec_unchecked(x, y)
+            assert np.array_equal(bits(y.cpu().numpy()), bits(ref)), off
+            assert float(by[off - 1]) == 5.0 and float(by[off + n]) == 5.0          # nothing written outside the view
+            y.fill_(0.0)
+            dd = A.mul_vec_dot_unchecked(x, y)
+            assert np.array_equal(bits(y.cpu().numpy()), bits(ref))
+            e = oracle.conj_dot(xh, ref)
+            assert abs(dd - e) <= 1e-12 * max(1.0, float(np.sum(np.abs(xh * ref))))
+    finally:
+        ctx.set("spmv_tile", -1)
