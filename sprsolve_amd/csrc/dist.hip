@@ -315,7 +315,7 @@ int dist_csr_create(sprs_comm *comm, int64_t n_local, int64_t n_ext, int64_t nnz
                                (left.empty() || hipMemcpy(TI.left, left.data(), sizeof(int32_t) * left.size(), hipMemcpyHostToDevice) == hipSuccess);
                     if (!okt) { sprs_csr_destroy(A); return SPRS_ERR_HIP; }
                     TI.n_tile = (int)(list.size() / 2); TI.n_left = (int)left.size();
-                    TI.ul = TP.ul; TI.fl = TP.fl; TI.fh = TP.fh;
+                    TI.ul = TP.ul; TI.fl = TP.fl; TI.fh = TP.fh; TI.w = TP.w;
                     for (int t = 0; t < 8; ++t) { TI.off[t] = TP.off[t]; TI.val[t] = TP.val[t]; }
                     D->tile_int_off = off_stream;
                 }

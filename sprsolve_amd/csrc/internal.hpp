@@ -138,6 +138,7 @@ struct sprs_tile_plan {
     int32_t *left = nullptr;       // device: the other blocks, in the walk order they had (128-row blocks: pair stream; 64-row blocks: offset stream)
     int n_tile = 0, n_left = 0;
     int ul = 0, fl = 0, fh = 0;    // pattern shape: slots, leading far slots, trailing far slots
+    int w = 0;                     // half-width of the x window (512, or 1536 for the pair stream's long-line grids)
     int32_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double val[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // pair stream: the pattern's values
     std::vector<int32_t> h_list, h_xstart;         // host copies of list / xstart (the distributed operator cuts its interior plan from them)

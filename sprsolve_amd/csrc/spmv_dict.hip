@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
 // phase within the far period (tile_plan below) so that a far window was some tile's near window on the same L2.  The
 // 128-row blocks outside the tiles (boundary planes, the tiles a boundary line cuts, the matrix ends) are walked by the
 // same launch afterwards (pair2_walk), so the launch writes all of y and one partial per workgroup.
-constexpr int TILE_ROWS = 4096, TILE_W = 512, TILE_B = TILE_ROWS / (2 * WAVE);
+constexpr int TILE_ROWS = 4096, TILE_W = 512, TILE_W_WIDE = 1536, TILE_B = TILE_ROWS / (2 * WAVE);
 struct TilePat { int32_t off[8]; double val[8]; };
 
 // one thread per candidate tile (blocks [t TILE_B, (t + 1) TILE_B)): its pattern (up to 8 codes, low byte first) and
@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(BLOCK) void tile_flag_kernel(int n_wide, const BlkD
 }
 
 // UX: the dot operand of DOT == 2 is the input vector itself (K4 without a preconditioner): taken from the window
-template <int DOT, bool UX, int UL, int FL, int FH>
+template <int DOT, bool UX, int UL, int FL, int FH, int W>
 __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(const int2 *__restrict__ tile_list, const int32_t *__restrict__ xstart,
                                                           const BlkDesc *__restrict__ desc, const TilePat pat,
                                                           int n_left, const int32_t *__restrict__ left_order,
@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(const int2 *__restrict
                                                           double *__restrict__ part0, double *__restrict__ part1,
                                                           const int *__restrict__ status, int nrows, int ncols, const Fin fin) {
     using T = double;
-    constexpr int TR = TILE_ROWS, W = TILE_W;
+    constexpr int TR = TILE_ROWS;                       // W: half-width of the window (TILE_W, or TILE_W_WIDE for line bands up to 1534)
     constexpr int NW = (TR + 2 * W) / 2 / BLOCK;        // 16-byte window pieces per lane
     constexpr int NQ = TILE_B / NWAVE;                  // 128-row blocks per wavefront and tile
     constexpr int NN = UL - FL - FH;                    // near slots
@@ -1474,9 +1474,12 @@ static std::vector<int32_t> xcd_period_order(int nblk, int64_t G, FirstRow first
 // (UL, FL, FH) shapes spmv_tile_kernel is built for: 7-point 3-D, 5-point 2-D with a far or a near line band, 3-point 1-D, and
 // bands with two far diagonals
 #define SPRS_TILE_SHAPES(X) X(7, 1, 1) X(5, 1, 1) X(5, 0, 0) X(3, 0, 0) X(3, 1, 1) X(7, 0, 0)
-static bool tile_shape_built(int ul, int fl, int fh) {
+// ... and with the wide window (pair-code stream only; grids whose lines are 511 to 1534 long)
+#define SPRS_TILE_SHAPES_WIDE(X) X(7, 1, 1) X(5, 1, 1) X(5, 0, 0) X(7, 0, 0)
+static bool tile_shape_built(int ul, int fl, int fh, int w) {
 #define SPRS_TILE_HAS(U, L, H) if (ul == U && fl == L && fh == H) return true;
-    SPRS_TILE_SHAPES(SPRS_TILE_HAS)
+    if (w == TILE_W) { SPRS_TILE_SHAPES(SPRS_TILE_HAS) }
+    if (w == TILE_W_WIDE) { SPRS_TILE_SHAPES_WIDE(SPRS_TILE_HAS) }
 #undef SPRS_TILE_HAS
     return false;
 }
@@ -1491,7 +1494,7 @@ template <> struct has_val_dict<float> { static constexpr bool value = true; };
 // make_left(in_tile, left) lists the blocks the tiles do not cover, in the walk order of the stream's per-block kernel.
 template <class MakeLeft>
 static int build_tile_plan(sprs_csr *A, sprs_tile_plan &TP, const BlkDesc *desc_dev, const uint8_t *code_dev, const std::vector<BlkDescHost2> &wd,
-                           const int32_t *off_tab, const double *val_tab, MakeLeft &&make_left) {
+                           const int32_t *off_tab, const double *val_tab, bool wide_window_ok, MakeLeft &&make_left) {
     sprs_ctx *c = A->ctx;
     const int nw = (int)wd.size();
     const int n_cand = nw / TILE_B;
@@ -1515,10 +1518,10 @@ static int build_tile_plan(sprs_csr *A, sprs_tile_plan &TP, const BlkDesc *desc_
     int best = 0;
     for (const auto &kv : hist) if (kv.second > best) { best = kv.second; canon = kv.first; }
     const int UL = canon.second;
-    int FL = 0, FH = 0;
-    bool shape_ok = best >= 8 && UL >= 1;
+    int FL = 0, FH = 0, WIN = 0;
+    bool shape_ok = false;
     int64_t far_band = 0;
-    if (shape_ok) {
+    if (best >= 8 && UL >= 1) {
         int32_t o[8];
         for (int t = 0; t < UL; ++t) {
             const int cd = (int)((canon.first >> (8 * t)) & 255u);
@@ -1526,15 +1529,24 @@ static int build_tile_plan(sprs_csr *A, sprs_tile_plan &TP, const BlkDesc *desc_
             TP.off[t] = o[t];
             TP.val[t] = val_tab ? val_tab[cd] : 0.0;
         }
-        const int NEAR = TILE_W - 2;
-        while (FL < UL && o[FL] < -NEAR) ++FL;
-        while (FH < UL - FL && o[UL - 1 - FH] > NEAR) ++FH;
-        for (int t = FL; t < UL - FH; ++t) shape_ok = shape_ok && o[t] >= -NEAR && o[t] <= NEAR;
-        shape_ok = shape_ok && UL - FL - FH >= 1 && tile_shape_built(UL, FL, FH);
+        // the window for which the pattern is far* near+ far* with a shape the kernels are built for and the fewest loads per
+        // 128 rows: (T + 2w) / T window loads + one per far slot (a 2-D grid of 1500-row lines: 1.25 + 2 narrow, 1.75 + 0 wide)
+        double best_cost = 1e9;
+        for (int w : {TILE_W, TILE_W_WIDE}) {
+            if (w == TILE_W_WIDE && !wide_window_ok) continue;
+            const int NEAR = w - 2;
+            int fl = 0, fh = 0;
+            while (fl < UL && o[fl] < -NEAR) ++fl;
+            while (fh < UL - fl && o[UL - 1 - fh] > NEAR) ++fh;
+            bool ok = UL - fl - fh >= 1 && tile_shape_built(UL, fl, fh, w);
+            for (int t = fl; t < UL - fh; ++t) ok = ok && o[t] >= -NEAR && o[t] <= NEAR;
+            const double cost = (double)(TILE_ROWS + 2 * w) / TILE_ROWS + fl + fh;
+            if (ok && cost < best_cost) { shape_ok = true; best_cost = cost; FL = fl; FH = fh; WIN = w; }
+        }
         for (int t = 0; t < FL; ++t) far_band = std::max<int64_t>(far_band, std::llabs((long long)o[t]));
         for (int t = UL - FH; t < UL; ++t) far_band = std::max<int64_t>(far_band, std::llabs((long long)o[t]));
     }
-    if (!shape_ok) { drop(); return SPRS_OK; }
+    if (!shape_ok || A->ncols < TILE_ROWS + 2 * WIN) { drop(); return SPRS_OK; }
     // tiles are placed greedily on the runs of consecutive blocks of that pattern (a run ends where a boundary line or plane
     // changes the pattern; tiles on a fixed lattice would lose a whole tile per break)
     TILE_TRY(hipMalloc((void **)&flag_d, (size_t)nw));
@@ -1552,9 +1564,9 @@ static int build_tile_plan(sprs_csr *A, sprs_tile_plan &TP, const BlkDesc *desc_
         int e = j + 1;
         while (e < nw && flag[(size_t)e] && wd[(size_t)e].ra == wd[(size_t)e - 1].ra + 2 * WAVE) ++e;
         int b = j;
-        while (b < e && (int64_t)wd[(size_t)b].ra - TILE_W < 0) ++b;                 // the window starts inside x
+        while (b < e && (int64_t)wd[(size_t)b].ra - WIN < 0) ++b;                    // the window starts inside x
         for (; b + TILE_B <= e; b += TILE_B) {
-            if ((int64_t)wd[(size_t)b].ra + TILE_ROWS + TILE_W > A->ncols) break;     // ... and ends inside it
+            if ((int64_t)wd[(size_t)b].ra + TILE_ROWS + WIN > A->ncols) break;        // ... and ends inside it
             starts.push_back(b);
             for (int q = 0; q < TILE_B; ++q) in_tile[(size_t)(b + q)] = 1;
         }
@@ -1591,7 +1603,7 @@ static int build_tile_plan(sprs_csr *A, sprs_tile_plan &TP, const BlkDesc *desc_
     if (!left.empty()) TILE_TRY(hipMemcpyAsync(TP.left, left.data(), sizeof(int32_t) * left.size(), hipMemcpyHostToDevice, c->stream));
     TILE_TRY(hipStreamSynchronize(c->stream));
     TP.n_tile = n_elig; TP.n_left = (int)left.size();
-    TP.ul = UL; TP.fl = FL; TP.fh = FH;
+    TP.ul = UL; TP.fl = FL; TP.fh = FH; TP.w = WIN;
     TP.h_list = list; TP.h_xstart = xstart;
     drop();
 #undef TILE_TRY
@@ -1795,7 +1807,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const std::vector
                 {
                     std::vector<int32_t> left_order;
                     if (const int st = build_tile_plan(A, D->tile_pair, reinterpret_cast<const BlkDesc *>(D->wide_desc), (const uint8_t *)D->pair_code, wd,
-                                                       pair_off.data(), reinterpret_cast<const double *>(pair_val.data()), [&](std::vector<char> &in_tile, std::vector<int32_t> &left) {
+                                                       pair_off.data(), reinterpret_cast<const double *>(pair_val.data()), true, [&](std::vector<char> &in_tile, std::vector<int32_t> &left) {
                             for (int pos = 0; pos < nw; ++pos) {
                                 const int j = ord.empty() ? pos : ord[(size_t)pos];
                                 if (!in_tile[(size_t)j]) left.push_back(j);
@@ -1825,7 +1837,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const std::vector
             DICT_TRY2(hipStreamSynchronize(c->stream));
             D->n_owide = nw;
             if (const int st = build_tile_plan(A, D->tile_off, reinterpret_cast<const BlkDesc *>(D->owide_desc), (const uint8_t *)D->idx_code, owd,
-                                               off_tab.data(), (const double *)nullptr, [&](std::vector<char> &in_tile, std::vector<int32_t> &left) {
+                                               off_tab.data(), (const double *)nullptr, false, [&](std::vector<char> &in_tile, std::vector<int32_t> &left) {
                     for (int j = 0; j < nw; ++j) {          // the per-block kernel's 64-row blocks, natural order
                         if (in_tile[(size_t)j]) continue;
                         left.push_back(2 * j);
@@ -1920,14 +1932,19 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
             const sprs_tile_plan &TP = *tpp;
             for (int t = 0; t < 8; ++t) { tp.off[t] = TP.off[t]; tp.val[t] = TP.val[t]; }
             const bool ux = dot_mode == 2 && u == x;
-#define SPRS_TSPMV(DM, UXV, U, L, H) SPRS_LAUNCH_SPMV(c, (spmv_tile_kernel<DM, UXV, U, L, H>), g, reinterpret_cast<const int2 *>(TP.list), TP.xstart, wd, tp, TP.n_left, \
+#define SPRS_TSPMV(DM, UXV, U, L, H) SPRS_LAUNCH_SPMV(c, (spmv_tile_kernel<DM, UXV, U, L, H, SPRS_TW>), g, reinterpret_cast<const int2 *>(TP.list), TP.xstart, wd, tp, TP.n_left, \
                                                       TP.left, A->row_ptr, D->pair_code, D->pair_off, pvd, x, y, u, part0, part1, status, (int)A->nrows, (int)A->ncols, fin)
 #define SPRS_TSHAPE(U, L, H)                                                                                             \
             if (TP.ul == U && TP.fl == L && TP.fh == H) {                                                 \
                 if (dot_mode == 0) SPRS_TSPMV(0, false, U, L, H); else if (dot_mode == 1) SPRS_TSPMV(1, false, U, L, H);   \
                 else if (ux) SPRS_TSPMV(2, true, U, L, H); else SPRS_TSPMV(2, false, U, L, H);                           \
             }
-            SPRS_TILE_SHAPES(SPRS_TSHAPE)
+#define SPRS_TW TILE_W
+            if (TP.w == TILE_W) { SPRS_TILE_SHAPES(SPRS_TSHAPE) }
+#undef SPRS_TW
+#define SPRS_TW TILE_W_WIDE
+            if (TP.w == TILE_W_WIDE) { SPRS_TILE_SHAPES_WIDE(SPRS_TSHAPE) }
+#undef SPRS_TW
 #undef SPRS_TSHAPE
 #undef SPRS_TSPMV
             SPRS_HIP_TRY(c, hipGetLastError());

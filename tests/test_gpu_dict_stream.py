@@ -711,8 +711,8 @@ def test_lds_window_tiles_policy_and_fallbacks(sa, oracle):
     assert A.tile_plan() == (0, 0, 0)                                      # automatic: 2 MB vectors
     try:
         ctx.set("spmv_tile", 1)
-        # two far bands on each side (nx = 600 > window): shape (7, 2, 2) is not built
-        ip2, ix2, d2, _ = gen.poisson3d(600, 20, 20)
+        # two far bands on each side (nx = 1600 > the wide window too): shape (7, 2, 2) is not built
+        ip2, ix2, d2, _ = gen.poisson3d(1600, 20, 20)
         n2 = ip2.size - 1
         A2 = sa.HipCsr.new((n2, n2), ip2, ix2, d2)
         assert A2.stream_format()[0] == 2 and A2.tile_plan() == (0, 0, 0)
@@ -893,5 +893,38 @@ def test_lds_window_tiles_unaligned_device_vectors(sa, oracle, stream):
             assert np.array_equal(bits(y.cpu().numpy()), bits(ref))
             e = oracle.conj_dot(xh, ref)
             assert abs(dd - e) <= 1e-12 * max(1.0, float(np.sum(np.abs(xh * ref))))
+    finally:
+        ctx.set("spmv_tile", -1)
+
+
+@pytest.mark.parametrize("name", ["p3_800x64x8", "p2_dirichlet_1500"])
+def test_lds_window_tiles_wide_window(sa, oracle, name):
+    """Grids whose lines are 511 to 1534 rows long: the pair-code tile kernel takes a window of half-width 1536 (the +-nx columns
+    are near again: one staged window instead of a far load per row pair each); the offset-code stream keeps the per-block
+    kernel there.  y bit-identical either way."""
+    from sprsolve_amd import gen
+    ctx = sa.default_ctx(0)
+    if name == "p3_800x64x8":
+        indptr, cols, data, _ = gen.poisson3d(800, 64, 8)
+    else:
+        indptr, cols, data = gen.grid_laplacian_dirichlet(1500, 1500)
+    n = indptr.size - 1
+    x = rand_vec(n, np.float64, 123)
+    try:
+        ctx.set("spmv_tile", 1)
+        for stream in ("pair", "offsets"):
+            vals = data if stream == "pair" else data * np.random.default_rng(3).uniform(0.5, 1.5, data.size)
+            ref = oracle.spmv(indptr, cols, vals, x)
+            A = sa.HipCsr.new((n, n), indptr, cols, vals)
+            assert A.stream_format()[0] == (2 if stream == "pair" else 1)
+            nt = A.tile_plan()[0]
+            # (offset codes: window 512 only — the 3-D grid's +-800 would be two far bands a side, not built; the 2-D grid's +-1500 are its one far band)
+            assert (nt >= 8) if (stream == "pair" or name == "p2_dirichlet_1500") else (nt == 0), (stream, A.tile_plan())
+            y = np.full(n, 3.0); A.mul_vec(x, y)
+            assert np.array_equal(bits(y), bits(ref)), stream
+            y2 = np.zeros(n); d = A.mul_vec_dot(x, y2)
+            assert np.array_equal(bits(y2), bits(ref))
+            e = oracle.conj_dot(x, ref)
+            assert abs(d - e) <= 1e-12 * max(1.0, float(np.sum(np.abs(x * ref))))
     finally:
         ctx.set("spmv_tile", -1)
