@@ -260,7 +260,7 @@ __global__ __launch_bounds__(BLOCK) void k_winv(long r_begin, long r_end, int nx
 int main(int argc, char **argv) {
     const std::string filt = argc > 1 ? argv[1] : "";
     const int reps = argc > 2 ? atoi(argv[2]) : 20;
-    const int nx = 500, ny = 500, nz = 200;
+    const int nx = 500, ny = 500, nz = argc > 3 ? atoi(argv[3]) : 200;      // (nz = 25: the per-rank slab of N = 8)
     const long P = (long)nx * ny, n = P * nz;
     const long LCM = 8192;                                   // every variant's tile divides the timed range
     const long r_begin = P, r_end = r_begin + (n - 2 * P) / LCM * LCM;
@@ -313,7 +313,7 @@ int main(int argc, char **argv) {
     };
     int *o1024, *x1024, *o2048, *x2048, *o4096, *x4096;
     make_order(1024, &o1024, &x1024); make_order(2048, &o2048, &x2048); make_order(4096, &o4096, &x4096);
-    for (int grid : {512, 768, 1024, 1536}) {
+    for (int grid : {256, 512, 768, 1024, 1536, 2048}) {
         const std::string g = "/" + std::to_string(grid);
         run("gl5/dot0" + g, 0, [&] { k_gl5<0><<<grid, BLOCK>>>(r_begin, r_end, nx, P, c, x, y, u, part); });
         run("gl5/dot1" + g, 1, [&] { k_gl5<1><<<grid, BLOCK>>>(r_begin, r_end, nx, P, c, x, y, u, part); });
