@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(BLOCK) void tile_flag_kernel(int n_wide, const BlkD
     flag[j] = ok ? 1 : 0;
 }
 
-// UX: the dot operand of DOT == 2 is the input vector itself (K4 without a preconditioner): taken from the window
+// UX: the dot operand is the input vector itself (mul_vec_dot, MINRES' v.Av, K4 without a preconditioner): taken from the window
 template <int DOT, bool UX, int UL, int FL, int FH, int W>
 __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(const int2 *__restrict__ tile_list, const int32_t *__restrict__ xstart,
                                                           const BlkDesc *__restrict__ desc, const TilePat pat,
@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(const int2 *__restrict
             for (int k = 0; k < FL; ++k) far[q][k] = *reinterpret_cast<const D2 *>(xr + pat.off[k]);
 #pragma unroll
             for (int k = 0; k < FH; ++k) far[q][FL + k] = *reinterpret_cast<const D2 *>(xr + pat.off[UL - FH + k]);
-            if (DOT == 1 || (DOT == 2 && !UX)) {
+            if (DOT != 0 && !UX) {
                 const u4v w4 = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(u + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
                 __builtin_memcpy(&uu[q], &w4, 16);
             }
@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(const int2 *__restrict
                 else { pl[t] = npl[t - FL]; ph[t] = nph[t - FL]; }
             }
             T ux0 = 0.0, ux1 = 0.0;
-            if (DOT == 2 && UX) { ux0 = win[li]; ux1 = win[li + 1]; }
+            if (DOT != 0 && UX) { ux0 = win[li]; ux1 = win[li + 1]; }
             if (q + 1 < NQ) read_near(q + 1);
             T acc0 = 0.0, acc1 = 0.0;
             if (!seam) {
@@ -1242,7 +1242,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(const int2 *__restrict
             u4v qv;
             __builtin_memcpy(&qv, &yy, 16);
             __builtin_nontemporal_store(qv, reinterpret_cast<u4v *>(y + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
-            if (DOT == 1) { d0 = d0 + uu[q].lo * acc0; d0 = d0 + uu[q].hi * acc1; }
+            if (DOT == 1) { d0 = d0 + (UX ? ux0 : uu[q].lo) * acc0; d0 = d0 + (UX ? ux1 : uu[q].hi) * acc1; }
             if (DOT == 2) {
                 const T u0 = UX ? ux0 : uu[q].lo, u1 = UX ? ux1 : uu[q].hi;
                 d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * u0; d0 = d0 + acc1 * acc1; d1 = d1 + acc1 * u1;
@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_off_kernel(const int2 *__rest
             for (int k = 0; k < FL; ++k) far[q][k] = *reinterpret_cast<const D2 *>(xr + pat.off[k]);
 #pragma unroll
             for (int k = 0; k < FH; ++k) far[q][FL + k] = *reinterpret_cast<const D2 *>(xr + pat.off[UL - FH + k]);
-            if (DOT == 1 || (DOT == 2 && !UX)) {
+            if (DOT != 0 && !UX) {
                 const u4v w4 = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(u + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
                 __builtin_memcpy(&uu[q], &w4, 16);
             }
@@ -1387,7 +1387,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_off_kernel(const int2 *__rest
                 else { pl[t] = npl[t - FL]; ph[t] = nph[t - FL]; }
             }
             T ux0 = 0.0, ux1 = 0.0;
-            if (DOT == 2 && UX) { ux0 = win[li]; ux1 = win[li + 1]; }
+            if (DOT != 0 && UX) { ux0 = win[li]; ux1 = win[li + 1]; }
             if (q + 1 < NQ) read_near(q + 1);
             T acc0 = 0.0, acc1 = 0.0;
             if (!seam) {
@@ -1419,7 +1419,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_off_kernel(const int2 *__rest
             u4v qv;
             __builtin_memcpy(&qv, &yy, 16);
             __builtin_nontemporal_store(qv, reinterpret_cast<u4v *>(y + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
-            if (DOT == 1) { d0 = d0 + uu[q].lo * acc0; d0 = d0 + uu[q].hi * acc1; }
+            if (DOT == 1) { d0 = d0 + (UX ? ux0 : uu[q].lo) * acc0; d0 = d0 + (UX ? ux1 : uu[q].hi) * acc1; }
             if (DOT == 2) {
                 const T u0 = UX ? ux0 : uu[q].lo, u1 = UX ? ux1 : uu[q].hi;
                 d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * u0; d0 = d0 + acc1 * acc1; d1 = d1 + acc1 * u1;
@@ -1931,12 +1931,13 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
             TilePat tp;
             const sprs_tile_plan &TP = *tpp;
             for (int t = 0; t < 8; ++t) { tp.off[t] = TP.off[t]; tp.val[t] = TP.val[t]; }
-            const bool ux = dot_mode == 2 && u == x;
+            const bool ux = dot_mode != 0 && u == x;      // the dot operand is the input vector (mul_vec_dot, MINRES' v.Av, K4 without a preconditioner)
 #define SPRS_TSPMV(DM, UXV, U, L, H) SPRS_LAUNCH_SPMV(c, (spmv_tile_kernel<DM, UXV, U, L, H, SPRS_TW>), g, reinterpret_cast<const int2 *>(TP.list), TP.xstart, wd, tp, TP.n_left, \
                                                       TP.left, A->row_ptr, D->pair_code, D->pair_off, pvd, x, y, u, part0, part1, status, (int)A->nrows, (int)A->ncols, fin)
 #define SPRS_TSHAPE(U, L, H)                                                                                             \
             if (TP.ul == U && TP.fl == L && TP.fh == H) {                                                 \
-                if (dot_mode == 0) SPRS_TSPMV(0, false, U, L, H); else if (dot_mode == 1) SPRS_TSPMV(1, false, U, L, H);   \
+                if (dot_mode == 0) SPRS_TSPMV(0, false, U, L, H);                                                        \
+                else if (dot_mode == 1) { if (ux) SPRS_TSPMV(1, true, U, L, H); else SPRS_TSPMV(1, false, U, L, H); }    \
                 else if (ux) SPRS_TSPMV(2, true, U, L, H); else SPRS_TSPMV(2, false, U, L, H);                           \
             }
 #define SPRS_TW TILE_W
@@ -1988,13 +1989,14 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
                 const sprs_tile_plan &TP = *tpp;
                 TilePat tp;
                 for (int t = 0; t < 8; ++t) { tp.off[t] = TP.off[t]; tp.val[t] = 0.0; }
-                const bool ux = dot_mode == 2 && u == x;
+                const bool ux = dot_mode != 0 && u == x;      // the dot operand is the input vector (mul_vec_dot, MINRES' v.Av, K4 without a preconditioner)
                 const BlkDesc *owd = reinterpret_cast<const BlkDesc *>(D->owide_desc);
 #define SPRS_TOSPMV(DM, UXV, U, L, H) SPRS_LAUNCH_SPMV(c, (spmv_tile_off_kernel<DM, UXV, U, L, H>), g, reinterpret_cast<const int2 *>(TP.list), TP.xstart, owd, tp, \
                                                        TP.n_left, TP.left, dsc, A->row_ptr, code, otab, v, x, y, u, part0, part1, status, fin, tail2, g2_last)
 #define SPRS_TOSHAPE(U, L, H)                                                                                            \
                 if (TP.ul == U && TP.fl == L && TP.fh == H) {                                                            \
-                    if (dot_mode == 0) SPRS_TOSPMV(0, false, U, L, H); else if (dot_mode == 1) SPRS_TOSPMV(1, false, U, L, H); \
+                    if (dot_mode == 0) SPRS_TOSPMV(0, false, U, L, H);                                                   \
+                    else if (dot_mode == 1) { if (ux) SPRS_TOSPMV(1, true, U, L, H); else SPRS_TOSPMV(1, false, U, L, H); } \
                     else if (ux) SPRS_TOSPMV(2, true, U, L, H); else SPRS_TOSPMV(2, false, U, L, H);                     \
                 }
                 SPRS_TILE_SHAPES(SPRS_TOSHAPE)
