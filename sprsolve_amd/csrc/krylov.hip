@@ -279,6 +279,12 @@ struct MinresM3 {
     MinresDev<T> *D; int par; long long its; const Real<T> *partBeta; const T *partBeta2; int P;
     T *v_new; T *w_new; const T *q; const T *p_old; const T *p_oold; T *p; T *x;
     Real<T> inv, r1_inv, beta_new, s_new; T nr2, nr3, coef, c_new;
+    // This launch's own epilogue sets the status to "converged at `its`" when workgroup 0 is done — possibly before another
+    // workgroup of the SAME launch has read the status word.  That workgroup must still do its share of this iteration (the
+    // reference updates x, then tests: minres.rs:162-167), so the event carries its iteration and this launch does not
+    // stop for its own.  (Found by the solver fuzz: one solve in ~10^5 returned x with only some tiles updated.)
+    __device__ __forceinline__ int converged_word() const { return ST_CONVERGED | (int)((its & 0x7ffffff) << 4); }
+    __device__ __forceinline__ bool stopped(int status) const { return status != ST_RUNNING && status != converged_word(); }
     __device__ __forceinline__ bool prologue() {
         __shared__ Real<T> smD[NWAVE];
         __shared__ T smT[NWAVE];
@@ -286,7 +292,7 @@ struct MinresM3 {
         const MinresState<T> S = D->st[par];                        // (a copy: st[par] is not written by this launch)
         if (PC) {
             const T b2 = reduce_partials(partBeta2, P, smT);        // :278
-            if (status != ST_RUNNING) return false;
+            if (stopped(status)) return false;
             if (sre(b2) < seps<Real<T>>() || sim(b2) > seps<Real<T>>() * sre(b2)) {         // :279-287
                 if (first_thread()) { D->st[par].pc_re = sre(b2); D->its = its; D->status = ST_INVALID_PC; }
                 return false;
@@ -294,7 +300,7 @@ struct MinresM3 {
             beta_new = ssqrt(sre(b2));                               // :288
         } else {
             beta_new = ssqrt(reduce_partials(partBeta, P, smD));     // :120
-            if (status != ST_RUNNING) return false;
+            if (stopped(status)) return false;
         }
         inv = Real<T>(1) / beta_new;                                       // :121 / :289
         const Real<T> beta = S.beta;
@@ -346,7 +352,7 @@ struct MinresM3 {
         N.eta = smulr(S.eta, -s_new);                               // :168
         N.pc_re = 0.0; N.pad0 = 0.0;
         D->st[par ^ 1] = N;
-        if (N.res_norm < S.threshold) { D->its = its; D->status = ST_CONVERGED; }   // :165-167
+        if (N.res_norm < S.threshold) { D->its = its; D->status = converged_word(); }   // :165-167
     }
 };
 
@@ -956,7 +962,7 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> t
         if (done_enqueue || since_poll >= poll) {
             since_poll = 0;
             SPRS_TRY(fetch());
-            if (H.status == ST_CONVERGED) {                                 // :165-167 (0-based its)
+            if ((H.status & 15) == ST_CONVERGED) {                          // :165-167 (0-based its; the word carries the iteration, MinresM3)
                 *its_out = (size_t)H.its;
                 *res_out = H.st[(H.its + 1) & 1].res_norm / rhs_norm;
                 if (tracing) {

@@ -1215,3 +1215,27 @@ def test_non_temporal_accesses_are_a_pure_cache_hint(oracle):
     for k in (1, 3, 5, 7, 9):
         assert np.array_equal(bits(a[k]), bits(b[k])), k
     assert np.array_equal(bits(a[1]), bits(oracle.spmv(ip, ix, d, np.linspace(-1.0, 1.0, n) ** 3)))
+
+
+def test_minres_converging_launch_finishes_its_own_iteration(sa, oracle):
+    """MINRES tests convergence AFTER updating x (minres.rs:162-167), so the kernel that finds the solve converged also holds
+    that iteration's x update: a workgroup of that launch which reads the status word late must not take the event its own
+    launch set for a reason to skip its tiles.  (The solver fuzz met it once in ~10^5 solves: its / residual right, x updated
+    in some tiles only.)  The status word now carries the iteration; this hammers the case — thousands of solves that converge in
+    their first iterations, small enough that workgroup 0 is done within microseconds — and compares every x with the oracle."""
+    from sprsolve_amd import gen
+    rng = np.random.default_rng(99)
+    for n, dtype in ((1000, np.complex128), (4099, np.float64), (257, np.complex128)):
+        ip, ix, d, _ = gen.symmetric_banded(n, hbw=3)
+        d = d.astype(dtype)
+        A = sa.HipCsr.new((n, n), ip, ix, d)
+        s = sa.MinRes.new(A, n)
+        for k in range(400):
+            rhs = rng.uniform(-1, 1, n).astype(dtype)
+            if np.dtype(dtype).kind == "c":
+                rhs = rhs + 1j * rng.uniform(-1, 1, n)
+            tol = (0.5, 0.3, 0.1)[k % 3]
+            ref = oracle.minres(ip, ix, d, rhs, np.zeros(n, dtype=dtype), 50, tol)
+            x = np.zeros(n, dtype=dtype)
+            its, res = s.solve(rhs, x, 50, tol)
+            assert its == ref.its and np.max(np.abs(x - ref.x)) <= 1e-12 * max(1.0, float(np.max(np.abs(ref.x)))), (n, k, its, ref.its)
