@@ -42,7 +42,6 @@ MARGINAL rate (K_hi - K) / (T(K_hi) - T(K)); both regions are in the line.
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -96,15 +95,28 @@ def parse():
 # ------------------------------------------------------------------------------------------ self-launch
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This process has not touched the
-    GPU (no torch import, no HIP call), the ranks are ordinary children (never an exec)."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    GPU (no torch import, no HIP call), the ranks are ordinary children (never an exec).
+
+    No port is chosen here: the launcher's c10d rendezvous binds port 0 ITSELF (atomically) and the ranks share that store
+    (torch elastic's agent store), so there is no window between "find a free port" and "bind it" for another process to
+    take it (round 3's EADDRINUSE).  Should the agent still die on a socket error before any rank ran, ONE fresh child is
+    started — a new rendezvous, a new port."""
+    import uuid
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for k in ("MASTER_PORT", "MASTER_ADDR", "RANK", "LOCAL_RANK", "WORLD_SIZE", "TORCH_DISABLE_SHARE_RDZV_TCP_STORE"):
+        env.pop(k, None)
+    p = None
+    for attempt in range(2):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--rdzv-backend", "c10d", "--rdzv-endpoint", "127.0.0.1:0", "--rdzv-id", uuid.uuid4().hex,
+               "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(p.stderr)
+        sock_err = any(w in p.stderr for w in ("EADDRINUSE", "Address already in use", "address already in use"))
+        if p.returncode == 0 or not sock_err or "bench.py rank" in p.stderr or attempt == 1:
+            break
+        print("bench.py: the launcher lost a socket before any rank started; starting one fresh child", file=sys.stderr)
     line = None
     for ln in p.stdout.splitlines():
         if ln.startswith("{") and '"metric"' in ln:
@@ -532,6 +544,8 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        print("bench.py rank %d of %d started" % (rank, world), file=sys.stderr, flush=True)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -543,7 +557,8 @@ def main():
         else:
             dist.init_process_group(backend="gloo")
     elif args.force_dist:
-        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
+        # one rank through the real RCCL: an in-process store — no port at all
+        dist.init_process_group(backend="nccl", store=dist.HashStore(), rank=0, world_size=1,
                                 device_id=torch.device("cuda", local_rank))
 
     import numpy as np

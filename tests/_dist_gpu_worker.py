@@ -9,10 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(rank, world, port, kind, outdir, exchange="halo"):
+def main(rank, world, rdzv, kind, outdir, exchange="halo"):
     import torch
     import torch.distributed as tdist
-    tdist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    # rendezvous through a file in the caller's private temp directory: no TCP port to pick, none to lose
+    tdist.init_process_group("gloo", init_method="file://" + rdzv, rank=rank, world_size=world)
     import sprsolve_amd as sa
     from sprsolve_amd import dist as sdist, gen, partition
     dev = torch.device("cuda", 0)
@@ -118,4 +119,4 @@ def main(rank, world, port, kind, outdir, exchange="halo"):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6] if len(sys.argv) > 6 else "halo")
+    main(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6] if len(sys.argv) > 6 else "halo")

@@ -114,9 +114,9 @@ class DistEmu:
         return x, max_iter, None, trace
 
 
-def main(rank, world, port, kind, outdir):
+def main(rank, world, rdzv, kind, outdir):
     import torch.distributed as dist
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method="file://" + rdzv, rank=rank, world_size=world)   # no TCP port to pick
     from oracle import oracle as orc
     from sprsolve_amd import partition
     ip, ix, d, rhs, plane = build_global(kind)
@@ -143,4 +143,4 @@ def main(rank, world, port, kind, outdir):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5])
+    main(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5])

@@ -5,7 +5,6 @@ shared-memory stand-in for the nine RCCL calls it makes.  Everything else is the
 (partition.py), pack kernel, grouped send/recv per neighbour, interior/boundary overlap, SpMV, the fused C++
 recurrences with all-reduced scalars.  Results are compared with the single-process oracle."""
 import os
-import socket
 import subprocess
 import sys
 import tempfile
@@ -27,10 +26,10 @@ def mock_lib():
 
 
 def _run(world, kind, mock_lib, exchange="halo"):
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = tempfile.mkdtemp(prefix="sprs_distgpu_")
+    rdzv = os.path.join(out, "rendezvous")       # file:// store in a private directory: no port is picked, none can be lost
     env = dict(os.environ, SPRS_RCCL_LIB=mock_lib, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_gpu_worker.py"), str(r), str(world), str(port), kind, out, exchange], env=env)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_gpu_worker.py"), str(r), str(world), rdzv, kind, out, exchange], env=env)
              for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0

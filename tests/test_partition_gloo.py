@@ -2,7 +2,6 @@
 (row ranges, column localisation, halo plan exchange) and a numpy twin of the distributed
 recurrence; results are compared with the single-process oracle."""
 import os
-import socket
 import subprocess
 import sys
 import tempfile
@@ -13,15 +12,10 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
-    return p
-
-
 def _run(world, kind):
-    port = _free_port()
     out = tempfile.mkdtemp(prefix="sprs_dist_")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(r), str(world), str(port), kind, out],
+    rdzv = os.path.join(out, "rendezvous")       # file:// store: no port to pick
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(r), str(world), rdzv, kind, out],
                               env=dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1"))
              for r in range(world)]
     for p in procs:
