@@ -17,7 +17,7 @@
 //!     signatures with the whole recurrence on the device.
 #![allow(non_camel_case_types)]
 
-use num_complex::Complex64;
+use num_complex::{Complex32, Complex64};
 use sprs::{CompressedStorage, CsMatI};
 use sprsolve::error::{SolveResult, SolverError};
 use sprsolve::MatVecMul;
@@ -148,6 +148,79 @@ pub mod sys {
         pub fn sprs_gauss_seidel_destroy(g: *mut sprs_gauss_seidel) -> c_int;
         pub fn sprs_gauss_seidel_solve_d(g: *mut sprs_gauss_seidel, rhs: *const f64, rhs_len: usize, x: *mut f64, x_len: usize,
             max_iter: usize, eps: f64, its: *mut usize, res: *mut f64) -> c_int;
+
+        // ---- f32 / Complex<f32> twins (`_s`, `_c`, `_cs`): the reference is generic over all four `cauchy::Scalar` types and
+        // tests f32 / c32 BLAS-1 (src/vecalg.rs:647-658,669-677,771-830); every `T::Real` quantity is `f32` here
+        pub fn sprs_csr_create_s(ctx: *mut sprs_ctx, nrows: i64, ncols: i64, nnz: i64, row_ptr: *const i32,
+            col_idx: *const i32, val: *const f32, storage_csc: c_int, out: *mut *mut sprs_csr) -> c_int;
+        pub fn sprs_csr_create_c(ctx: *mut sprs_ctx, nrows: i64, ncols: i64, nnz: i64, row_ptr: *const i32,
+            col_idx: *const i32, val: *const Complex32, storage_csc: c_int, out: *mut *mut sprs_csr) -> c_int;
+        pub fn sprs_csr_create_i64_s(ctx: *mut sprs_ctx, nrows: i64, ncols: i64, nnz: i64, row_ptr: *const i64,
+            col_idx: *const i64, val: *const f32, storage_csc: c_int, out: *mut *mut sprs_csr) -> c_int;
+        pub fn sprs_csr_create_i64_c(ctx: *mut sprs_ctx, nrows: i64, ncols: i64, nnz: i64, row_ptr: *const i64,
+            col_idx: *const i64, val: *const Complex32, storage_csc: c_int, out: *mut *mut sprs_csr) -> c_int;
+        pub fn sprs_mul_vec_s(a: *const sprs_csr, x: *const f32, x_len: usize, y: *mut f32, y_len: usize) -> c_int;
+        pub fn sprs_mul_vec_c(a: *const sprs_csr, x: *const Complex32, x_len: usize, y: *mut Complex32, y_len: usize) -> c_int;
+        pub fn sprs_mul_vec_dot_s(a: *const sprs_csr, x: *const f32, x_len: usize, y: *mut f32, y_len: usize, dot: *mut f32) -> c_int;
+        pub fn sprs_mul_vec_dot_c(a: *const sprs_csr, x: *const Complex32, x_len: usize, y: *mut Complex32, y_len: usize,
+            dot: *mut Complex32) -> c_int;
+        pub fn sprs_mul_vec_dev_s(a: *const sprs_csr, x: *const f32, y: *mut f32) -> c_int;
+        pub fn sprs_mul_vec_dev_c(a: *const sprs_csr, x: *const Complex32, y: *mut Complex32) -> c_int;
+        pub fn sprs_mul_vec_dot_dev_s(a: *const sprs_csr, x: *const f32, y: *mut f32, dot: *mut f32) -> c_int;
+        pub fn sprs_mul_vec_dot_dev_c(a: *const sprs_csr, x: *const Complex32, y: *mut Complex32, dot: *mut Complex32) -> c_int;
+        pub fn sprs_dot_s(ctx: *mut sprs_ctx, n: usize, x: *const f32, y: *const f32, out: *mut f32) -> c_int;
+        pub fn sprs_dot_c(ctx: *mut sprs_ctx, n: usize, x: *const Complex32, y: *const Complex32, out: *mut Complex32) -> c_int;
+        pub fn sprs_conj_dot_s(ctx: *mut sprs_ctx, n: usize, x: *const f32, y: *const f32, out: *mut f32) -> c_int;
+        pub fn sprs_conj_dot_c(ctx: *mut sprs_ctx, n: usize, x: *const Complex32, y: *const Complex32, out: *mut Complex32) -> c_int;
+        pub fn sprs_norm2_s(ctx: *mut sprs_ctx, n: usize, x: *const f32, out: *mut f32) -> c_int;
+        pub fn sprs_norm2_c(ctx: *mut sprs_ctx, n: usize, x: *const Complex32, out: *mut f32) -> c_int;
+        pub fn sprs_scale_s(ctx: *mut sprs_ctx, n: usize, a: f32, x: *mut f32) -> c_int;
+        pub fn sprs_scale_c(ctx: *mut sprs_ctx, n: usize, a: Complex32, x: *mut Complex32) -> c_int;
+        pub fn sprs_rscale_s(ctx: *mut sprs_ctx, n: usize, a: f32, x: *mut f32) -> c_int;
+        pub fn sprs_rscale_c(ctx: *mut sprs_ctx, n: usize, a: f32, x: *mut Complex32) -> c_int;
+        pub fn sprs_conj_s(ctx: *mut sprs_ctx, n: usize, v_in: *const f32, v_out: *mut f32) -> c_int;
+        pub fn sprs_conj_c(ctx: *mut sprs_ctx, n: usize, v_in: *const Complex32, v_out: *mut Complex32) -> c_int;
+        pub fn sprs_axpy_s(ctx: *mut sprs_ctx, n: usize, a: f32, x: *const f32, y: *mut f32) -> c_int;
+        pub fn sprs_axpy_c(ctx: *mut sprs_ctx, n: usize, a: Complex32, x: *const Complex32, y: *mut Complex32) -> c_int;
+        pub fn sprs_axpy_cs(ctx: *mut sprs_ctx, n: usize, a: f32, x: *const Complex32, y: *mut Complex32) -> c_int;
+        pub fn sprs_axpby_s(ctx: *mut sprs_ctx, n: usize, a: f32, x: *const f32, b: f32, y: *mut f32) -> c_int;
+        pub fn sprs_axpby_c(ctx: *mut sprs_ctx, n: usize, a: Complex32, x: *const Complex32, b: Complex32, y: *mut Complex32) -> c_int;
+        pub fn sprs_diag_precond_create_s(ctx: *mut sprs_ctx, n: usize, diag: *const f32, out: *mut *mut sprs_diag) -> c_int;
+        pub fn sprs_diag_precond_create_cs(ctx: *mut sprs_ctx, n: usize, diag: *const f32, out: *mut *mut sprs_diag) -> c_int;
+        pub fn sprs_diag_precond_create_c(ctx: *mut sprs_ctx, n: usize, diag: *const Complex32, out: *mut *mut sprs_diag) -> c_int;
+        pub fn sprs_diag_mul_vec_s(p: *const sprs_diag, v_in: *const f32, in_len: usize, v_out: *mut f32, out_len: usize) -> c_int;
+        pub fn sprs_diag_mul_vec_c(p: *const sprs_diag, v_in: *const Complex32, in_len: usize, v_out: *mut Complex32, out_len: usize) -> c_int;
+        pub fn sprs_diag_mul_vec_dev_s(p: *const sprs_diag, v_in: *const f32, v_out: *mut f32) -> c_int;
+        pub fn sprs_diag_mul_vec_dev_c(p: *const sprs_diag, v_in: *const Complex32, v_out: *mut Complex32) -> c_int;
+        pub fn sprs_bicgstab_create_s(a: *const sprs_csr, size: usize, out: *mut *mut sprs_bicgstab) -> c_int;
+        pub fn sprs_bicgstab_create_c(a: *const sprs_csr, size: usize, out: *mut *mut sprs_bicgstab) -> c_int;
+        pub fn sprs_bicgstab_solve_s(s: *mut sprs_bicgstab, rhs: *const f32, rhs_len: usize, x: *mut f32, x_len: usize,
+            max_iter: usize, tol: f32, its: *mut usize, res: *mut f32) -> c_int;
+        pub fn sprs_bicgstab_solve_c(s: *mut sprs_bicgstab, rhs: *const Complex32, rhs_len: usize, x: *mut Complex32,
+            x_len: usize, max_iter: usize, tol: f32, its: *mut usize, res: *mut f32) -> c_int;
+        pub fn sprs_bicgstab_precond_solve_s(s: *mut sprs_bicgstab, p: *const sprs_diag, rhs: *const f32, rhs_len: usize,
+            x: *mut f32, x_len: usize, max_iter: usize, tol: f32, its: *mut usize, res: *mut f32) -> c_int;
+        pub fn sprs_bicgstab_precond_solve_c(s: *mut sprs_bicgstab, p: *const sprs_diag, rhs: *const Complex32,
+            rhs_len: usize, x: *mut Complex32, x_len: usize, max_iter: usize, tol: f32, its: *mut usize,
+            res: *mut f32) -> c_int;
+        pub fn sprs_minres_create_s(a: *const sprs_csr, size: usize, out: *mut *mut sprs_minres) -> c_int;
+        pub fn sprs_minres_create_c(a: *const sprs_csr, size: usize, out: *mut *mut sprs_minres) -> c_int;
+        pub fn sprs_minres_solve_s(s: *mut sprs_minres, rhs: *const f32, rhs_len: usize, x: *mut f32, x_len: usize,
+            max_iter: usize, tol: f32, its: *mut usize, res: *mut f32) -> c_int;
+        pub fn sprs_minres_solve_c(s: *mut sprs_minres, rhs: *const Complex32, rhs_len: usize, x: *mut Complex32,
+            x_len: usize, max_iter: usize, tol: f32, its: *mut usize, res: *mut f32) -> c_int;
+        pub fn sprs_minres_precond_solve_s(s: *mut sprs_minres, p: *const sprs_diag, rhs: *const f32, rhs_len: usize,
+            x: *mut f32, x_len: usize, max_iter: usize, tol: f32, its: *mut usize, res: *mut f32) -> c_int;
+        pub fn sprs_minres_precond_solve_c(s: *mut sprs_minres, p: *const sprs_diag, rhs: *const Complex32, rhs_len: usize,
+            x: *mut Complex32, x_len: usize, max_iter: usize, tol: f32, its: *mut usize, res: *mut f32) -> c_int;
+        pub fn sprs_csminres_create_s(a: *const sprs_csr, size: usize, out: *mut *mut sprs_csminres) -> c_int;
+        pub fn sprs_csminres_create_c(a: *const sprs_csr, size: usize, out: *mut *mut sprs_csminres) -> c_int;
+        pub fn sprs_csminres_solve_s(s: *mut sprs_csminres, rhs: *const f32, rhs_len: usize, x: *mut f32,
+            x_len: usize, max_iter: usize, tol: f32, its: *mut usize, res: *mut f32) -> c_int;
+        pub fn sprs_csminres_solve_c(s: *mut sprs_csminres, rhs: *const Complex32, rhs_len: usize, x: *mut Complex32,
+            x_len: usize, max_iter: usize, tol: f32, its: *mut usize, res: *mut f32) -> c_int;
+        pub fn sprs_gauss_seidel_solve_s(g: *mut sprs_gauss_seidel, rhs: *const f32, rhs_len: usize, x: *mut f32, x_len: usize,
+            max_iter: usize, eps: f32, its: *mut usize, res: *mut f32) -> c_int;
     }
 }
 
@@ -181,8 +254,8 @@ pub fn last_error() -> String {
 /// Destroys the shared context.  Only after every handle and `DevVec` of the process has been dropped.
 pub unsafe fn shutdown(ctx: *mut sys::sprs_ctx) { sys::sprs_ctx_destroy(ctx); }
 
-/// Status -> the reference's `SolveResult` (src/error.rs:7-22).
-fn map_status(st: c_int, its: usize, res: f64) -> SolveResult<(usize, f64)> {
+/// Status -> the reference's `SolveResult` (src/error.rs:7-22).  `R` = `T::Real` (f64 or f32).
+fn map_status<R: Copy + std::fmt::Display>(st: c_int, its: usize, res: R) -> SolveResult<(usize, R)> {
     match st {
         sys::SPRS_OK => Ok((its, res)),
         sys::SPRS_INCOMPATIBLE_RHS_SIZE => Err(SolverError::IncompatibleMatrixFormat(String::from(
@@ -240,9 +313,11 @@ impl HipIndex for u32 {
     }
 }
 
-/// Scalars the backend implements: one C symbol per operation and type (`_d`, `_z`) — the build's
-/// analogue of the reference's TypeId dispatch (src/lib.rs:23-41).
-pub trait HipScalar: cauchy::Scalar<Real = f64> {
+/// Scalars the backend implements — all four `cauchy::Scalar` types the reference is generic over (src/mat.rs:12-37;
+/// f32 / c32 BLAS-1 tests src/vecalg.rs:647-658,771-830): one C symbol per operation and type (`_d`, `_z`, `_s`, `_c`) — the
+/// build's analogue of the reference's TypeId dispatch (src/lib.rs:23-41).  Every `T::Real` quantity (tolerances, norms,
+/// residuals, real scale factors) is `Self::Real`: f64 for f64 / Complex64, f32 for f32 / Complex32.
+pub trait HipScalar: cauchy::Scalar {
     unsafe fn csr_create_i32(ctx: *mut sys::sprs_ctx, nr: i64, nc: i64, nnz: i64, p: *const i32, i: *const i32,
                              v: *const Self, csc: c_int, out: *mut *mut sys::sprs_csr) -> c_int;
     unsafe fn csr_create_i64(ctx: *mut sys::sprs_ctx, nr: i64, nc: i64, nnz: i64, p: *const i64, i: *const i64,
@@ -255,22 +330,22 @@ pub trait HipScalar: cauchy::Scalar<Real = f64> {
     unsafe fn diag_mul_vec_dev(p: *const sys::sprs_diag, x: *const Self, y: *mut Self) -> c_int;
     unsafe fn bicgstab_create(a: *const sys::sprs_csr, n: usize, out: *mut *mut sys::sprs_bicgstab) -> c_int;
     unsafe fn bicgstab_solve(s: *mut sys::sprs_bicgstab, p: *const sys::sprs_diag, rhs: &[Self], x: &mut [Self],
-                             max_iter: usize, tol: f64, its: &mut usize, res: &mut f64) -> c_int;
+                             max_iter: usize, tol: Self::Real, its: &mut usize, res: &mut Self::Real) -> c_int;
     unsafe fn minres_create(a: *const sys::sprs_csr, n: usize, out: *mut *mut sys::sprs_minres) -> c_int;
     unsafe fn minres_solve(s: *mut sys::sprs_minres, p: *const sys::sprs_diag, rhs: &[Self], x: &mut [Self],
-                           max_iter: usize, tol: f64, its: &mut usize, res: &mut f64) -> c_int;
+                           max_iter: usize, tol: Self::Real, its: &mut usize, res: &mut Self::Real) -> c_int;
     unsafe fn csminres_create(a: *const sys::sprs_csr, n: usize, out: *mut *mut sys::sprs_csminres) -> c_int;
-    unsafe fn csminres_solve(s: *mut sys::sprs_csminres, rhs: &[Self], x: &mut [Self], max_iter: usize, tol: f64,
-                             its: &mut usize, res: &mut f64) -> c_int;
+    unsafe fn csminres_solve(s: *mut sys::sprs_csminres, rhs: &[Self], x: &mut [Self], max_iter: usize, tol: Self::Real,
+                             its: &mut usize, res: &mut Self::Real) -> c_int;
     // vecalg on device pointers
     unsafe fn v_dot(c: *mut sys::sprs_ctx, n: usize, x: *const Self, y: *const Self, o: &mut Self) -> c_int;
     unsafe fn v_conj_dot(c: *mut sys::sprs_ctx, n: usize, x: *const Self, y: *const Self, o: &mut Self) -> c_int;
-    unsafe fn v_norm2(c: *mut sys::sprs_ctx, n: usize, x: *const Self, o: &mut f64) -> c_int;
+    unsafe fn v_norm2(c: *mut sys::sprs_ctx, n: usize, x: *const Self, o: &mut Self::Real) -> c_int;
     unsafe fn v_scale(c: *mut sys::sprs_ctx, n: usize, a: Self, x: *mut Self) -> c_int;
-    unsafe fn v_rscale(c: *mut sys::sprs_ctx, n: usize, a: f64, x: *mut Self) -> c_int;
+    unsafe fn v_rscale(c: *mut sys::sprs_ctx, n: usize, a: Self::Real, x: *mut Self) -> c_int;
     unsafe fn v_conj(c: *mut sys::sprs_ctx, n: usize, i: *const Self, o: *mut Self) -> c_int;
     unsafe fn v_axpy(c: *mut sys::sprs_ctx, n: usize, a: Self, x: *const Self, y: *mut Self) -> c_int;
-    unsafe fn v_axpy_real(c: *mut sys::sprs_ctx, n: usize, a: f64, x: *const Self, y: *mut Self) -> c_int;
+    unsafe fn v_axpy_real(c: *mut sys::sprs_ctx, n: usize, a: Self::Real, x: *const Self, y: *mut Self) -> c_int;
     unsafe fn v_axpby(c: *mut sys::sprs_ctx, n: usize, a: Self, x: *const Self, b: Self, y: *mut Self) -> c_int;
 }
 
@@ -305,7 +380,7 @@ macro_rules! impl_scalar {
                 sys::$bc(a, n, out)
             }
             unsafe fn bicgstab_solve(s: *mut sys::sprs_bicgstab, p: *const sys::sprs_diag, rhs: &[Self], x: &mut [Self],
-                                     max_iter: usize, tol: f64, its: &mut usize, res: &mut f64) -> c_int {
+                                     max_iter: usize, tol: Self::Real, its: &mut usize, res: &mut Self::Real) -> c_int {
                 if p.is_null() { sys::$bs(s, rhs.as_ptr(), rhs.len(), x.as_mut_ptr(), x.len(), max_iter, tol, its, res) }
                 else { sys::$bps(s, p, rhs.as_ptr(), rhs.len(), x.as_mut_ptr(), x.len(), max_iter, tol, its, res) }
             }
@@ -313,25 +388,25 @@ macro_rules! impl_scalar {
                 sys::$mc(a, n, out)
             }
             unsafe fn minres_solve(s: *mut sys::sprs_minres, p: *const sys::sprs_diag, rhs: &[Self], x: &mut [Self],
-                                   max_iter: usize, tol: f64, its: &mut usize, res: &mut f64) -> c_int {
+                                   max_iter: usize, tol: Self::Real, its: &mut usize, res: &mut Self::Real) -> c_int {
                 if p.is_null() { sys::$ms(s, rhs.as_ptr(), rhs.len(), x.as_mut_ptr(), x.len(), max_iter, tol, its, res) }
                 else { sys::$mps(s, p, rhs.as_ptr(), rhs.len(), x.as_mut_ptr(), x.len(), max_iter, tol, its, res) }
             }
             unsafe fn csminres_create(a: *const sys::sprs_csr, n: usize, out: *mut *mut sys::sprs_csminres) -> c_int {
                 sys::$cc(a, n, out)
             }
-            unsafe fn csminres_solve(s: *mut sys::sprs_csminres, rhs: &[Self], x: &mut [Self], max_iter: usize, tol: f64,
-                                     its: &mut usize, res: &mut f64) -> c_int {
+            unsafe fn csminres_solve(s: *mut sys::sprs_csminres, rhs: &[Self], x: &mut [Self], max_iter: usize, tol: Self::Real,
+                                     its: &mut usize, res: &mut Self::Real) -> c_int {
                 sys::$cs(s, rhs.as_ptr(), rhs.len(), x.as_mut_ptr(), x.len(), max_iter, tol, its, res)
             }
             unsafe fn v_dot(c: *mut sys::sprs_ctx, n: usize, x: *const Self, y: *const Self, o: &mut Self) -> c_int { sys::$dot(c, n, x, y, o) }
             unsafe fn v_conj_dot(c: *mut sys::sprs_ctx, n: usize, x: *const Self, y: *const Self, o: &mut Self) -> c_int { sys::$cdot(c, n, x, y, o) }
-            unsafe fn v_norm2(c: *mut sys::sprs_ctx, n: usize, x: *const Self, o: &mut f64) -> c_int { sys::$nrm(c, n, x, o) }
+            unsafe fn v_norm2(c: *mut sys::sprs_ctx, n: usize, x: *const Self, o: &mut Self::Real) -> c_int { sys::$nrm(c, n, x, o) }
             unsafe fn v_scale(c: *mut sys::sprs_ctx, n: usize, a: Self, x: *mut Self) -> c_int { sys::$scale(c, n, a, x) }
-            unsafe fn v_rscale(c: *mut sys::sprs_ctx, n: usize, a: f64, x: *mut Self) -> c_int { sys::$rscale(c, n, a, x) }
+            unsafe fn v_rscale(c: *mut sys::sprs_ctx, n: usize, a: Self::Real, x: *mut Self) -> c_int { sys::$rscale(c, n, a, x) }
             unsafe fn v_conj(c: *mut sys::sprs_ctx, n: usize, i: *const Self, o: *mut Self) -> c_int { sys::$conj(c, n, i, o) }
             unsafe fn v_axpy(c: *mut sys::sprs_ctx, n: usize, a: Self, x: *const Self, y: *mut Self) -> c_int { sys::$axpy(c, n, a, x, y) }
-            unsafe fn v_axpy_real(c: *mut sys::sprs_ctx, n: usize, a: f64, x: *const Self, y: *mut Self) -> c_int { sys::$axpyr(c, n, a, x, y) }
+            unsafe fn v_axpy_real(c: *mut sys::sprs_ctx, n: usize, a: Self::Real, x: *const Self, y: *mut Self) -> c_int { sys::$axpyr(c, n, a, x, y) }
             unsafe fn v_axpby(c: *mut sys::sprs_ctx, n: usize, a: Self, x: *const Self, b: Self, y: *mut Self) -> c_int { sys::$axpby(c, n, a, x, b, y) }
         }
     };
@@ -346,6 +421,16 @@ impl_scalar!(Complex64, sprs_csr_create_z, sprs_csr_create_i64_z, sprs_mul_vec_z
              sprs_bicgstab_create_z, sprs_bicgstab_solve_z, sprs_bicgstab_precond_solve_z,
              sprs_minres_create_z, sprs_minres_solve_z, sprs_minres_precond_solve_z, sprs_csminres_create_z, sprs_csminres_solve_z,
              sprs_dot_z, sprs_conj_dot_z, sprs_norm2_z, sprs_scale_z, sprs_rscale_z, sprs_conj_z, sprs_axpy_z, sprs_axpy_zd, sprs_axpby_z);
+impl_scalar!(f32, sprs_csr_create_s, sprs_csr_create_i64_s, sprs_mul_vec_s, sprs_mul_vec_dot_s, sprs_mul_vec_dev_s,
+             sprs_mul_vec_dot_dev_s, sprs_diag_mul_vec_s, sprs_diag_mul_vec_dev_s,
+             sprs_bicgstab_create_s, sprs_bicgstab_solve_s, sprs_bicgstab_precond_solve_s,
+             sprs_minres_create_s, sprs_minres_solve_s, sprs_minres_precond_solve_s, sprs_csminres_create_s, sprs_csminres_solve_s,
+             sprs_dot_s, sprs_conj_dot_s, sprs_norm2_s, sprs_scale_s, sprs_rscale_s, sprs_conj_s, sprs_axpy_s, sprs_axpy_s, sprs_axpby_s);
+impl_scalar!(Complex32, sprs_csr_create_c, sprs_csr_create_i64_c, sprs_mul_vec_c, sprs_mul_vec_dot_c, sprs_mul_vec_dev_c,
+             sprs_mul_vec_dot_dev_c, sprs_diag_mul_vec_c, sprs_diag_mul_vec_dev_c,
+             sprs_bicgstab_create_c, sprs_bicgstab_solve_c, sprs_bicgstab_precond_solve_c,
+             sprs_minres_create_c, sprs_minres_solve_c, sprs_minres_precond_solve_c, sprs_csminres_create_c, sprs_csminres_solve_c,
+             sprs_dot_c, sprs_conj_dot_c, sprs_norm2_c, sprs_scale_c, sprs_rscale_c, sprs_conj_c, sprs_axpy_c, sprs_axpy_cs, sprs_axpby_c);
 
 // ------------------------------------------------------------------------------------------------ operator
 /// Device-resident CSR operator: the MI355X twin of `MklMat<T>` (src/mkl_mat.rs:15-74).
@@ -444,6 +529,21 @@ impl HipDiag<Complex64> for Complex64 { // DiagPrecond<Complex64, Complex64>: te
         sys::sprs_diag_precond_create_z(ctx, d.len(), d.as_ptr(), out)
     }
 }
+impl HipDiag<f32> for f32 {
+    unsafe fn diag_create(ctx: *mut sys::sprs_ctx, d: &[f32], out: *mut *mut sys::sprs_diag) -> c_int {
+        sys::sprs_diag_precond_create_s(ctx, d.len(), d.as_ptr(), out)
+    }
+}
+impl HipDiag<f32> for Complex32 {
+    unsafe fn diag_create(ctx: *mut sys::sprs_ctx, d: &[f32], out: *mut *mut sys::sprs_diag) -> c_int {
+        sys::sprs_diag_precond_create_cs(ctx, d.len(), d.as_ptr(), out)
+    }
+}
+impl HipDiag<Complex32> for Complex32 {
+    unsafe fn diag_create(ctx: *mut sys::sprs_ctx, d: &[Complex32], out: *mut *mut sys::sprs_diag) -> c_int {
+        sys::sprs_diag_precond_create_c(ctx, d.len(), d.as_ptr(), out)
+    }
+}
 
 /// Jacobi preconditioner resident in HBM: `DiagPrecond<T, V>` (src/precond.rs:6-63).  `new` stores 1 / diag
 /// (no zero check, like the reference); `impl MatVecMul<T>` applies it.
@@ -481,14 +581,14 @@ impl<'data, T: HipScalar> HipBiCGStab<'data, T> {
         ok_or_panic(unsafe { T::bicgstab_create(a.raw(), size, &mut h) });
         HipBiCGStab { _a: a, handle: h }
     }
-    pub fn solve(&mut self, rhs: &[T], x: &mut [T], max_iter: usize, tol: f64) -> SolveResult<(usize, f64)> {
-        let (mut its, mut res) = (0usize, 0f64);
+    pub fn solve(&mut self, rhs: &[T], x: &mut [T], max_iter: usize, tol: T::Real) -> SolveResult<(usize, T::Real)> {
+        let (mut its, mut res) = (0usize, <T::Real>::zero());
         let st = unsafe { T::bicgstab_solve(self.handle, ptr::null(), rhs, x, max_iter, tol, &mut its, &mut res) };
         map_status(st, its, res)
     }
-    pub fn precond_solve<V>(&mut self, precond: &HipDiagPrecond<T, V>, rhs: &[T], x: &mut [T], max_iter: usize, tol: f64)
-        -> SolveResult<(usize, f64)> where T: HipDiag<V> {
-        let (mut its, mut res) = (0usize, 0f64);
+    pub fn precond_solve<V>(&mut self, precond: &HipDiagPrecond<T, V>, rhs: &[T], x: &mut [T], max_iter: usize, tol: T::Real)
+        -> SolveResult<(usize, T::Real)> where T: HipDiag<V> {
+        let (mut its, mut res) = (0usize, <T::Real>::zero());
         let st = unsafe { T::bicgstab_solve(self.handle, precond.raw(), rhs, x, max_iter, tol, &mut its, &mut res) };
         map_status(st, its, res)
     }
@@ -503,14 +603,14 @@ impl<'data, T: HipScalar> HipMinRes<'data, T> {
         ok_or_panic(unsafe { T::minres_create(a.raw(), size, &mut h) });
         HipMinRes { _a: a, handle: h }
     }
-    pub fn solve(&mut self, rhs: &[T], x: &mut [T], max_iter: usize, tol: f64) -> SolveResult<(usize, f64)> {
-        let (mut its, mut res) = (0usize, 0f64);
+    pub fn solve(&mut self, rhs: &[T], x: &mut [T], max_iter: usize, tol: T::Real) -> SolveResult<(usize, T::Real)> {
+        let (mut its, mut res) = (0usize, <T::Real>::zero());
         let st = unsafe { T::minres_solve(self.handle, ptr::null(), rhs, x, max_iter, tol, &mut its, &mut res) };
         map_status(st, its, res)
     }
-    pub fn precond_solve<V>(&mut self, precond: &HipDiagPrecond<T, V>, rhs: &[T], x: &mut [T], max_iter: usize, tol: f64)
-        -> SolveResult<(usize, f64)> where T: HipDiag<V> {
-        let (mut its, mut res) = (0usize, 0f64);
+    pub fn precond_solve<V>(&mut self, precond: &HipDiagPrecond<T, V>, rhs: &[T], x: &mut [T], max_iter: usize, tol: T::Real)
+        -> SolveResult<(usize, T::Real)> where T: HipDiag<V> {
+        let (mut its, mut res) = (0usize, <T::Real>::zero());
         let st = unsafe { T::minres_solve(self.handle, precond.raw(), rhs, x, max_iter, tol, &mut its, &mut res) };
         map_status(st, its, res)
     }
@@ -525,31 +625,48 @@ impl<'data, T: HipScalar> HipCSMinRes<'data, T> {
         ok_or_panic(unsafe { T::csminres_create(a.raw(), size, &mut h) });
         HipCSMinRes { _a: a, handle: h }
     }
-    pub fn solve(&mut self, rhs: &[T], x: &mut [T], max_iter: usize, tol: f64) -> SolveResult<(usize, f64)> {
-        let (mut its, mut res) = (0usize, 0f64);
+    pub fn solve(&mut self, rhs: &[T], x: &mut [T], max_iter: usize, tol: T::Real) -> SolveResult<(usize, T::Real)> {
+        let (mut its, mut res) = (0usize, <T::Real>::zero());
         let st = unsafe { T::csminres_solve(self.handle, rhs, x, max_iter, tol, &mut its, &mut res) };
         map_status(st, its, res)
     }
 }
 impl<'data, T: HipScalar> Drop for HipCSMinRes<'data, T> { fn drop(&mut self) { unsafe { sys::sprs_csminres_destroy(self.handle); } } }
 
+/// Real scalars the Gauss-Seidel sweep exists for (`_d`, `_s`).
+pub trait HipGsScalar: HipScalar<Real = Self> {
+    unsafe fn gs_solve(g: *mut sys::sprs_gauss_seidel, rhs: &[Self], x: &mut [Self], max_iter: usize, eps: Self, its: &mut usize,
+                       res: &mut Self) -> c_int;
+}
+impl HipGsScalar for f64 {
+    unsafe fn gs_solve(g: *mut sys::sprs_gauss_seidel, rhs: &[f64], x: &mut [f64], max_iter: usize, eps: f64, its: &mut usize,
+                       res: &mut f64) -> c_int {
+        sys::sprs_gauss_seidel_solve_d(g, rhs.as_ptr(), rhs.len(), x.as_mut_ptr(), x.len(), max_iter, eps, its, res)
+    }
+}
+impl HipGsScalar for f32 {
+    unsafe fn gs_solve(g: *mut sys::sprs_gauss_seidel, rhs: &[f32], x: &mut [f32], max_iter: usize, eps: f32, its: &mut usize,
+                       res: &mut f32) -> c_int {
+        sys::sprs_gauss_seidel_solve_s(g, rhs.as_ptr(), rhs.len(), x.as_mut_ptr(), x.len(), max_iter, eps, its, res)
+    }
+}
+
 /// `GaussSeidel` on the device (src/gauss_seidel.rs:8-141): level-scheduled sweeps, iterates bit-identical to
 /// the serial sweep.  `solve` returns the ABSOLUTE residual norm like the reference (:107,136).
-pub struct HipGaussSeidel<'data> { _a: &'data HipCsr<f64>, handle: *mut sys::sprs_gauss_seidel }
-impl<'data> HipGaussSeidel<'data> {
-    pub fn new(a: &'data HipCsr<f64>) -> SolveResult<Self> {
+pub struct HipGaussSeidel<'data, T: HipGsScalar = f64> { _a: &'data HipCsr<T>, handle: *mut sys::sprs_gauss_seidel }
+impl<'data, T: HipGsScalar> HipGaussSeidel<'data, T> {
+    pub fn new(a: &'data HipCsr<T>) -> SolveResult<Self> {
         let mut h = ptr::null_mut();
         let st = unsafe { sys::sprs_gauss_seidel_create(a.raw(), &mut h) };
-        map_status(st, 0, 0.0).map(|_| HipGaussSeidel { _a: a, handle: h })
+        map_status(st, 0, 0.0f64).map(|_| HipGaussSeidel { _a: a, handle: h })
     }
-    pub fn solve(&mut self, rhs: &[f64], x: &mut [f64], max_iter: usize, eps: f64) -> SolveResult<(usize, f64)> {
-        let (mut its, mut res) = (0usize, 0f64);
-        let st = unsafe { sys::sprs_gauss_seidel_solve_d(self.handle, rhs.as_ptr(), rhs.len(), x.as_mut_ptr(), x.len(),
-                                                         max_iter, eps, &mut its, &mut res) };
+    pub fn solve(&mut self, rhs: &[T], x: &mut [T], max_iter: usize, eps: T) -> SolveResult<(usize, T)> {
+        let (mut its, mut res) = (0usize, T::zero());
+        let st = unsafe { T::gs_solve(self.handle, rhs, x, max_iter, eps, &mut its, &mut res) };
         map_status(st, its, res)
     }
 }
-impl<'data> Drop for HipGaussSeidel<'data> { fn drop(&mut self) { unsafe { sys::sprs_gauss_seidel_destroy(self.handle); } } }
+impl<'data, T: HipGsScalar> Drop for HipGaussSeidel<'data, T> { fn drop(&mut self) { unsafe { sys::sprs_gauss_seidel_destroy(self.handle); } } }
 
 // ------------------------------------------------------------------------------------------------ device vectors
 /// A vector resident in HBM.  With `vecalg` below and `HipCsr::mul_vec_dev` this is the level at which a
@@ -610,15 +727,15 @@ pub mod vecalg {
         o
     }
     /// sqrt(sum |x_i|^2), unscaled (src/vecalg.rs:63-69,601-605)
-    pub fn norm2<T: HipScalar>(x: &DevVec<T>) -> f64 {
-        let mut o = 0f64;
+    pub fn norm2<T: HipScalar>(x: &DevVec<T>) -> T::Real {
+        let mut o = <T::Real>::zero();
         ok_or_panic(unsafe { T::v_norm2(default_ctx(), x.len(), x.as_ptr(), &mut o) });
         o
     }
     /// x *= a (src/vecalg.rs:74-80)
     pub fn scale<T: HipScalar>(a: T, x: &mut DevVec<T>) { ok_or_panic(unsafe { T::v_scale(default_ctx(), x.len(), a, x.as_mut_ptr()) }); }
     /// x = x.mul_real(a) (src/vecalg.rs:86-92)
-    pub fn rscale<T: HipScalar>(a: f64, x: &mut DevVec<T>) { ok_or_panic(unsafe { T::v_rscale(default_ctx(), x.len(), a, x.as_mut_ptr()) }); }
+    pub fn rscale<T: HipScalar>(a: T::Real, x: &mut DevVec<T>) { ok_or_panic(unsafe { T::v_rscale(default_ctx(), x.len(), a, x.as_mut_ptr()) }); }
     /// out = conj(in) (src/vecalg.rs:96-104)
     pub fn conj<T: HipScalar>(v_in: &DevVec<T>, v_out: &mut DevVec<T>) {
         assert_eq!(v_in.len(), v_out.len());
@@ -630,7 +747,7 @@ pub mod vecalg {
         ok_or_panic(unsafe { T::v_axpy(default_ctx(), x.len(), a, x.as_ptr(), y.as_mut_ptr()) });
     }
     /// y += a * x with a REAL scalar on a complex vector (`T: Mul<S>`, src/vecalg.rs:746-757)
-    pub fn axpy_real<T: HipScalar>(a: f64, x: &DevVec<T>, y: &mut DevVec<T>) {
+    pub fn axpy_real<T: HipScalar>(a: T::Real, x: &DevVec<T>, y: &mut DevVec<T>) {
         assert_eq!(x.len(), y.len());
         ok_or_panic(unsafe { T::v_axpy_real(default_ctx(), x.len(), a, x.as_ptr(), y.as_mut_ptr()) });
     }

@@ -9,14 +9,12 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import sprsolve_amd as sa            # noqa: E402
 from oracle import oracle           # noqa: E402
 from sprsolve_amd import error as E  # noqa: E402
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
-ctx = sa.default_ctx(0)
+rng = np.random.default_rng(2024)      # re-seeded by run()
 SIZES = [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 1000]
 
 
@@ -65,87 +63,107 @@ def outcome_gpu(fn):
         return oracle.INVALID_PRECOND, -1, None
 
 
-t_end = time.time() + budget
-cases = hard = soft = 0
-by_status = {}
-while time.time() < t_end:
-    dtype = [np.float64, np.complex128, np.float32, np.complex64][int(rng.integers(0, 4))]
-    is_c = np.dtype(dtype).kind == "c"
-    single = np.dtype(dtype).itemsize in (4, 8) and np.dtype(dtype) in (np.dtype(np.float32), np.dtype(np.complex64))
-    kinds = ["bicgstab", "minres"] + (["csminres"] if is_c else [])
-    kind = kinds[int(rng.integers(0, len(kinds)))]
-    n = int(SIZES[int(rng.integers(0, len(SIZES)))]) if rng.uniform() < 0.7 else int(rng.integers(1, 400))
-    # MINRES wants a symmetric (real) / Hermitian matrix: use real symmetric data even for complex T; CSMINRES complex-symmetric
-    if kind == "minres":
-        ip, ix, d = banded(n, np.float64 if not single else np.float32, True, False)
-        d = d.astype(dtype)
-    else:
-        ip, ix, d = banded(n, dtype, False, kind == "csminres")
-    mode = int(rng.integers(0, 6))
-    rhs = cplx(n, dtype)
-    x0 = np.zeros(n, dtype=dtype)
-    max_iter, tol = 400, (1e-4 if single else 1e-10)
-    if mode == 1:
-        rhs = np.zeros(n, dtype=dtype)                  # rhs = 0: the early return (x = 0, Ok(0, 0))
-    elif mode == 2:
-        max_iter = int(rng.integers(0, 3))              # InsufficientIterNum (or a lucky Ok)
-    elif mode == 3:
-        tol = 0.5                                       # loose: Ok after very few iterations
-    elif mode == 4:
-        x0 = cplx(n, dtype)                             # non-zero initial guess
-    use_pc = kind != "csminres" and rng.uniform() < 0.5
-    pdiag = None
-    if use_pc:
-        pdiag = np.abs(np.array([d[ip[i]:ip[i + 1]][ix[ip[i]:ip[i + 1]] == i][0] for i in range(n)])).astype(
-            np.float32 if single else np.float64)       # positive real diagonal (MINRES needs an SPD preconditioner)
-    ref = getattr(oracle, kind)(ip, ix, d, rhs, x0, max_iter, tol, **({"precond_diag": pdiag} if use_pc else {}))
-    A = sa.HipCsr.new((n, n), ip, ix, d)
-    cls = {"bicgstab": sa.BiCGStab, "minres": sa.MinRes, "csminres": sa.CSMinRes}[kind]
-    P = sa.DiagPrecond.new(pdiag, t_dtype=dtype) if use_pc else None
-    for smode in ("fused", "literal"):
-        s = cls.new(A, n); s.set_mode(smode)
-        x = x0.copy()
-        st, its, res = outcome_gpu((lambda: s.precond_solve(P, rhs, x, max_iter, tol)) if use_pc else (lambda: s.solve(rhs, x, max_iter, tol)))
-        cases += 1
-        by_status[st] = by_status.get(st, 0) + 1
-        tag = "%s %s n=%d pc=%d mode=%d %s" % (kind, np.dtype(dtype).name, n, int(use_pc), mode, smode)
-        scale = max(1.0, float(np.max(np.abs(ref.x))) if n else 1.0)
-        xtol = (5e-3 if single else 1e-7) * scale
-        if st != ref.status:
-            # an outcome may legitimately flip only at a knife edge: convergence test within rounding of the tolerance
-            knife = ref.status in (oracle.OK, oracle.INSUFFICIENT_ITER) and st in (oracle.OK, oracle.INSUFFICIENT_ITER) and mode == 2
-            if not knife:
-                # ... or where the recurrence itself sits on an edge that the summation ORDER decides (a 3 x 3 system in f32 whose
-                # Krylov space is exhausted: beta^2 = 5e-9 against eps on one order, convergence on the other): the oracle with
-                # its reductions in the GPU kernels' order (oracle/krylov_tmpl.h) then takes the GPU's branch
-                oracle.set_reduction_order("gpu", int(sa.default_ctx(0).get("grid")))
-                try:
-                    ref_g = getattr(oracle, kind)(ip, ix, d, rhs, x0, max_iter, tol, **({"precond_diag": pdiag} if use_pc else {}))
-                finally:
-                    oracle.set_reduction_order("reference")
-                knife = ref_g.status == st and (st != oracle.OK or abs(its - ref_g.its) <= max(2, ref_g.its // 8))
-            if knife:
-                soft += 1
-                continue
-            print("HARD outcome mismatch:", tag, "gpu", st, its, "oracle", ref)
-            hard += 1
-            break
-        if st == oracle.OK:
-            bad_its = abs(its - ref.its) > max(2, ref.its // 8)
-            bad_x = float(np.max(np.abs(x - ref.x))) > xtol if n else False
-            if bad_its or bad_x:
-                print("HARD result mismatch:", tag, "gpu its %d res %.3e" % (its, res), "oracle", ref,
-                      "max|dx| %.3e" % float(np.max(np.abs(x - ref.x))))
+def run(budget=60.0, seed=2024, max_cases=None, mode_weights=None, sizes=None, verbose=True):
+    """Fuzz for `budget` seconds or `max_cases` solves (whichever ends first; max_cases alone makes the run deterministic).
+    mode_weights: relative weights of the six input modes (0 plain, 1 zero rhs, 2 tiny max_iter, 3 loose tolerance = converges
+    within its first iterations, 4 non-zero x0, 5 plain); sizes: the size table.  Returns a summary dict; `hard` must be 0."""
+    global rng
+    rng = np.random.default_rng(seed)
+    SZ = list(sizes) if sizes is not None else SIZES
+    mw = np.asarray(mode_weights if mode_weights is not None else [1, 1, 1, 1, 1, 1], dtype=float)
+    mw = mw / mw.sum()
+    t_end = time.time() + budget
+    cases = hard = soft = 0
+    by_status = {}
+    fail = None
+    while time.time() < t_end and (max_cases is None or cases < max_cases):
+        dtype = [np.float64, np.complex128, np.float32, np.complex64][int(rng.integers(0, 4))]
+        is_c = np.dtype(dtype).kind == "c"
+        single = np.dtype(dtype).itemsize in (4, 8) and np.dtype(dtype) in (np.dtype(np.float32), np.dtype(np.complex64))
+        kinds = ["bicgstab", "minres"] + (["csminres"] if is_c else [])
+        kind = kinds[int(rng.integers(0, len(kinds)))]
+        n = int(SZ[int(rng.integers(0, len(SZ)))]) if rng.uniform() < 0.7 else int(rng.integers(1, 400))
+        # MINRES wants a symmetric (real) / Hermitian matrix: use real symmetric data even for complex T; CSMINRES complex-symmetric
+        if kind == "minres":
+            ip, ix, d = banded(n, np.float64 if not single else np.float32, True, False)
+            d = d.astype(dtype)
+        else:
+            ip, ix, d = banded(n, dtype, False, kind == "csminres")
+        mode = int(rng.choice(6, p=mw))
+        rhs = cplx(n, dtype)
+        x0 = np.zeros(n, dtype=dtype)
+        max_iter, tol = 400, (1e-4 if single else 1e-10)
+        if mode == 1:
+            rhs = np.zeros(n, dtype=dtype)                  # rhs = 0: the early return (x = 0, Ok(0, 0))
+        elif mode == 2:
+            max_iter = int(rng.integers(0, 3))              # InsufficientIterNum (or a lucky Ok)
+        elif mode == 3:
+            tol = (0.5, 0.3, 0.1)[int(rng.integers(0, 3))]                                       # loose: Ok after very few iterations
+        elif mode == 4:
+            x0 = cplx(n, dtype)                             # non-zero initial guess
+        use_pc = kind != "csminres" and rng.uniform() < 0.5
+        pdiag = None
+        if use_pc:
+            pdiag = np.abs(np.array([d[ip[i]:ip[i + 1]][ix[ip[i]:ip[i + 1]] == i][0] for i in range(n)])).astype(
+                np.float32 if single else np.float64)       # positive real diagonal (MINRES needs an SPD preconditioner)
+        ref = getattr(oracle, kind)(ip, ix, d, rhs, x0, max_iter, tol, **({"precond_diag": pdiag} if use_pc else {}))
+        A = sa.HipCsr.new((n, n), ip, ix, d)
+        cls = {"bicgstab": sa.BiCGStab, "minres": sa.MinRes, "csminres": sa.CSMinRes}[kind]
+        P = sa.DiagPrecond.new(pdiag, t_dtype=dtype) if use_pc else None
+        for smode in ("fused", "literal"):
+            s = cls.new(A, n); s.set_mode(smode)
+            x = x0.copy()
+            st, its, res = outcome_gpu((lambda: s.precond_solve(P, rhs, x, max_iter, tol)) if use_pc else (lambda: s.solve(rhs, x, max_iter, tol)))
+            cases += 1
+            by_status[st] = by_status.get(st, 0) + 1
+            tag = "%s %s n=%d pc=%d mode=%d %s" % (kind, np.dtype(dtype).name, n, int(use_pc), mode, smode)
+            scale = max(1.0, float(np.max(np.abs(ref.x))) if n else 1.0)
+            xtol = (5e-3 if single else 1e-7) * scale
+            if st != ref.status:
+                # an outcome may legitimately flip only at a knife edge: convergence test within rounding of the tolerance
+                knife = ref.status in (oracle.OK, oracle.INSUFFICIENT_ITER) and st in (oracle.OK, oracle.INSUFFICIENT_ITER) and mode == 2
+                if not knife:
+                    # ... or where the recurrence itself sits on an edge that the summation ORDER decides (a 3 x 3 system in f32 whose
+                    # Krylov space is exhausted: beta^2 = 5e-9 against eps on one order, convergence on the other): the oracle with
+                    # its reductions in the GPU kernels' order (oracle/krylov_tmpl.h) then takes the GPU's branch
+                    oracle.set_reduction_order("gpu", int(sa.default_ctx(0).get("grid")))
+                    try:
+                        ref_g = getattr(oracle, kind)(ip, ix, d, rhs, x0, max_iter, tol, **({"precond_diag": pdiag} if use_pc else {}))
+                    finally:
+                        oracle.set_reduction_order("reference")
+                    knife = ref_g.status == st and (st != oracle.OK or abs(its - ref_g.its) <= max(2, ref_g.its // 8))
+                if knife:
+                    soft += 1
+                    continue
+                print("HARD outcome mismatch:", tag, "gpu", st, its, "oracle", ref)
                 hard += 1
                 break
-            if its != ref.its:
-                soft += 1
-        elif st == oracle.INSUFFICIENT_ITER and its != ref.its:
-            print("HARD its mismatch (InsufficientIterNum):", tag, its, ref)
-            hard += 1
+            if st == oracle.OK:
+                bad_its = abs(its - ref.its) > max(2, ref.its // 8)
+                bad_x = float(np.max(np.abs(x - ref.x))) > xtol if n else False
+                if bad_its or bad_x:
+                    print("HARD result mismatch:", tag, "gpu its %d res %.3e" % (its, res), "oracle", ref,
+                          "max|dx| %.3e" % float(np.max(np.abs(x - ref.x))))
+                    hard += 1
+                    break
+                if its != ref.its:
+                    soft += 1
+            elif st == oracle.INSUFFICIENT_ITER and its != ref.its:
+                print("HARD its mismatch (InsufficientIterNum):", tag, its, ref)
+                hard += 1
+                break
+        if hard:
+            fail = dict(indptr=ip, cols=ix, d=d, rhs=rhs, x0=x0)
             break
-    if hard:
-        np.savez("gpurun_out/fuzz_solver_fail.npz", indptr=ip, cols=ix, d=d, rhs=rhs, x0=x0)
+    return dict(cases=cases, hard=hard, soft=soft, by_status={int(k): v for k, v in sorted(by_status.items())}, fail=fail)
+
+
+if __name__ == "__main__":
+    r = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+    if r["hard"]:
+        import os
+        os.makedirs("gpurun_out", exist_ok=True)
+        np.savez("gpurun_out/fuzz_solver_fail.npz", **r["fail"])
         sys.exit(1)
-print("solver fuzz ok: %d solves (both modes), outcomes %s, %d differed from the oracle by an iteration or two (rounding), 0 hard mismatches"
-      % (cases, {int(k): v for k, v in sorted(by_status.items())}, soft))
+    print("solver fuzz ok: %d solves (both modes), outcomes %s, %d differed from the oracle by an iteration or two (rounding), 0 hard mismatches"
+          % (r["cases"], r["by_status"], r["soft"]))

@@ -85,6 +85,9 @@ __device__ __forceinline__ void reduce_partials2(const TA *__restrict__ pa, cons
 // drains its store (`s_waitcnt vmcnt(0)`) before it counts its arrival with an agent-scope atomic add, and the workgroup
 // whose add returned gridDim.x - 1 loads only after that add has returned (its other waves behind a workgroup barrier) —
 // MI355X_MICROARCH.md, "Valid forms", first row of the sc1 hand-off table.  No cache-wide release / acquire is issued.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "st_through / ld_through / finalize_last_block rely on gfx942 / gfx950 semantics: sc1 accesses write through to / read from memory, and stores count in vmcnt (gfx10+ counts them in vscnt). Port the hand-off (release fetch_add + acquire fence) before building for another target."
+#endif
 __device__ __forceinline__ void st_through(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_through(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_through(cplx *p, cplx v) { st_through(&p->re, v.re); st_through(&p->im, v.im); }
@@ -98,6 +101,17 @@ __device__ __forceinline__ cplxf ld_through(const cplxf *p) { return cplxf{ld_th
 template <class T>
 __device__ __forceinline__ void st_partial(const Fin &fin, T *p, T v) {
     if (fin.counter) st_through(p, v); else *p = v;
+}
+
+// A producer that returns at its first instruction because the solve's status word is no longer "running" leaves its
+// hand-off cells at ZERO: the distributed consumers' in-place all-reduce would otherwise multiply a stale value by the
+// world size once per no-op hand-off (up to 3 * poll of them; f32 would reach inf).  Consumers test the status word
+// before they use a handed-off value, so the zero is never read as data.
+__device__ __forceinline__ void fin_idle(const Fin &fin, bool two) {
+    if (fin.counter == nullptr || blockIdx.x != 0 || threadIdx.x != 0) return;
+    double *a = reinterpret_cast<double *>(fin.out0);
+    a[0] = 0.0; a[1] = 0.0;                                   // a 16-byte cell whatever the scalar type
+    if (two) { double *b = reinterpret_cast<double *>(fin.out1); b[0] = 0.0; b[1] = 0.0; }
 }
 
 // Called by ALL threads of every workgroup after thread 0 has st_partial'ed its partial(s).  Same per-thread addition

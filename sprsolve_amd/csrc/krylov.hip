@@ -180,7 +180,7 @@ struct BicgK5 {
         const T alpha = S->alpha;
         T tt, tr;
         reduce_partials2(partTT, partTR, P, smT, smT2, tt, tr);     // :178, :183
-        if (status != ST_RUNNING) return false;
+        if (status != ST_RUNNING) { fin_idle(fin, true); return false; }
         w = (sre(tt) > 0.0) ? sdiv(tr, tt) : szero<T>();            // :179-186
         na = sneg(alpha); nw = sneg(w);
         accN = 0.0; accR = szero<T>();
@@ -229,7 +229,7 @@ struct MinresM2 {
         const int status = D->status;                               // requested together with the partials
         const Real<T> beta = D->st[par].beta;
         const T alpha = reduce_partials(partAlpha, P, smT);         // :116
-        if (status != ST_RUNNING) return false;
+        if (status != ST_RUNNING) { fin_idle(fin, false); return false; }
         nb = sfromr<T>(-beta);                                      // :117 T::from_real(-beta)
         na = sneg(alpha);                                           // :118
         accD = 0.0; accT = szero<T>();

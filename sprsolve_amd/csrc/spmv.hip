@@ -19,6 +19,7 @@
 //    conj(y).u, so the solvers' dot products cost no extra pass over y.
 #include <algorithm>
 #include <memory>
+#include <system_error>
 #include <thread>
 
 #include "device.hpp"
@@ -41,7 +42,9 @@ static void host_parallel_for(int64_t n, int64_t min_chunk, F &&f) {
     for (int64_t t = 0; t < T; ++t) {
         const int64_t a = t * per, b = std::min<int64_t>(n, a + per);
         if (a >= b) break;
-        th.emplace_back(call, a, b, (int)t);
+        // a thread that cannot be started (std::system_error: resource limits) must not unwind past the joinable ones
+        // already in `th` (std::terminate): its chunk runs here instead
+        try { th.emplace_back(call, a, b, (int)t); } catch (const std::system_error &) { call(a, b, (int)t); }
     }
     for (auto &x : th) x.join();
 }
@@ -165,7 +168,8 @@ int build_rowblocks(sprs_csr *A, const int32_t *rp) {
     }
     if (!from_summaries && rp == nullptr) {
         // (uninitialised storage: value-initialising 200 MB for 50 M rows cost 45 ms before the copy overwrote it)
-        rp_own.reset(new int32_t[(size_t)n + 1]);
+        rp_own.reset(new (std::nothrow) int32_t[(size_t)n + 1]);
+        if (!rp_own) { snprintf(c->err, sizeof(c->err), "build_rowblocks: no host memory for %lld row_ptr entries", (long long)n + 1); return SPRS_ERR_HIP; }
         SPRS_HIP_TRY(c, hipMemcpyAsync(rp_own.get(), A->row_ptr, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, c->stream));
         SPRS_HIP_TRY(c, hipStreamSynchronize(c->stream));
         rp = rp_own.get();
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
     // duplicates hit the same cache line.
     for (; b < bend; b += bstep) {
         const BlkDesc d = desc[order ? order[b] : b];
-        if (run_state != ST_RUNNING) return;       // uniform over the grid; nothing has been stored yet
+        if (run_state != ST_RUNNING) { fin_idle(fin, DOT == 2); return; }       // uniform over the grid; nothing has been stored yet
         // eq_desc: the descriptors are the flagged copy (bit 30 of rb = equal-length rows; only built when nrows < 2^30)
         const bool eq_rows = eq_desc != 0 && ((uint32_t)d.rb & UNI2) != 0;
         const int ra = d.ra, rb = d.rb & (eq_desc ? 0x3fffffff : 0x7fffffff);
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_kernel(int n_rowblk, int xcd_chunk
             }
         }
     }
-    if (run_state != ST_RUNNING) return;           // a wavefront that had no row block comes straight here
+    if (run_state != ST_RUNNING) { fin_idle(fin, DOT == 2); return; }           // a wavefront that had no row block comes straight here
     if (DOT >= 1) {
         d0 = block_sum(d0, red);
         if (tid == 0) st_partial(fin, part0 + blockIdx.x, d0);
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_wide_kernel(int n_rowblk, int xcd_
     const D2v *val2 = reinterpret_cast<const D2v *>(val);
     for (; b < bend; b += bstep) {
         const BlkDesc d = desc[order ? order[b] : b];
-        if (run_state != ST_RUNNING) return;
+        if (run_state != ST_RUNNING) { fin_idle(fin, DOT == 2); return; }
         const bool eq_rows = eq_desc != 0 && ((uint32_t)d.rb & UNI2) != 0;
         const int ra = d.ra, rb = d.rb & (eq_desc ? 0x3fffffff : 0x7fffffff);
         if (d.rb >= 0) {
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_wide_kernel(int n_rowblk, int xcd_
             }
         }
     }
-    if (run_state != ST_RUNNING) return;
+    if (run_state != ST_RUNNING) { fin_idle(fin, DOT == 2); return; }
     if (DOT >= 1) {
         d0 = block_sum(d0, red);
         if (tid == 0) st_partial(fin, part0 + blockIdx.x, d0);

@@ -39,13 +39,12 @@
 #include <cstring>
 #include <map>
 
-#include "device.hpp"
+#include "spmv_dict_dev.hpp"
 
 namespace sprs {
 
 namespace {
 
-constexpr int TAB = 256;          // dictionary entries (one byte per code)
 constexpr int HSLOTS = 1024;      // open-addressing table used while collecting (4x the dictionary)
 constexpr uint32_t EMPTY32 = 0x80000000u;            // INT32_MIN: never a valid col - row (|.| < 2^31 - 1)
 constexpr uint64_t EMPTY64 = 0xFFFFFFFFFFFFFFFFull;  // a NaN pattern; a matrix holding it is not compressed
@@ -249,239 +248,6 @@ __global__ __launch_bounds__(BLOCK) void dict_pair_encode_kernel(int64_t nnz, co
         pair_code[k] = pair_of[idx_code[k] | (val_code[k] << 8)];
 }
 
-// ---------------------------------------------------------------------------------------------------------
-constexpr int CPAD = 16;    // readable bytes behind a block's codes: the row phase reads up to 7 + 3 bytes past them
-
-// LDS table entry of the pair stream: byte offset of the column relative to the row, and the value
-template <class T> struct alignas(sizeof(T) >= 8 ? 16 : 8) PairEnt { int32_t off8; T val; };
-
-// What a wavefront loads for one row block before it can work on it.  The loads of block i+1 are issued
-// before block i is processed (and the descriptor of block i+2 before that), so a block costs one exposed
-// memory round trip — its x gather — instead of three dependent ones (descriptor -> codes/row_ptr -> x).
-template <class T, bool PAIR, int ITEMS>
-struct BlkLoads {
-    int ra, rb, pa, nn;      // descriptor (nn = entries of the block, also for uniform blocks)
-    int ulen;                // > 0: uniform block — every row repeats the first row's ulen (<= UNI_OFF_MAXLEN) codes; no row_ptr, 1-9 code dwords
-    int s;                   // row_ptr[row] of this lane's row
-    T uu;                    // dot operand of this lane's row
-    uint32_t wc[2];          // code dwords
-    int di[2];               // ... and the LDS slots they go to
-    T vv[PAIR ? 1 : ITEMS];  // values (offset-code stream only)
-};
-
-// WV (f64 offset codes only): the block's values are read with 16 bytes per lane over its 16-byte-aligned window (entries
-// 2l, 2l + 1 of [pa - (pa & 1), ..) per load: 4 loads per 512 entries instead of 8) and staged to LDS with 16-byte stores;
-// the last 2-entry group of val, which may reach one entry past the array, comes from the handle's zero-padded tail copy.
-struct alignas(16) V2d { double a, b; };
-// The walk of the 64-row-block kernels of the compressed streams over `n_rowblk` blocks (positions of `order`, or natural
-// order), shared by spmv_dict_kernel (the whole matrix) and spmv_tile_kernel's offset-code flavour (the blocks outside its
-// tiles).  s_pair / s_off8: the staged tables; s_c: NWAVE zeroed code slices of CW dwords; s_v: NWAVE zeroed value slices of
-// s_v_stride (>= CAP + 16) entries, 16-byte aligned (offset-code stream).  d0 / d1: the lane's running dot partials.
-template <class T, int DOT, bool CONJX, bool PAIR, bool WV>
-__device__ __forceinline__ void dict_walk(int n_rowblk, int xcd_chunk, const BlkDesc *__restrict__ desc, const int32_t *__restrict__ order,
-                                          const int32_t *__restrict__ row_ptr, const uint8_t *__restrict__ code,
-                                          const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y, const T *__restrict__ u,
-                                          const V2d *__restrict__ tail2, int g2_last,
-                                          const PairEnt<T> *s_pair, const int32_t *s_off8, uint32_t (*s_c)[(nnz_cap<T>::value + 3 + CPAD + 3) / 4],
-                                          T *s_v, int s_v_stride, T &d0, T &d1) {
-    constexpr int CAP = nnz_cap<T>::value;          // nnz per row block (per wavefront)
-    constexpr int ITEMS = CAP / WAVE;
-    using Loads = BlkLoads<T, PAIR, ITEMS>;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint8_t *cb = reinterpret_cast<const uint8_t *>(s_c[wv]);
-    [[maybe_unused]] T *vs = s_v + (PAIR ? 0 : wv) * (size_t)s_v_stride;
-    const char *xbytes = reinterpret_cast<const char *>(x);
-
-    int b, bstep, bend;                             // the persistent walk of spmv.hip
-    if (xcd_chunk) {
-        const int chunk = (n_rowblk + 7) >> 3;
-        const int xcd = blockIdx.x & 7;
-        b = xcd * chunk + (blockIdx.x >> 3) * NWAVE + wv;
-        bstep = (gridDim.x >> 3) * NWAVE;
-        bend = min(n_rowblk, (xcd + 1) * chunk);
-    } else {
-        b = blockIdx.x * NWAVE + wv; bstep = gridDim.x * NWAVE; bend = n_rowblk;
-    }
-    if (b >= bend) b = bend;                        // falls through to the partial sums below
-
-    // Descriptors (and schedule entries) are fetched with VECTOR loads on a wave-uniform address: scalar loads
-    // return out of order, so one in flight would turn every later LDS wait into a full lgkmcnt(0) stall.
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    typedef const v4i __attribute__((address_space(1))) *gv4i_p;
-    typedef const int32_t __attribute__((address_space(1))) *gi32_p;
-    uintptr_t desc_a = reinterpret_cast<uintptr_t>(desc), order_a = reinterpret_cast<uintptr_t>(order);
-    asm volatile("" : "+v"(desc_a));                // hide the uniformity: keeps the loads on the vector path
-    asm volatile("" : "+v"(order_a));
-    const gv4i_p desc_v = reinterpret_cast<gv4i_p>(desc_a);
-    const gi32_p order_v = reinterpret_cast<gi32_p>(order_a);
-    auto load_desc = [&](int bi) -> BlkDesc { const v4i q = desc_v[bi]; return BlkDesc{q.x, q.y, q.z, q.w}; };
-    auto block_index = [&](int bi) -> int { return order ? order_v[bi] : bi; };
-    // ... and turned back into scalars where they are consumed, so that everything derived from a descriptor
-    // (block bounds, code alignment, branch conditions) is scalar-ALU work instead of 64-lane vector work
-    auto uniform = [&](const BlkDesc &d) -> BlkDesc {
-        return BlkDesc{__builtin_amdgcn_readfirstlane(d.ra), __builtin_amdgcn_readfirstlane(d.rb),
-                       __builtin_amdgcn_readfirstlane(d.pa), __builtin_amdgcn_readfirstlane(d.nn)};
-    };
-    // Phase 1 of a block: issue its loads (unconditional, clamped addresses: they go out back to back).
-    // Nothing here uses a loaded value, so the wavefront does not wait.
-    auto issue = [&](const BlkDesc &d, Loads &L) {
-        // dictionary matrices have no vector blocks (bit 31); bit 30 = uniform block (descriptors of the offset-code
-        // stream only, mark_uniform_kernel): its nn field holds the common row length, not the block's entry count
-        L.ra = d.ra; L.rb = d.rb & 0x3fffffff; L.pa = d.pa;
-        const bool uni = ((uint32_t)d.rb & UNI2) != 0;                     // scalar
-        L.ulen = uni ? d.nn : 0;
-        L.nn = uni ? (L.rb - L.ra) * d.nn : d.nn;
-        const int r = L.ra + lane;
-        const int rcl = r < L.rb ? r : L.rb - 1;
-        // uniform base + 32-bit lane offset everywhere (launch checks the sizes): no 64-bit address arithmetic
-        if (uni) L.s = L.pa + (rcl - L.ra) * L.ulen;                       // every row has ulen entries: row_ptr is not read
-        else L.s = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(row_ptr) + (uint32_t)rcl * 4u);   // row_ptr[row + 1] comes from the next lane (adopt)
-        if (DOT != 0) L.uu = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(u) + (uint32_t)rcl * (uint32_t)sizeof(T));
-        const int shift = L.pa & 3;
-        // dwords covering [pa, pa + nn) (<= CAP/4 + 1) — of a uniform block only the first row's codes: 1-9 dwords
-        const int nd = max((shift + (uni ? L.ulen : L.nn) + 3) >> 2, 1);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            L.di[i] = min(lane + i * WAVE, nd - 1);
-            L.wc[i] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(code) + (uint32_t)(L.pa - shift + 4 * L.di[i]));
-        }
-        if constexpr (!PAIR) {
-            [[maybe_unused]] const int last = max(L.nn - 1, 0);
-            if constexpr (WV) {
-                const int vsh = L.pa & 1, g0 = (L.pa - vsh) >> 1, lastq = max(L.nn + vsh - 1, 0) >> 1;
-                const V2d *val2 = reinterpret_cast<const V2d *>(val);
-#pragma unroll
-                for (int i = 0; i < ITEMS / 2; ++i) {
-                    const int G = g0 + min(lane + i * WAVE, lastq);
-                    const V2d q = *(G == g2_last ? tail2 : val2 + G);
-                    L.vv[2 * i] = q.a; L.vv[2 * i + 1] = q.b;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < ITEMS; ++i) L.vv[i] = val[L.pa + min(lane + i * WAVE, last)];
-            }
-        }
-    };
-    // Phase 2: the loads have landed — put the code bytes (and values) into this wavefront's LDS slice.
-    // Called when the slice is free: before the first block and at the bottom of the loop, after the row
-    // phase of the previous block has consumed it.
-    auto stage = [&](const Loads &L) {
-        const int shift = L.pa & 3;
-        if (L.nn > 0) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) s_c[wv][L.di[i]] = L.wc[i];   // clamped duplicates store the same dword to the same slot
-            if constexpr (CAP / 4 + 1 > 2 * WAVE) {
-                if (L.ulen == 0 && ((shift + L.nn + 3) >> 2) > 2 * WAVE && lane == 0)     // the 129th dword exists only when shift + nn > 512
-                    s_c[wv][2 * WAVE] = reinterpret_cast<const uint32_t *>(code + (L.pa - shift))[2 * WAVE];
-            }
-            if constexpr (!PAIR) {
-                if constexpr (WV) {
-                    const int tot = L.nn + (L.pa & 1);                  // window order: vs[k] = val[pa - (pa & 1) + k]
-#pragma unroll
-                    for (int i = 0; i < ITEMS / 2; ++i) {
-                        const int k = 2 * (lane + i * WAVE);
-                        if (k < tot) *reinterpret_cast<V2d *>(vs + k) = V2d{L.vv[2 * i], L.vv[2 * i + 1]};
-                    }
-                } else {
-#pragma unroll
-                for (int i = 0; i < ITEMS; ++i) {
-                    const int k = lane + i * WAVE;
-                    if (k < L.nn) vs[k] = L.vv[i];
-                }
-                }
-            }
-        }
-    };
-
-    // loop-carried state of the block being processed: plain values, no load in flight behind them
-    int c_ra = 0, c_rb = 0, c_s = 0, c_len = 0, c_shift = 0;
-    [[maybe_unused]] int c_vsh = 0;       // WV: the staged values start this many entries into the wavefront's slice
-    bool c_uni = false;      // scalar: every lane reads the FIRST row's codes
-    T c_uu = szero<T>();
-    auto adopt = [&](const Loads &L) {
-        const int r = L.ra + lane;
-        c_ra = L.ra; c_rb = L.rb; c_shift = L.pa & 3; c_uni = L.ulen > 0;
-        if constexpr (WV) c_vsh = L.pa & 1;
-        c_s = L.s - L.pa;
-        int e = __shfl_down(L.s, 1, WAVE);          // next row's start; the block's last row ends at pa + nn
-        if (r == L.rb - 1) e = L.pa + L.nn;
-        c_len = r < L.rb ? e - L.s : 0;
-        if (DOT != 0) c_uu = L.uu;
-    };
-    // Software pipeline, everything consumed one iteration after it was requested:
-    //   top of iteration i:    issue loads of block i+1 (descriptor dn), descriptor of block i+2 (index o2),
-    //                          schedule entry of block i+3
-    //   middle:                row phase of block i — its x gather is the only exposed memory round trip
-    //   bottom:                stage block i+1 into LDS, rotate dn <- dn2, o2 <- o3
-    BlkDesc dn{0, 1, 0, 0};
-    int o2 = 0;
-    if (b < bend) {
-        Loads first;
-        issue(uniform(load_desc(__builtin_amdgcn_readfirstlane(block_index(b)))), first);
-        if (b + bstep < bend) dn = uniform(load_desc(__builtin_amdgcn_readfirstlane(block_index(b + bstep))));
-        if (b + 2 * bstep < bend) o2 = __builtin_amdgcn_readfirstlane(block_index(b + 2 * bstep));
-        stage(first);
-        adopt(first);
-    }
-    for (; b < bend; b += bstep) {
-        const bool more = b + bstep < bend;
-        Loads nxt;
-        BlkDesc dn2{0, 1, 0, 0};
-        int o3 = 0;
-        if (b + 2 * bstep < bend) dn2 = load_desc(o2);
-        if (b + 3 * bstep < bend) o3 = block_index(b + 3 * bstep);
-        if (more) issue(dn, nxt);
-        wave_lds_fence();
-        // ---- one lane per row: mat.rs:100-105, fold(T::zero(), |acc, (col, val)| acc + x[col] * val)
-        const int r = c_ra + lane;
-        const uint32_t r8 = (uint32_t)r * (uint32_t)sizeof(T);     // byte offset of x[row]; launch checks ncols*sizeof(T) < 4 GiB
-        const int s = c_s, len = c_len;
-        T acc = szero<T>();
-        for (int j0 = 0; __builtin_amdgcn_ballot_w64(j0 < len) != 0; j0 += 8) {
-            // slots past a row's end read the (in-bounds, stale or zero) bytes behind it and are dropped below;
-            // one clamp per chunk keeps the whole chunk inside the wavefront's slice
-            const int kb = min(s + j0, CAP);
-            const uint8_t *cp = cb + c_shift + (c_uni ? j0 : kb);    // uniform block: the first row's codes, at one address for all lanes
-            T xg[8], av[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) { xg[t] = szero<T>(); av[t] = szero<T>(); }
-            // slots 4..7 are skipped (scalar branch) when no row of the block is that long: a 5-point row wastes
-            // none of the LDS look-ups and gathers of slots 5..7, a 7-point row none of slot 7
-            const uint64_t m4 = __builtin_amdgcn_ballot_w64(j0 + 4 < len), m5 = __builtin_amdgcn_ballot_w64(j0 + 5 < len),
-                           m6 = __builtin_amdgcn_ballot_w64(j0 + 6 < len), m7 = __builtin_amdgcn_ballot_w64(j0 + 7 < len);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (t == 4 && m4 == 0) break;
-                if (t == 5 && m5 == 0) break;
-                if (t == 6 && m6 == 0) break;
-                if (t == 7 && m7 == 0) break;
-                const bool valid = j0 + t < len;
-                const int cd = cp[t];
-                int off8;
-                if constexpr (PAIR) { const PairEnt<T> e = s_pair[cd]; off8 = e.off8; av[t] = e.val; }
-                else { off8 = s_off8[cd]; av[t] = vs[(WV ? c_vsh : 0) + kb + t]; }
-                const uint32_t vo = valid ? r8 + (uint32_t)off8 : 0u;     // lanes past their row gather x[0] and drop it
-                xg[t] = *reinterpret_cast<const T *>(xbytes + vo);
-            }
-            // all 8 gathers go out before the first product is formed (the scheduler otherwise hoists the
-            // first multiply between them and with it a wait for the first gather: two round trips per block)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-                if (j0 + t < len) acc = sadd(acc, smul(CONJX ? sconj(xg[t]) : xg[t], av[t]));
-        }
-        if (r < c_rb) {
-            *reinterpret_cast<T *>(reinterpret_cast<char *>(y) + r8) = acc;
-            if (DOT == 1) d0 = sadd(d0, smul(sconj(c_uu), acc));
-            if (DOT == 2) { d0 = sadd(d0, smul(sconj(acc), acc)); d1 = sadd(d1, smul(sconj(acc), c_uu)); }
-        }
-        wave_lds_fence();   // the row phase is done with the LDS slice: refill it for the next block
-        if (more) { stage(nxt); adopt(nxt); }
-        dn = uniform(dn2); o2 = __builtin_amdgcn_readfirstlane(o3);
-    }
-}
-
 template <class T, int DOT, bool CONJX, bool PAIR, bool WV = false>
 __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_chunk, const BlkDesc *__restrict__ desc,
                                                           const int32_t *__restrict__ order,
@@ -513,7 +279,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
     for (int i = lane; i < CW; i += WAVE) s_c[wv][i] = 0;       // the pad is read (and ignored) before it is ever written
     if constexpr (!PAIR) for (int i = lane; i < CAP + 16; i += WAVE) s_v[wv][i] = szero<T>();
     __syncthreads();                                // the only workgroup barrier: tables are read-only afterwards
-    if (run_state != ST_RUNNING) return;
+    if (run_state != ST_RUNNING) { fin_idle(fin, DOT == 2); return; }
 
     T d0 = szero<T>(), d1 = szero<T>();
     dict_walk<T, DOT, CONJX, PAIR, WV>(n_rowblk, xcd_chunk, desc, order, row_ptr, code, val, x, y, u, tail2, g2_last, s_pair, s_off8, s_c,
@@ -528,23 +294,6 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
     }
     if (DOT >= 1 && fin.counter) finalize_last_block<T, T>(fin, DOT == 2, red, red);
 }
-
-// ---------------------------------------------------------------------------------------------------------
-// Two rows per lane (f64, pair codes).  A 64-lane 8-byte gather costs the CU's vector-memory pipe ~14.4 cycles
-// whatever it touches — the same as a 16-byte one (scripts/micro/ta_rate.hip) — and the x gathers are most of the
-// pipe's work in the kernel above.  Here lane l owns rows ra + 2l and ra + 2l + 1 of a 128-row block; where both
-// rows have the same column offset in a slot (every interior row of a stencil) ONE 16-byte load returns x for
-// both, as does one 16-byte load for u and one 16-byte store for y.  Rows whose slots disagree (grid boundaries,
-// irregular rows) take an extra 8-byte gather for the second row, issued only if some lane of the wavefront needs
-// it.  Same fold per row (left to right from zero): y stays bit-identical; the fused dot partials group the rows
-// differently, so those reductions differ from the 64-row kernel's in summation order only.
-struct alignas(16) D2 { double lo, hi; };
-typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-constexpr int CAP2 = 2 * nnz_cap<double>::value;          // 1024 code bytes per wide block
-constexpr int CW2 = (CAP2 + 3 + CPAD + 15) / 16 * 4;      // dwords of a wavefront's slice (multiple of 4: b128 stores)
-
-constexpr int UNI_OFF_MAXLEN = 32;          // offset-code stream: the pattern is read from the staged first row, chunk by chunk
-constexpr int UNI2_MAXLEN = 8;              // ... of at most this many codes; the descriptor's nn then holds that length
 
 // One wavefront per 128-row block: are all its rows copies of the first one (same length, same codes)?  Interior
 // rows of a constant-coefficient stencil are; such a block needs neither its 1 KiB of codes nor row_ptr — the
@@ -661,345 +410,6 @@ __global__ __launch_bounds__(BLOCK) void mark_uniform_kernel(int n_wide, BlkDesc
     }
 }
 
-// FULL uniform block of the two-rows-per-lane kernels (every lane has both rows — the interior of a stencil): no row
-// masks, and no clamp either: the second row's column r0 + 1 + off is valid, so the 16-byte load at r0 + off stays
-// inside x.  Offset and value of a slot are wave-uniform: made scalars, the gather is SGPR base + lane offset and the
-// products take the value from SGPRs — 4 vector ALU instructions per slot instead of ~25 (the kernel ran at 43 % VALU
-// utilisation, profiles/r02_tuning.md §9).
-//
-// UL, SC > 0 (compile time): the pattern has UL slots and a column triple (c - 1, c, c + 1) in slots SC - 1, SC, SC + 1
-// (mark_uniform_kernel).  The outer two are not loaded: lane l's x[r0 - 1 + o] is lane l - 1's second half of the
-// centre pair, x[r0 + 2 + o] lane l + 1's first half (wavefront shifts); the two ends of the block come from two
-// scalar loads.  UL - 2 vector loads instead of UL, all issued in straight-line code.
-// UL == 0: run-time length `ulen`, every slot loaded.  after_loads() runs between the last load and the first product.
-__device__ __forceinline__ double wave_shift_up(double prev_for_lane0, double v) {       // lane l <- lane l - 1
-    const long long o = __double_as_longlong(prev_for_lane0), q = __double_as_longlong(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)q, 0x138, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(q >> 32), 0x138, 0xf, 0xf, false);
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-__device__ __forceinline__ double wave_shift_down(double next_for_last_lane, double v) { // lane l <- lane l + 1
-    const long long o = __double_as_longlong(next_for_last_lane), q = __double_as_longlong(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)q, 0x130, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(q >> 32), 0x130, 0xf, 0xf, false);
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-template <int UL, int SC, class AfterLoads>
-__device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair, uint64_t pat, int ulen, bool seam, int seam1, int seam2, const char *xbytes,
-                                                   uint32_t r8, uint32_t ra8, int lane, AfterLoads &&after_loads,
-                                                   double &acc0, double &acc1) {
-    using T = double;
-    T pl[8], ph[8], av[8];
-    int off8c = 0;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; av[t] = 0.0; }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        if (UL == 0 ? t >= ulen : t >= UL) break;
-        const PairEnt<T> e = s_pair[(int)((pat >> (8 * t)) & 255u)];
-        const int off8 = __builtin_amdgcn_readfirstlane(e.off8);
-        const uint32_t vlo = __builtin_amdgcn_readfirstlane((int)(uint32_t)__double_as_longlong(e.val));
-        const uint32_t vhi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(__double_as_longlong(e.val) >> 32));
-        av[t] = __longlong_as_double((long long)(((uint64_t)vhi << 32) | vlo));
-        if (SC > 0 && (t == SC - 1 || t == SC + 1)) continue;
-        const D2 px = *reinterpret_cast<const D2 *>(xbytes + (int64_t)off8 + r8);
-        pl[t] = px.lo; ph[t] = px.hi;
-        if (SC > 0 && t == SC) off8c = off8;
-    }
-    // the two ends of the block, x[ra - 1 + o] and x[ra + 128 + o]: wave-uniform addresses, read through the SCALAR
-    // cache after the last LDS read of the block (scalar loads return out of order and share the LDS counter) — a
-    // 64-lane load of them would cost the vector-memory pipe as much as a gather
-    T e_lo = 0.0, e_hi = 0.0;
-    if (SC > 0) {
-        const T *xe = reinterpret_cast<const T *>(xbytes + (int64_t)off8c + ra8);
-        e_lo = xe[-1]; e_hi = xe[2 * WAVE];
-    }
-    after_loads();
-    __builtin_amdgcn_sched_barrier(0);
-    if (SC > 0) {
-        constexpr int C = SC > 0 ? SC : 1;
-        const T left = wave_shift_up(e_lo, ph[C]), right = wave_shift_down(e_hi, pl[C]);
-        pl[C - 1] = left; ph[C - 1] = pl[C];
-        pl[C + 1] = ph[C]; ph[C + 1] = right;
-    }
-    if (!seam) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            if (UL == 0 ? t >= ulen : t >= UL) break;
-            acc0 = acc0 + pl[t] * av[t];
-            acc1 = acc1 + ph[t] * av[t];
-        }
-    } else {
-        // seam block: local rows k and k + 1 fold only the slots of their masks, with their own value where they carry one
-        // (a row with a value of its own has exactly one slot)
-        const int k = seam1 & 127, maskA = (seam1 >> 7) & 255, maskB = seam2 & 255;
-        const T valA = s_pair[(seam2 >> 8) & 255].val, valB = s_pair[(seam2 >> 16) & 255].val;
-        const bool ovA = ((seam2 >> 24) & 1) != 0, ovB = ((seam2 >> 25) & 1) != 0;
-        const bool a0 = 2 * lane == k, a1 = 2 * lane + 1 == k, b0 = 2 * lane == k + 1, b1 = 2 * lane + 1 == k + 1;
-        const int pm0 = a0 ? maskA : (b0 ? maskB : 255), pm1 = a1 ? maskA : (b1 ? maskB : 255);
-        const bool o0 = (a0 && ovA) || (b0 && ovB), o1 = (a1 && ovA) || (b1 && ovB);
-        const T v0 = a0 ? valA : valB, v1 = a1 ? valA : valB;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            if (UL == 0 ? t >= ulen : t >= UL) break;
-            const T n0 = acc0 + pl[t] * (o0 ? v0 : av[t]), n1 = acc1 + ph[t] * (o1 ? v1 : av[t]);
-            acc0 = ((pm0 >> t) & 1) ? n0 : acc0;
-            acc1 = ((pm1 >> t) & 1) ? n1 : acc1;
-        }
-    }
-}
-template <class AfterLoads>
-__device__ __forceinline__ void full_uniform_dispatch(const PairEnt<double> *s_pair, uint64_t pat, int ulen, int sc, bool seam, int seam1, int seam2, const char *xbytes,
-                                                      uint32_t r8, uint32_t ra8, int lane, AfterLoads &&after_loads,
-                                                      double &acc0, double &acc1) {
-    // (scalar branches) the stencils: 7-point 3-D, 5-point 2-D, 3-point 1-D with sorted columns; anything else generic
-    if (ulen == 7 && sc == 3) full_uniform_block<7, 3>(s_pair, pat, ulen, seam, seam1, seam2, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
-    else if (ulen == 5 && sc == 2) full_uniform_block<5, 2>(s_pair, pat, ulen, seam, seam1, seam2, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
-    else if (ulen == 3 && sc == 1) full_uniform_block<3, 1>(s_pair, pat, ulen, seam, seam1, seam2, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
-    else full_uniform_block<0, 0>(s_pair, pat, ulen, seam, seam1, seam2, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
-}
-
-
-struct Blk2Loads {
-    int ra, rb, pa, nn;      // descriptor of the 128-row block
-    bool uni; int ulen;      // uniform block (every row = the first row's ulen codes)
-    int tri;                 // ... and the slot of its column triple's centre (0: none)
-    bool is_seam; int seam1, seam2;   // ... or uniform but for one or two rows (mark_uniform_kernel's encoding: nn >> 16, rb's low bits)
-    int a, b;                // row_ptr[i0], row_ptr[i0 + 1], i0 = min(ra + 2 lane, rb - 1)
-    double u0, u1;           // dot operands of the lane's two rows
-    u4v wc;                  // 16 code bytes
-    int di;                  // ... and the b128 slot they go to
-};
-
-// The walk of the two-rows-per-lane kernels over `n_wide` 128-row blocks (positions of `order`, or natural order): a
-// wavefront takes every (gridDim.x * NWAVE)-th position, the next block's loads are issued before this block's products.
-// Shared by spmv_pair2_kernel (the whole matrix) and spmv_tile_kernel (the blocks outside its tiles).  d0 / d1: the
-// lane's running dot partials (DOT as in launch_spmv).  s_pair: the staged (byte offset, value) table; s_c: NWAVE
-// zero-initialised code slices.
-// YNT: y is written with non-temporal stores (HBM-sized vectors: the result is not read again before it has been evicted)
-template <int DOT, bool YNT>
-__device__ __forceinline__ void pair2_walk(int n_wide, int xcd_chunk, const BlkDesc *__restrict__ desc,
-                                           const int32_t *__restrict__ order, const int32_t *__restrict__ row_ptr,
-                                           const uint8_t *__restrict__ code, const double *__restrict__ x,
-                                           double *__restrict__ y, const double *__restrict__ u, int nrows, int ncols,
-                                           const PairEnt<double> *s_pair, uint32_t (*s_c)[CW2], double &d0, double &d1) {
-    using T = double;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint8_t *cb = reinterpret_cast<const uint8_t *>(s_c[wv]);
-    const char *xbytes = reinterpret_cast<const char *>(x);
-    const uint32_t xlast_pair = (uint32_t)(ncols - 2) * 8u;                    // last byte offset a 16-byte x load may start at
-
-    int b, bstep, bend;
-    if (xcd_chunk) {
-        const int chunk = (n_wide + 7) >> 3;
-        const int xcd = blockIdx.x & 7;
-        b = xcd * chunk + (blockIdx.x >> 3) * NWAVE + wv;
-        bstep = (gridDim.x >> 3) * NWAVE;
-        bend = min(n_wide, (xcd + 1) * chunk);
-    } else {
-        b = blockIdx.x * NWAVE + wv; bstep = gridDim.x * NWAVE; bend = n_wide;
-    }
-    if (b >= bend) b = bend;
-
-    typedef const int32_t __attribute__((address_space(1))) *gi32_p;
-    uintptr_t order_a = reinterpret_cast<uintptr_t>(order);
-    asm volatile("" : "+v"(order_a));               // vector (in-order, 4 bytes per lane) loads of the walk order
-    const gi32_p order_v = reinterpret_cast<gi32_p>(order_a);
-    // descriptors: wave-uniform index, read through the scalar cache (`desc` must stay un-captured for that: the
-    // compiler only uses scalar loads on memory it can prove nothing in the kernel writes)
-    auto load_desc = [&](int bi) -> BlkDesc { return desc[bi]; };
-    auto block_index = [&](int bi) -> int { return order ? order_v[bi] : bi; };
-    auto uniform = [&](const BlkDesc &d) -> BlkDesc {
-        return BlkDesc{__builtin_amdgcn_readfirstlane(d.ra), __builtin_amdgcn_readfirstlane(d.rb),
-                       __builtin_amdgcn_readfirstlane(d.pa), __builtin_amdgcn_readfirstlane(d.nn)};
-    };
-    auto issue = [&](const BlkDesc &d, Blk2Loads &L) {
-        L.uni = ((uint32_t)d.rb & UNI2) != 0;                                   // scalar: all rows share one code sequence of d.nn codes
-        L.is_seam = L.uni && ((uint32_t)d.rb & SEAM2) != 0;                     // ... but for one or two of them
-        L.ra = d.ra; L.rb = L.is_seam ? d.ra + 2 * WAVE : (int)((uint32_t)d.rb & ~UNI2); L.pa = d.pa;
-        L.ulen = L.uni ? (d.nn & 0xff) : 0;
-        L.tri = L.uni ? ((d.nn >> 8) & 0xff) : 0;
-        L.seam1 = L.is_seam ? (d.nn >> 16) : 0;
-        L.seam2 = L.is_seam ? (int)((uint32_t)d.rb & 0x3ffffffu) : 0;
-        L.nn = L.uni ? L.ulen * (L.rb - L.ra) : d.nn;
-        const int r0 = L.ra + 2 * lane;
-        L.a = 0; L.b = 0;
-        if (!L.uni) {                                                           // a uniform block needs no row_ptr
-            const int i0 = min(r0, L.rb - 1);                                   // row_ptr[i0 + 1] exists: i0 + 1 <= rb <= nrows
-            const int2 ab = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(row_ptr) + (uint32_t)i0 * 4u);
-            L.a = ab.x; L.b = ab.y;
-        }
-        if (DOT != 0) {
-            const int p0 = min(r0, nrows - 2);                                  // the pair (u[p0], u[p0 + 1]) is inside u
-            const D2 uu = *reinterpret_cast<const D2 *>(reinterpret_cast<const char *>(u) + (uint32_t)p0 * 8u);
-            L.u0 = r0 == p0 ? uu.lo : uu.hi;                                    // r0 == nrows - 1: its operand is the pair's second half
-            L.u1 = uu.hi;
-        }
-        const int shift = L.pa & 3;
-        const int nq = L.uni ? 1 : max((shift + L.nn + 15) >> 4, 1);            // 16-byte pieces covering the codes, <= 65 (uniform: the first row's only)
-        L.di = min(lane, nq - 1);
-        L.wc = *reinterpret_cast<const u4v *>(reinterpret_cast<const char *>(code) + (uint32_t)(L.pa - shift + 16 * L.di));
-    };
-    int c_ra = 0, c_rb = 0, c_shift = 0, c_s0 = 0, c_s1 = 0, c_len0 = 0, c_len1 = 0;
-    bool c_uni = false;
-    uint64_t c_pat = 0;      // uniform block: its (at most 8) codes, first code in the low byte
-    int c_tri = 0;           // ... and the centre slot of its column triple
-    bool c_seam = false;     // ... or uniform but for one or two rows:
-    int c_seam1 = 0, c_seam2 = 0;
-    T c_u0 = 0.0, c_u1 = 0.0;
-    auto stage = [&](const Blk2Loads &L) {
-        const int shift = L.pa & 3;
-        c_uni = L.uni;
-        if (L.uni) {
-            // every lane holds the same 16 bytes [pa - shift, pa - shift + 16): the pattern starts `shift` bytes in
-            const uint64_t lo = (uint64_t)__builtin_amdgcn_readfirstlane(L.wc.x) | ((uint64_t)__builtin_amdgcn_readfirstlane(L.wc.y) << 32);
-            const uint64_t hi = (uint64_t)__builtin_amdgcn_readfirstlane(L.wc.z);
-            c_pat = shift ? (lo >> (8 * shift)) | (hi << (64 - 8 * shift)) : lo;
-            const int r0 = L.ra + 2 * lane;
-            c_ra = L.ra; c_rb = L.rb; c_shift = shift; c_tri = L.tri; c_seam = L.is_seam; c_seam1 = L.seam1; c_seam2 = L.seam2;
-            c_s0 = 0; c_s1 = 0;
-            c_len0 = r0 < L.rb ? L.ulen : 0;
-            c_len1 = r0 + 1 < L.rb ? L.ulen : 0;
-            if (DOT != 0) { c_u0 = L.u0; c_u1 = L.u1; }
-            return;
-        }
-        if (L.nn > 0) {
-            *reinterpret_cast<u4v *>(&s_c[wv][4 * L.di]) = L.wc;               // clamped duplicates store the same 16 bytes
-            if (shift + L.nn > CAP2 && lane == 0)                               // the 65th piece exists only then: one dword is enough
-                s_c[wv][CAP2 / 4] = *reinterpret_cast<const uint32_t *>(code + (L.pa - shift) + CAP2);
-        }
-        const int r0 = L.ra + 2 * lane;
-        int c = __shfl_down(L.a, 1, WAVE);                                      // row_ptr[r0 + 2] sits in the next lane
-        if (r0 + 2 >= L.rb) c = L.pa + L.nn;                                    // ... unless the block ends there
-        c_ra = L.ra; c_rb = L.rb; c_shift = shift;
-        c_s0 = L.a - L.pa; c_s1 = L.b - L.pa;
-        c_len0 = r0 < L.rb ? L.b - L.a : 0;
-        c_len1 = r0 + 1 < L.rb ? c - L.b : 0;
-        if (DOT != 0) { c_u0 = L.u0; c_u1 = L.u1; }
-    };
-
-    BlkDesc dn{0, 1, 0, 0};
-    int o2 = 0;
-    if (b < bend) {
-        Blk2Loads first;
-        issue(uniform(load_desc(__builtin_amdgcn_readfirstlane(block_index(b)))), first);
-        if (b + bstep < bend) dn = uniform(load_desc(__builtin_amdgcn_readfirstlane(block_index(b + bstep))));
-        if (b + 2 * bstep < bend) o2 = __builtin_amdgcn_readfirstlane(block_index(b + 2 * bstep));
-        stage(first);
-    }
-    for (; b < bend; b += bstep) {
-        const bool more = b + bstep < bend;
-        Blk2Loads nxt;
-        BlkDesc dn2{0, 1, 0, 0};
-        int o3 = 0;
-        if (b + 3 * bstep < bend) o3 = block_index(b + 3 * bstep);
-        if (more) issue(dn, nxt);
-        // The descriptor of the block after next comes through the SCALAR cache (its index is wave-uniform): a 64-lane
-        // 16-byte load of it costs the vector-memory pipe as much as a gather.  Scalar loads return out of order and
-        // share their counter with the LDS, so it is requested after the block's gathers (and the LDS reads that
-        // address them) are out, and looked at when the block is done.
-        const bool want_dn2 = b + 2 * bstep < bend;
-        auto after_gathers = [&]() { if (want_dn2) dn2 = load_desc(o2); };
-        wave_lds_fence();
-        const int r0 = c_ra + 2 * lane;
-        const uint32_t r8 = (uint32_t)r0 * 8u;
-        const int len0 = c_len0, len1 = c_len1, lenm = max(len0, len1);
-        T acc0 = 0.0, acc1 = 0.0;
-        if (c_uni) {
-            // ---- uniform block: the pattern is scalar.  Per slot one LDS read of {offset, value} at a wave-uniform
-            // address, one 16-byte gather for the lane's two rows, two multiply-adds; no codes, no row_ptr.
-            const int ulen = __builtin_amdgcn_readfirstlane(lenm);             // == the block's row length (lane 0 always has a row)
-            T pl[8], ph[8], av[8];
-            uint32_t hi_bits = 0;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; av[t] = 0.0; }
-            if (c_rb - c_ra == 2 * WAVE) {
-                full_uniform_dispatch(s_pair, c_pat, ulen, c_tri, c_seam, c_seam1, c_seam2, xbytes, r8, (uint32_t)c_ra * 8u, lane, after_gathers, acc0, acc1);
-            } else {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (t >= ulen) break;
-                const PairEnt<T> e = s_pair[(int)((c_pat >> (8 * t)) & 255u)];
-                av[t] = e.val;
-                const uint32_t vo0 = len0 > 0 ? r8 + (uint32_t)e.off8 : 0u;
-                const uint32_t vp = min(vo0, xlast_pair);                       // only a single-row lane at the matrix end is ever clamped
-                hi_bits |= (vo0 != vp ? 1u : 0u) << t;
-                const D2 px = *reinterpret_cast<const D2 *>(xbytes + vp);
-                pl[t] = px.lo; ph[t] = px.hi;
-            }
-            after_gathers();
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (t >= ulen) break;
-                if (len0 > 0) acc0 = acc0 + (((hi_bits >> t) & 1u) ? ph[t] : pl[t]) * av[t];
-                if (len1 > 0) acc1 = acc1 + ph[t] * av[t];
-            }
-            }
-        } else {
-        if (__builtin_amdgcn_ballot_w64(0 < lenm) == 0) after_gathers();        // (a block of empty rows)
-        for (int j0 = 0; __builtin_amdgcn_ballot_w64(j0 < lenm) != 0; j0 += 8) {
-            const uint8_t *cp0 = cb + c_shift + min(c_s0 + j0, CAP2);
-            const uint8_t *cp1 = cb + c_shift + min(c_s1 + j0, CAP2);
-            T pl[8], ph[8];           // the 16-byte gather of the slot: x[col0], x[col0 + 1]
-            T xs[8];                  // row 1's own gather where its column is not row 0's + 1
-            uint32_t same_bits = 0, hi_bits = 0;      // per slot: row 1 shares the gather / row 0's x is the pair's second half
-#pragma unroll
-            for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; xs[t] = 0.0; }
-            const uint64_t m4 = __builtin_amdgcn_ballot_w64(j0 + 4 < lenm), m5 = __builtin_amdgcn_ballot_w64(j0 + 5 < lenm),
-                           m6 = __builtin_amdgcn_ballot_w64(j0 + 6 < lenm), m7 = __builtin_amdgcn_ballot_w64(j0 + 7 < lenm);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (t == 4 && m4 == 0) break;
-                if (t == 5 && m5 == 0) break;
-                if (t == 6 && m6 == 0) break;
-                if (t == 7 && m7 == 0) break;
-                const bool v0 = j0 + t < len0, v1 = j0 + t < len1;
-                const int off0 = s_pair[cp0[t]].off8, off1 = s_pair[cp1[t]].off8;
-                const bool same = v0 && v1 && off0 == off1;                     // column of row 1 == column of row 0 + 1
-                const uint32_t vo0 = v0 ? r8 + (uint32_t)off0 : 0u;             // byte offset of x[col0]; unused rows read x[0]
-                const uint32_t vp = min(vo0, xlast_pair);                       // a 16-byte load must start at or before x[ncols - 2]
-                same_bits |= (same ? 1u : 0u) << t;
-                hi_bits |= (vo0 != vp ? 1u : 0u) << t;                          // col0 == ncols - 1: it is the pair's second half
-                const D2 px = *reinterpret_cast<const D2 *>(xbytes + vp);
-                pl[t] = px.lo; ph[t] = px.hi;
-                const bool need1 = v1 && !same;
-                if (__builtin_amdgcn_ballot_w64(need1) != 0)                    // scalar branch: interior stencil blocks skip it
-                    xs[t] = *reinterpret_cast<const T *>(xbytes + (need1 ? r8 + 8u + (uint32_t)off1 : 0u));
-            }
-            if (j0 == 0) after_gathers();
-            __builtin_amdgcn_sched_barrier(0);                                  // every gather out before the first product
-            asm volatile("" ::: "memory");      // the values are looked up again below rather than held in 32 registers across the wait
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (j0 + t < len0) acc0 = acc0 + (((hi_bits >> t) & 1u) ? ph[t] : pl[t]) * s_pair[cp0[t]].val;
-                if (j0 + t < len1) acc1 = acc1 + (((same_bits >> t) & 1u) ? ph[t] : xs[t]) * s_pair[cp1[t]].val;
-            }
-        }
-        }
-        if (r0 + 1 < c_rb) {
-            if constexpr (YNT) {
-                const D2 yy{acc0, acc1};
-                u4v q;
-                __builtin_memcpy(&q, &yy, 16);
-                __builtin_nontemporal_store(q, reinterpret_cast<u4v *>(reinterpret_cast<char *>(y) + r8));
-            } else {
-                *reinterpret_cast<D2 *>(reinterpret_cast<char *>(y) + r8) = D2{acc0, acc1};
-            }
-            if (DOT == 1) { d0 = d0 + c_u0 * acc0; d0 = d0 + c_u1 * acc1; }
-            if (DOT == 2) { d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * c_u0; d0 = d0 + acc1 * acc1; d1 = d1 + acc1 * c_u1; }
-        } else if (r0 < c_rb) {
-            *reinterpret_cast<T *>(reinterpret_cast<char *>(y) + r8) = acc0;
-            if (DOT == 1) d0 = d0 + c_u0 * acc0;
-            if (DOT == 2) { d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * c_u0; }
-        }
-        wave_lds_fence();
-        if (more) stage(nxt);
-        dn = uniform(dn2); o2 = __builtin_amdgcn_readfirstlane(o3);
-    }
-}
-
 template <int DOT, bool YNT>
 __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_chunk, const BlkDesc *__restrict__ desc,
                                                            const int32_t *__restrict__ order,
@@ -1021,7 +431,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
     s_pair[tid] = PairEnt<T>{off_tab[tid] * 8, val_tab[tid]};                  // BLOCK == TAB
     for (int i = lane; i < CW2; i += WAVE) s_c[wv][i] = 0;                     // the pad is read (and ignored) before it is written
     __syncthreads();
-    if (run_state != ST_RUNNING) return;
+    if (run_state != ST_RUNNING) { fin_idle(fin, DOT == 2); return; }
 
     T d0 = 0.0, d1 = 0.0;
     pair2_walk<DOT, YNT>(n_wide, xcd_chunk, desc, order, row_ptr, code, x, y, u, nrows, ncols, s_pair, s_c, d0, d1);
@@ -1035,23 +445,6 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
     }
     if (DOT >= 1 && fin.counter) finalize_last_block<T, T>(fin, DOT == 2, red, red);
 }
-
-// ---- LDS x-window tiles (knob "spmv_tile"; profiles/r03_tuning.md §8) -------------------------------------------------
-// The per-block walk above pulls every column window of a 128-row block through the vector L1 on its own: five 16-byte
-// loads per lane for a 7-point stencil, and the texture-address unit / L1 miss path is what the kernel waits for
-// (TA busy 78 %, 0.45 of the HBM rate).  Consecutive row blocks of a stencil overlap in all their NEAR windows: a
-// workgroup that owns TILE_ROWS consecutive rows needs x[ts - W, ts + TILE_ROWS + W) ONCE for every column within W of the
-// diagonal — (T + 2W) / T = 1.25 loads per lane and 128 rows instead of one per near window — and only the FAR windows
-// (the +-plane neighbours) one by one.  So: a tile = TILE_B consecutive FULL uniform 128-row blocks (plain or seam,
-// mark_uniform_kernel) that share one pattern whose slots are, in row order, FL far slots, UL - FL - FH near slots, FH
-// far slots (sorted columns give exactly that).  The workgroup stages the window in LDS with 16-byte loads, issues the far
-// pair loads of all its rows, and every lane folds its two rows' slots left to right — the same products in the same order
-// as full_uniform_block, x taken from LDS for the near slots: y bit-identical.  Tiles are dealt to the XCDs by their
-// phase within the far period (tile_plan below) so that a far window was some tile's near window on the same L2.  The
-// 128-row blocks outside the tiles (boundary planes, the tiles a boundary line cuts, the matrix ends) are walked by the
-// same launch afterwards (pair2_walk), so the launch writes all of y and one partial per workgroup.
-constexpr int TILE_ROWS = 4096, TILE_W = 512, TILE_W_WIDE = 1536, TILE_B = TILE_ROWS / (2 * WAVE);
-struct TilePat { int32_t off[8]; double val[8]; };
 
 // one thread per candidate tile (blocks [t TILE_B, (t + 1) TILE_B)): its pattern (up to 8 codes, low byte first) and
 // length, or length 0 when the blocks are not TILE_B consecutive full uniform blocks of one pattern
@@ -1097,352 +490,6 @@ __global__ __launch_bounds__(BLOCK) void tile_flag_kernel(int n_wide, const BlkD
     flag[j] = ok ? 1 : 0;
 }
 
-// UX: the dot operand is the input vector itself (mul_vec_dot, MINRES' v.Av, K4 without a preconditioner): taken from the window
-template <int DOT, bool UX, int UL, int FL, int FH, int W>
-__global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(const int2 *__restrict__ tile_list, const int32_t *__restrict__ xstart,
-                                                          const BlkDesc *__restrict__ desc, const TilePat pat,
-                                                          int n_left, const int32_t *__restrict__ left_order,
-                                                          const int32_t *__restrict__ row_ptr, const uint8_t *__restrict__ code,
-                                                          const int32_t *__restrict__ off_tab, const double *__restrict__ val_tab,
-                                                          const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ u,
-                                                          double *__restrict__ part0, double *__restrict__ part1,
-                                                          const int *__restrict__ status, int nrows, int ncols, const Fin fin) {
-    using T = double;
-    constexpr int TR = TILE_ROWS;                       // W: half-width of the window (TILE_W, or TILE_W_WIDE for line bands up to 1534)
-    constexpr int NW = (TR + 2 * W) / 2 / BLOCK;        // 16-byte window pieces per lane
-    constexpr int NQ = TILE_B / NWAVE;                  // 128-row blocks per wavefront and tile
-    constexpr int NN = UL - FL - FH;                    // near slots
-    static_assert((TR + 2 * W) % (2 * BLOCK) == 0 && TILE_B % NWAVE == 0 && NN >= 1 && UL <= 8, "tile shape");
-    __shared__ __attribute__((aligned(16))) T win[TR + 2 * W];
-    __shared__ PairEnt<T> s_pair[TAB];
-    __shared__ __attribute__((aligned(16))) uint32_t s_c[NWAVE][CW2];
-    __shared__ T red[NWAVE];
-    const int run_state = status != nullptr ? *status : (int)ST_RUNNING;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    s_pair[tid] = PairEnt<T>{off_tab[tid] * 8, val_tab[tid]};                  // BLOCK == TAB (the seam rows' own values; the walk below)
-    for (int i = lane; i < CW2; i += WAVE) s_c[wv][i] = 0;
-    __syncthreads();
-    if (run_state != ST_RUNNING) return;
-    T d0 = 0.0, d1 = 0.0;
-
-    const int xcd = blockIdx.x & 7;
-    const int sstep = gridDim.x >> 3;
-    const int send = xstart[xcd + 1];
-    int s = xstart[xcd] + (blockIdx.x >> 3);
-    // tile_list entries: {first 128-row block, first row}; the next tile's entry is requested a tile ahead
-    // ... and the seam words of its blocks (wave-uniform: scalar loads) are read a tile ahead too
-    int2 ent = s < send ? tile_list[s] : int2{0, 0};
-    int2 ent1 = s + sstep < send ? tile_list[s + sstep] : int2{0, 0};
-    uint32_t rbw[NQ]; int nnw[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) { const BlkDesc d = desc[__builtin_amdgcn_readfirstlane(ent.x) + q * NWAVE + wv]; rbw[q] = (uint32_t)d.rb; nnw[q] = d.nn; }
-    for (; s < send; s += sstep) {
-        const int ts = __builtin_amdgcn_readfirstlane(ent.y);
-        ent = ent1;
-        if (s + 2 * sstep < send) ent1 = tile_list[s + 2 * sstep];
-        uint32_t rbc[NQ]; int nnc[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) { rbc[q] = rbw[q]; nnc[q] = nnw[q]; }
-        // ---- loads: the window, then the far pairs (and dot operands) of the lane's NQ row pairs
-        u4v wreg[NW];
-        const T *wbase = x + (ts - W);
-#pragma unroll
-        for (int i = 0; i < NW; ++i) wreg[i] = *reinterpret_cast<const u4v *>(wbase + 2 * (tid + i * BLOCK));
-        D2 far[NQ][FL + FH > 0 ? FL + FH : 1];
-        D2 uu[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const T *xr = x + (ts + ((q * NWAVE + wv) << 7) + 2 * lane);
-#pragma unroll
-            for (int k = 0; k < FL; ++k) far[q][k] = *reinterpret_cast<const D2 *>(xr + pat.off[k]);
-#pragma unroll
-            for (int k = 0; k < FH; ++k) far[q][FL + k] = *reinterpret_cast<const D2 *>(xr + pat.off[UL - FH + k]);
-            if (DOT != 0 && !UX) {
-                const u4v w4 = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(u + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
-                __builtin_memcpy(&uu[q], &w4, 16);
-            }
-        }
-        if (s + sstep < send) {
-            const int b1 = __builtin_amdgcn_readfirstlane(ent.x);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) { const BlkDesc d = desc[b1 + q * NWAVE + wv]; rbw[q] = (uint32_t)d.rb; nnw[q] = d.nn; }
-        }
-        __syncthreads();                                                        // the previous tile's window has been read
-#pragma unroll
-        for (int i = 0; i < NW; ++i) *reinterpret_cast<u4v *>(&win[2 * (tid + i * BLOCK)]) = wreg[i];
-        __syncthreads();
-        // near slots from the window; the reads of block q + 1 are issued before block q is folded (the seam branch
-        // below keeps the compiler from doing that itself, and a fold behind an exposed LDS round trip eight times per
-        // tile is 10 % of the launch)
-        T npl[NN], nph[NN];
-        auto read_near = [&](int q) {
-            const int li = W + ((q * NWAVE + wv) << 7) + 2 * lane;
-#pragma unroll
-            for (int t = 0; t < NN; ++t) { npl[t] = win[li + pat.off[FL + t]]; nph[t] = win[li + pat.off[FL + t] + 1]; }
-        };
-        read_near(0);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const uint32_t rbq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rbc[q]);
-            const bool seam = (rbq & SEAM2) != 0;
-            const int li = W + ((q * NWAVE + wv) << 7) + 2 * lane;              // window index of x[r0]
-            T pl[UL], ph[UL];
-#pragma unroll
-            for (int t = 0; t < UL; ++t) {
-                if (t < FL) { pl[t] = far[q][t].lo; ph[t] = far[q][t].hi; }
-                else if (t >= UL - FH) { pl[t] = far[q][t - (UL - FH) + FL].lo; ph[t] = far[q][t - (UL - FH) + FL].hi; }
-                else { pl[t] = npl[t - FL]; ph[t] = nph[t - FL]; }
-            }
-            T ux0 = 0.0, ux1 = 0.0;
-            if (DOT != 0 && UX) { ux0 = win[li]; ux1 = win[li + 1]; }
-            if (q + 1 < NQ) read_near(q + 1);
-            T acc0 = 0.0, acc1 = 0.0;
-            if (!seam) {
-#pragma unroll
-                for (int t = 0; t < UL; ++t) {
-                    acc0 = acc0 + pl[t] * pat.val[t];
-                    acc1 = acc1 + ph[t] * pat.val[t];
-                }
-            } else {
-                // (full_uniform_block's seam fold) local rows k and k + 1 fold only the slots of their masks, with their
-                // own value where they carry one.  A slot BOTH of them have is a plain step for the whole wavefront (a
-                // scalar test): a stencil's line seam costs two masked steps, not UL
-                const int seam1 = __builtin_amdgcn_readfirstlane(nnc[q]) >> 16, seam2 = (int)(rbq & 0x3ffffffu);
-                const int k = seam1 & 127, maskA = (seam1 >> 7) & 255, maskB = seam2 & 255;
-                const bool a0 = 2 * lane == k, a1 = 2 * lane + 1 == k, b0s = 2 * lane == k + 1, b1s = 2 * lane + 1 == k + 1;
-                if ((seam2 & 0x3000000) == 0) {
-                    // no row with a value of its own (a stencil's line seam): a step is plain unless row k or k + 1 lacks
-                    // the slot (scalar tests), and then those lanes alone keep their sum
-#pragma unroll
-                    for (int t = 0; t < UL; ++t) {
-                        const bool am = ((maskA >> t) & 1) == 0, bm = ((maskB >> t) & 1) == 0;       // scalar
-                        const T n0 = acc0 + pl[t] * pat.val[t], n1 = acc1 + ph[t] * pat.val[t];
-                        if (!am && !bm) { acc0 = n0; acc1 = n1; }
-                        else {
-                            acc0 = ((am && a0) || (bm && b0s)) ? acc0 : n0;
-                            acc1 = ((am && a1) || (bm && b1s)) ? acc1 : n1;
-                        }
-                    }
-                } else {
-                    const T valA = s_pair[(seam2 >> 8) & 255].val, valB = s_pair[(seam2 >> 16) & 255].val;
-                    const bool ovA = ((seam2 >> 24) & 1) != 0, ovB = ((seam2 >> 25) & 1) != 0;
-                    const int pm0 = a0 ? maskA : (b0s ? maskB : 255), pm1 = a1 ? maskA : (b1s ? maskB : 255);
-                    const bool o0 = (a0 && ovA) || (b0s && ovB), o1 = (a1 && ovA) || (b1s && ovB);
-                    const T v0 = a0 ? valA : valB, v1 = a1 ? valA : valB;
-#pragma unroll
-                    for (int t = 0; t < UL; ++t) {
-                        const T n0 = acc0 + pl[t] * (o0 ? v0 : pat.val[t]), n1 = acc1 + ph[t] * (o1 ? v1 : pat.val[t]);
-                        acc0 = ((pm0 >> t) & 1) ? n0 : acc0;
-                        acc1 = ((pm1 >> t) & 1) ? n1 : acc1;
-                    }
-                }
-            }
-            const D2 yy{acc0, acc1};
-            u4v qv;
-            __builtin_memcpy(&qv, &yy, 16);
-            __builtin_nontemporal_store(qv, reinterpret_cast<u4v *>(y + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
-            if (DOT == 1) { d0 = d0 + (UX ? ux0 : uu[q].lo) * acc0; d0 = d0 + (UX ? ux1 : uu[q].hi) * acc1; }
-            if (DOT == 2) {
-                const T u0 = UX ? ux0 : uu[q].lo, u1 = UX ? ux1 : uu[q].hi;
-                d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * u0; d0 = d0 + acc1 * acc1; d1 = d1 + acc1 * u1;
-            }
-        }
-    }
-    if (n_left > 0) {
-        __syncthreads();
-        pair2_walk<DOT, true>(n_left, 0, desc, left_order, row_ptr, code, x, y, u, nrows, ncols, s_pair, s_c, d0, d1);
-    }
-    if (DOT >= 1) {
-        d0 = block_sum(d0, red);
-        if (tid == 0) st_partial(fin, part0 + blockIdx.x, d0);
-    }
-    if (DOT == 2) {
-        d1 = block_sum(d1, red);
-        if (tid == 0) st_partial(fin, part1 + blockIdx.x, d1);
-    }
-    if (DOT >= 1 && fin.counter) finalize_last_block<T, T>(fin, DOT == 2, red, red);
-}
-
-// The same tiles for the OFFSET-CODE stream (a value per entry: any stencil or band with variable coefficients).  The 128-row
-// descriptors are the offset stream's own (owide_desc: uniform and seam blocks marked on the offset codes).  A full block's
-// 128 UL values are consecutive in val[]: the wavefront loads them with 16-byte loads (stream order), passes them through its
-// LDS slice one block ahead of the fold and reads them back by row — lane l's rows 2l, 2l + 1 sit at entries (2l) UL and
-// (2l + 1) UL behind the block's first one; in a seam block the rows behind the short ones move up by what those lack, and a
-// short row steps through its values only on the slots it has.  x as in spmv_tile_kernel.  The 64-row blocks outside the tiles
-// go through dict_walk in the same launch.
-template <int DOT, bool UX, int UL, int FL, int FH>
-__global__ __launch_bounds__(BLOCK) void spmv_tile_off_kernel(const int2 *__restrict__ tile_list, const int32_t *__restrict__ xstart,
-                                                              const BlkDesc *__restrict__ desc, const TilePat pat,
-                                                              int n_left, const int32_t *__restrict__ left_order, const BlkDesc *__restrict__ desc64,
-                                                              const int32_t *__restrict__ row_ptr, const uint8_t *__restrict__ code,
-                                                              const int32_t *__restrict__ off_tab, const double *__restrict__ val,
-                                                              const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ u,
-                                                              double *__restrict__ part0, double *__restrict__ part1,
-                                                              const int *__restrict__ status, const Fin fin, const V2d *__restrict__ tail2, int g2_last) {
-    using T = double;
-    constexpr int TR = TILE_ROWS, W = TILE_W;
-    constexpr int NW = (TR + 2 * W) / 2 / BLOCK;        // 16-byte window pieces per lane
-    constexpr int NQ = TILE_B / NWAVE;                  // 128-row blocks per wavefront and tile
-    constexpr int NN = UL - FL - FH;                    // near slots
-    constexpr int VROW = 2 * WAVE * UL;                 // values of a full block
-    constexpr int NV = (VROW / 2 + 1 + WAVE - 1) / WAVE;   // 16-byte value loads per lane and block (a block may start on an odd entry)
-    constexpr int CAPD = nnz_cap<T>::value;
-    constexpr int CWD = (CAPD + 3 + CPAD + 3) / 4;
-    constexpr int VS = (VROW + 2 + 15) / 16 * 16 > CAPD + 16 ? (VROW + 2 + 15) / 16 * 16 : CAPD + 16;    // slice stride: the tile phase's block, or dict_walk's
-    static_assert((TR + 2 * W) % (2 * BLOCK) == 0 && TILE_B % NWAVE == 0 && NN >= 1 && UL <= 8, "tile shape");
-    __shared__ __attribute__((aligned(16))) T win[TR + 2 * W];
-    __shared__ __attribute__((aligned(16))) T vsl[NWAVE][VS];
-    __shared__ int32_t s_off8[TAB];
-    __shared__ uint32_t s_c[NWAVE][CWD];
-    __shared__ T red[NWAVE];
-    const int run_state = status != nullptr ? *status : (int)ST_RUNNING;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    s_off8[tid] = off_tab[tid] * (int32_t)sizeof(T);                            // BLOCK == TAB
-    for (int i = lane; i < CWD; i += WAVE) s_c[wv][i] = 0;
-    for (int i = lane; i < VS; i += WAVE) vsl[wv][i] = 0.0;
-    __syncthreads();
-    if (run_state != ST_RUNNING) return;
-    T d0 = 0.0, d1 = 0.0;
-
-    const int xcd = blockIdx.x & 7;
-    const int sstep = gridDim.x >> 3;
-    const int send = xstart[xcd + 1];
-    int s = xstart[xcd] + (blockIdx.x >> 3);
-    // tile entries {first 128-row block, first row} and per block its seam words and its first entry: scalar loads a tile ahead
-    int2 ent = s < send ? tile_list[s] : int2{0, 0};
-    int2 ent1 = s + sstep < send ? tile_list[s + sstep] : int2{0, 0};
-    uint32_t rbw[NQ]; int nnw[NQ], vbw[NQ];
-    auto load_words = [&](int b0, int ts) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const BlkDesc d = desc[b0 + q * NWAVE + wv];
-            rbw[q] = (uint32_t)d.rb; nnw[q] = d.nn; vbw[q] = row_ptr[ts + ((q * NWAVE + wv) << 7)];
-        }
-    };
-    load_words(__builtin_amdgcn_readfirstlane(ent.x), __builtin_amdgcn_readfirstlane(ent.y));
-    T *vs = vsl[wv];
-    for (; s < send; s += sstep) {
-        const int ts = __builtin_amdgcn_readfirstlane(ent.y);
-        ent = ent1;
-        if (s + 2 * sstep < send) ent1 = tile_list[s + 2 * sstep];
-        uint32_t rbc[NQ]; int nnc[NQ], vbc[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) { rbc[q] = rbw[q]; nnc[q] = nnw[q]; vbc[q] = __builtin_amdgcn_readfirstlane(vbw[q]); }
-        // ---- loads: the window, the far pairs (and dot operands) of the lane's NQ row pairs, the first block's values
-        u4v wreg[NW];
-        const T *wbase = x + (ts - W);
-#pragma unroll
-        for (int i = 0; i < NW; ++i) wreg[i] = *reinterpret_cast<const u4v *>(wbase + 2 * (tid + i * BLOCK));
-        D2 far[NQ][FL + FH > 0 ? FL + FH : 1];
-        D2 uu[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const T *xr = x + (ts + ((q * NWAVE + wv) << 7) + 2 * lane);
-#pragma unroll
-            for (int k = 0; k < FL; ++k) far[q][k] = *reinterpret_cast<const D2 *>(xr + pat.off[k]);
-#pragma unroll
-            for (int k = 0; k < FH; ++k) far[q][FL + k] = *reinterpret_cast<const D2 *>(xr + pat.off[UL - FH + k]);
-            if (DOT != 0 && !UX) {
-                const u4v w4 = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(u + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
-                __builtin_memcpy(&uu[q], &w4, 16);
-            }
-        }
-        u4v vreg[NV];
-        auto load_vals = [&](int vb) {                  // chunks [vb >> 1, (vb >> 1) + VROW / 2]: the block's values from its 16-byte boundary
-            const u4v *v2 = reinterpret_cast<const u4v *>(val) + (vb >> 1);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) vreg[i] = __builtin_nontemporal_load(v2 + min(lane + i * WAVE, VROW / 2));      // read once: 720 -> 674 us (profiles/r03_tuning.md §9)
-        };
-        load_vals(vbc[0]);
-        if (s + sstep < send) load_words(__builtin_amdgcn_readfirstlane(ent.x), __builtin_amdgcn_readfirstlane(ent.y));
-        __syncthreads();                                                        // the previous tile's window has been read
-#pragma unroll
-        for (int i = 0; i < NW; ++i) *reinterpret_cast<u4v *>(&win[2 * (tid + i * BLOCK)]) = wreg[i];
-        __syncthreads();
-        T npl[NN], nph[NN];
-        auto read_near = [&](int q) {
-            const int li = W + ((q * NWAVE + wv) << 7) + 2 * lane;
-#pragma unroll
-            for (int t = 0; t < NN; ++t) { npl[t] = win[li + pat.off[FL + t]]; nph[t] = win[li + pat.off[FL + t] + 1]; }
-        };
-        read_near(0);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            // this block's values: registers -> the wavefront's slice (stream order), then the next block's loads go out
-#pragma unroll
-            for (int i = 0; i < NV; ++i) *reinterpret_cast<u4v *>(&vs[2 * min(lane + i * WAVE, VROW / 2)]) = vreg[i];
-            if (q + 1 < NQ) load_vals(vbc[q + 1 < NQ ? q + 1 : q]);
-            wave_lds_fence();
-            const uint32_t rbq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rbc[q]);
-            const bool seam = (rbq & SEAM2) != 0;
-            const int shift = vbc[q] & 1;
-            const int li = W + ((q * NWAVE + wv) << 7) + 2 * lane;              // window index of x[r0]
-            T pl[UL], ph[UL];
-#pragma unroll
-            for (int t = 0; t < UL; ++t) {
-                if (t < FL) { pl[t] = far[q][t].lo; ph[t] = far[q][t].hi; }
-                else if (t >= UL - FH) { pl[t] = far[q][t - (UL - FH) + FL].lo; ph[t] = far[q][t - (UL - FH) + FL].hi; }
-                else { pl[t] = npl[t - FL]; ph[t] = nph[t - FL]; }
-            }
-            T ux0 = 0.0, ux1 = 0.0;
-            if (DOT != 0 && UX) { ux0 = win[li]; ux1 = win[li + 1]; }
-            if (q + 1 < NQ) read_near(q + 1);
-            T acc0 = 0.0, acc1 = 0.0;
-            if (!seam) {
-                const T *v0 = vs + shift + 2 * lane * UL;
-#pragma unroll
-                for (int t = 0; t < UL; ++t) {
-                    acc0 = acc0 + pl[t] * v0[t];
-                    acc1 = acc1 + ph[t] * v0[UL + t];
-                }
-            } else {
-                // rows k, k + 1 (local) hold only the slots of their masks: their values are fewer, and the rows behind them
-                // start that much earlier in the slice
-                const int seam1 = __builtin_amdgcn_readfirstlane(nnc[q]) >> 16, seam2 = (int)(rbq & 0x3ffffffu);
-                const int k = seam1 & 127, full = (1 << UL) - 1, maskA = (seam1 >> 7) & full, maskB = seam2 & full;
-                const int cA = UL - __builtin_popcount(maskA), cB = UL - __builtin_popcount(maskB);
-                const int i0 = 2 * lane, i1 = i0 + 1;
-                int p0 = shift + i0 * UL - (i0 > k ? cA : 0) - (i0 > k + 1 ? cB : 0);
-                int p1 = shift + i1 * UL - (i1 > k ? cA : 0) - (i1 > k + 1 ? cB : 0);
-                const int pm0 = i0 == k ? maskA : (i0 == k + 1 ? maskB : full), pm1 = i1 == k ? maskA : (i1 == k + 1 ? maskB : full);
-#pragma unroll
-                for (int t = 0; t < UL; ++t) {
-                    const T n0 = acc0 + pl[t] * vs[p0], n1 = acc1 + ph[t] * vs[p1];
-                    const bool h0 = ((pm0 >> t) & 1) != 0, h1 = ((pm1 >> t) & 1) != 0;
-                    acc0 = h0 ? n0 : acc0; p0 += h0 ? 1 : 0;
-                    acc1 = h1 ? n1 : acc1; p1 += h1 ? 1 : 0;
-                }
-            }
-            const D2 yy{acc0, acc1};
-            u4v qv;
-            __builtin_memcpy(&qv, &yy, 16);
-            __builtin_nontemporal_store(qv, reinterpret_cast<u4v *>(y + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
-            if (DOT == 1) { d0 = d0 + (UX ? ux0 : uu[q].lo) * acc0; d0 = d0 + (UX ? ux1 : uu[q].hi) * acc1; }
-            if (DOT == 2) {
-                const T u0 = UX ? ux0 : uu[q].lo, u1 = UX ? ux1 : uu[q].hi;
-                d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * u0; d0 = d0 + acc1 * acc1; d1 = d1 + acc1 * u1;
-            }
-            wave_lds_fence();                                                   // the slice is free for the next block's values
-        }
-    }
-    if (n_left > 0) {
-        __syncthreads();
-        dict_walk<T, DOT, false, false, true>(n_left, 0, desc64, left_order, row_ptr, code, val, x, y, u, tail2, g2_last,
-                                             (const PairEnt<T> *)nullptr, s_off8, s_c, &vsl[0][0], VS, d0, d1);
-    }
-    if (DOT >= 1) {
-        d0 = block_sum(d0, red);
-        if (tid == 0) st_partial(fin, part0 + blockIdx.x, d0);
-    }
-    if (DOT == 2) {
-        d1 = block_sum(d1, red);
-        if (tid == 0) st_partial(fin, part1 + blockIdx.x, d1);
-    }
-    if (DOT >= 1 && fin.counter) finalize_last_block<T, T>(fin, DOT == 2, red, red);
-}
-
 // XCD-period schedule (knob "spmv_period") of a stream's row blocks.  With the far band P = max |col - row| (a 3-D
 // stencil's plane), rows are cut into chunks of P/8 and chunk c goes to XCD c mod 8: rows r and r +- P are multiplied on
 // the SAME XCD one chunk apart, so x[r + P] is fetched over the fabric once — when row r needs it — and hits that
@@ -1471,11 +518,6 @@ static std::vector<int32_t> xcd_period_order(int nblk, int64_t G, FirstRow first
     return ord;
 }
 
-// (UL, FL, FH) shapes spmv_tile_kernel is built for: 7-point 3-D, 5-point 2-D with a far or a near line band, 3-point 1-D, and
-// bands with two far diagonals
-#define SPRS_TILE_SHAPES(X) X(7, 1, 1) X(5, 1, 1) X(5, 0, 0) X(3, 0, 0) X(3, 1, 1) X(7, 0, 0)
-// ... and with the wide window (pair-code stream only; grids whose lines are 511 to 1534 long)
-#define SPRS_TILE_SHAPES_WIDE(X) X(7, 1, 1) X(5, 1, 1) X(5, 0, 0) X(7, 0, 0)
 static bool tile_shape_built(int ul, int fl, int fh, int w) {
 #define SPRS_TILE_HAS(U, L, H) if (ul == U && fl == L && fh == H) return true;
     if (w == TILE_W) { SPRS_TILE_SHAPES(SPRS_TILE_HAS) }
@@ -1564,9 +606,15 @@ static int build_tile_plan(sprs_csr *A, sprs_tile_plan &TP, const BlkDesc *desc_
         int e = j + 1;
         while (e < nw && flag[(size_t)e] && wd[(size_t)e].ra == wd[(size_t)e - 1].ra + 2 * WAVE) ++e;
         int b = j;
-        while (b < e && (int64_t)wd[(size_t)b].ra - WIN < 0) ++b;                    // the window starts inside x
+        // every 16-byte load of a tile stays inside x — the near window [ra - WIN, ra + TILE_ROWS + WIN) and each far slot's
+        // pairs x[r + o], x[r + o + 1] for ALL the tile's rows: the kernels load them for every lane, also for a seam row whose
+        // mask lacks that slot (damaged-row or band matrices can put such a row where r + o leaves [0, ncols))
+        int64_t lo_need = WIN, hi_need = WIN;
+        for (int t = 0; t < FL; ++t) lo_need = std::max<int64_t>(lo_need, -(int64_t)TP.off[t]);
+        for (int t = UL - FH; t < UL; ++t) hi_need = std::max<int64_t>(hi_need, (int64_t)TP.off[t]);
+        while (b < e && (int64_t)wd[(size_t)b].ra - lo_need < 0) ++b;                // the window / far pairs start inside x
         for (; b + TILE_B <= e; b += TILE_B) {
-            if ((int64_t)wd[(size_t)b].ra + TILE_ROWS + WIN > A->ncols) break;        // ... and ends inside it
+            if ((int64_t)wd[(size_t)b].ra + TILE_ROWS + hi_need > A->ncols) break;    // ... and end inside it
             starts.push_back(b);
             for (int q = 0; q < TILE_B; ++q) in_tile[(size_t)(b + q)] = 1;
         }
@@ -1925,31 +973,8 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
         if (pair && whole && D->tile_pair.n_tile > 0) tpp = &D->tile_pair;
         else if (pair && interior && !A->dist->tile_int_off) tpp = &A->dist->tile_int;
         if (tpp && c->spmv_tile != 0 && c->spmv_wide != 0 && g % 8 == 0) {
-            // LDS x-window tiles + the per-block walk over the blocks outside them, one launch
-            const BlkDesc *wd = reinterpret_cast<const BlkDesc *>(D->wide_desc);
-            const double *pvd = reinterpret_cast<const double *>(D->pair_val);
-            TilePat tp;
-            const sprs_tile_plan &TP = *tpp;
-            for (int t = 0; t < 8; ++t) { tp.off[t] = TP.off[t]; tp.val[t] = TP.val[t]; }
-            const bool ux = dot_mode != 0 && u == x;      // the dot operand is the input vector (mul_vec_dot, MINRES' v.Av, K4 without a preconditioner)
-#define SPRS_TSPMV(DM, UXV, U, L, H) SPRS_LAUNCH_SPMV(c, (spmv_tile_kernel<DM, UXV, U, L, H, SPRS_TW>), g, reinterpret_cast<const int2 *>(TP.list), TP.xstart, wd, tp, TP.n_left, \
-                                                      TP.left, A->row_ptr, D->pair_code, D->pair_off, pvd, x, y, u, part0, part1, status, (int)A->nrows, (int)A->ncols, fin)
-#define SPRS_TSHAPE(U, L, H)                                                                                             \
-            if (TP.ul == U && TP.fl == L && TP.fh == H) {                                                 \
-                if (dot_mode == 0) SPRS_TSPMV(0, false, U, L, H);                                                        \
-                else if (dot_mode == 1) { if (ux) SPRS_TSPMV(1, true, U, L, H); else SPRS_TSPMV(1, false, U, L, H); }    \
-                else if (ux) SPRS_TSPMV(2, true, U, L, H); else SPRS_TSPMV(2, false, U, L, H);                           \
-            }
-#define SPRS_TW TILE_W
-            if (TP.w == TILE_W) { SPRS_TILE_SHAPES(SPRS_TSHAPE) }
-#undef SPRS_TW
-#define SPRS_TW TILE_W_WIDE
-            if (TP.w == TILE_W_WIDE) { SPRS_TILE_SHAPES_WIDE(SPRS_TSHAPE) }
-#undef SPRS_TW
-#undef SPRS_TSHAPE
-#undef SPRS_TSPMV
-            SPRS_HIP_TRY(c, hipGetLastError());
-            return SPRS_OK;
+            // LDS x-window tiles + the per-block walk over the blocks outside them, one launch (spmv_tile.hip)
+            return launch_tile_pair(A, *tpp, g, x, y, dot_mode, u, part0, part1, status, fin);
         }
         if (pair && D->wide_desc && c->spmv_wide != 0 && count_w >= 0 && A->nrows >= 2 && A->ncols >= 2) {
             const int gw = g;     // same grid as the 64-row kernel: the consumers reduce exactly spmv_num_partials(A) partials
@@ -1985,25 +1010,8 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
             if (whole && D->tile_off.n_tile > 0) tpp = &D->tile_off;
             else if (interior && A->dist->tile_int_off) tpp = &A->dist->tile_int;
             if (tpp && D->owide_desc && c->spmv_tile != 0 && c->spmv_wide != 0 && c->spmv_uniform != 0 && g % 8 == 0 && !conj_x) {
-                // LDS x-window tiles + the per-block walk over the 64-row blocks outside them, one launch
-                const sprs_tile_plan &TP = *tpp;
-                TilePat tp;
-                for (int t = 0; t < 8; ++t) { tp.off[t] = TP.off[t]; tp.val[t] = 0.0; }
-                const bool ux = dot_mode != 0 && u == x;      // the dot operand is the input vector (mul_vec_dot, MINRES' v.Av, K4 without a preconditioner)
-                const BlkDesc *owd = reinterpret_cast<const BlkDesc *>(D->owide_desc);
-#define SPRS_TOSPMV(DM, UXV, U, L, H) SPRS_LAUNCH_SPMV(c, (spmv_tile_off_kernel<DM, UXV, U, L, H>), g, reinterpret_cast<const int2 *>(TP.list), TP.xstart, owd, tp, \
-                                                       TP.n_left, TP.left, dsc, A->row_ptr, code, otab, v, x, y, u, part0, part1, status, fin, tail2, g2_last)
-#define SPRS_TOSHAPE(U, L, H)                                                                                            \
-                if (TP.ul == U && TP.fl == L && TP.fh == H) {                                                            \
-                    if (dot_mode == 0) SPRS_TOSPMV(0, false, U, L, H);                                                   \
-                    else if (dot_mode == 1) { if (ux) SPRS_TOSPMV(1, true, U, L, H); else SPRS_TOSPMV(1, false, U, L, H); } \
-                    else if (ux) SPRS_TOSPMV(2, true, U, L, H); else SPRS_TOSPMV(2, false, U, L, H);                     \
-                }
-                SPRS_TILE_SHAPES(SPRS_TOSHAPE)
-#undef SPRS_TOSHAPE
-#undef SPRS_TOSPMV
-                SPRS_HIP_TRY(c, hipGetLastError());
-                return SPRS_OK;
+                // LDS x-window tiles + the per-block walk over the 64-row blocks outside them, one launch (spmv_tile_off.hip)
+                return launch_tile_off(A, *tpp, g, dsc, x, y, dot_mode, u, part0, part1, status, fin, tail2, g2_last);
             }
 #define SPRS_DSPMVW(DM) SPRS_LAUNCH_SPMV(c, (spmv_dict_kernel<T, DM, false, false, true>), g, count, xcd_chunk, dsc, order, A->row_ptr, \
                                          code, otab, pv, v, x, y, u, part0, part1, status, fin, tail2, g2_last)

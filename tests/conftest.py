@@ -25,7 +25,7 @@ def oracle():
 # results again (round 3: EADDRINUSE in a launcher test stopped the run before tests/test_gpu_parity.py was reached).
 _FILE_ORDER = ["test_gpu_parity.py", "test_gpu_fuzz_slice.py", "test_gpu_dict_stream.py", "test_gpu_gauss_seidel.py",
                "test_gpu_threads.py", "test_gpu_dist.py", "test_gpu_p2p_allreduce.py", "test_gpu_dist_multirank.py"]
-_SPAWNING = ("test_c_program_through_the_abi", "test_host_owned_recurrence", "test_randomised_solver_parity_short", "test_bench_")
+_SPAWNING = ("test_c_program_through_the_abi", "test_host_owned_recurrence", "test_bench_")
 
 
 def pytest_collection_modifyitems(session, config, items):

@@ -838,6 +838,16 @@ def test_device_built_row_blocks_from_summaries(sa, oracle):
             short = cnt <= 96
             assert np.array_equal(bits(y[short]), bits(ref[short])), (case, stream)
             assert np.all(np.abs(y[~short] - ref[~short]) <= RED_RTOL * 300)
+        if case == "few-irregular":
+            # The two creation paths may cut an irregular run into different row blocks (the summary path restarts blocks at
+            # 64-row group boundaries): y is bit-identical all the same (the per-row fold does not depend on the block), the
+            # fused dot groups its partials by block and may differ in summation order only — stated tolerance below.
+            Ah = sa.HipCsr.new((n, n), indptr.astype(np.int32), indices, data)
+            Ad = sa.HipCsr.from_device((n, n), nnz, ip_d, ix_d, dv_d, adopt=True)
+            yh = np.empty(n); dh = Ah.mul_vec_dot(x, yh)
+            dd = Ad.mul_vec_dot(xd, yd)
+            assert np.array_equal(bits(yh), bits(yd.cpu().numpy()))
+            assert abs(dh - dd) <= RED_RTOL * float(np.sum(np.abs(x * yh))), (dh, dd)
         if case == "regular":
             nb, ne = (ctx.set("spmv_dict", 0), sa.HipCsr.from_device((n, n), nnz, ip_d, ix_d, dv_d, adopt=True).wide_blocks())[1]
             ctx.set("spmv_dict", -1)
@@ -1164,20 +1174,6 @@ def test_host_owned_recurrence_through_the_abi(tmp_path):
         out = subprocess.run([exe, size], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "bit-identical: yes" in out.stdout, out.stdout
-
-
-def test_randomised_solver_parity_short():
-    """scripts/fuzz_solvers.py for a few seconds (the long runs are recorded in profiles/r02_tuning.md): random small
-    systems, all four scalar types, three solvers, plain / Jacobi, fused / literal — outcome, iteration count and
-    solution against the oracle's restatement of the reference recurrences."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_solvers.py"), "6", "77"], cwd=root,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
-    assert p.returncode == 0, p.stdout[-3000:]
-    assert "0 hard mismatches" in p.stdout
 
 
 def test_non_temporal_accesses_are_a_pure_cache_hint(oracle):

@@ -119,6 +119,23 @@ def test_every_d_symbol_has_its_z_sibling():
     assert {"sprs_diag_precond_create_d", "sprs_diag_precond_create_zd", "sprs_diag_precond_create_z", "sprs_axpy_zd"} <= r
 
 
+def test_every_f64_symbol_has_its_f32_sibling():
+    """The reference is generic over all four cauchy::Scalar types and tests f32 / Complex<f32> BLAS-1 itself
+    (src/vecalg.rs:647-658,669-677,771-830): every `_d` wrapper needs its `_s` sibling, every `_z` its `_c`, `_zd` its `_cs`,
+    and the generic wrappers must not pin `Real = f64`."""
+    r = set(rust_prototypes())
+    missing = [n for n in sorted(r) if n.endswith("_d") and n[:-2] + "_s" not in r]
+    missing += [n for n in sorted(r) if n.endswith("_z") and n[:-2] + "_c" not in r]
+    missing += [n for n in sorted(r) if n.endswith("_zd") and n[:-3] + "_cs" not in r]
+    assert not missing, missing
+    src = _rust_src()
+    assert "Scalar<Real = f64>" not in src
+    for needle in ("impl_scalar!(f32,", "impl_scalar!(Complex32,", "impl HipDiag<f32> for f32", "impl HipDiag<f32> for Complex32",
+                   "impl HipDiag<Complex32> for Complex32", "impl HipGsScalar for f32", "-> SolveResult<(usize, T::Real)>",
+                   "pub fn norm2<T: HipScalar>(x: &DevVec<T>) -> T::Real"):
+        assert needle in src, needle
+
+
 def test_wrappers_cover_the_reference_test_surface():
     src = _rust_src()
     for needle in ("pub struct HipBiCGStab<'data, T: HipScalar>", "pub struct HipMinRes<'data, T: HipScalar>",
