@@ -59,6 +59,9 @@ KERNEL_NAMES = {0: "spmv_kernel<double> (plain CSR stream, wavefront-private LDS
                 4: "spmv_tile_off_kernel<DOT> (offset codes + 8-byte values; runs of 4096 rows of one stencil pattern: x from a window staged in "
                    "LDS + per-row-pair far loads, the values streamed through the wavefront's LDS slice; the other 64-row blocks by the "
                    "per-block walk of the same launch; csrc/spmv_dict.hip)",
+                5: "spmv_chain_kernel<DOT> (pair codes; plane-streaming chains: a workgroup walks a column of 2048-row tiles plane by plane with the "
+                   "x windows of three consecutive tiles in LDS — the +-plane operands come from the neighbouring tiles' windows, no far load; "
+                   "the other 128-row blocks by the per-block walk of the same launch; csrc/spmv_chain.hip)",
                 3: "spmv_tile_kernel<DOT> (pair codes; runs of 4096 rows of one stencil pattern multiplied from an x window staged in "
                    "LDS + per-row-pair far loads, tiles dealt to the XCDs by the far period; the other 128-row blocks by the "
                    "per-block walk of the same launch; csrc/spmv_dict.hip)"}
@@ -161,6 +164,10 @@ def stream_info(A, n, nnz, s):
                row_blocks=nb, descriptor_only_blocks=nu, bytes_moved_per_launch=moved)
     if tiles[0] > 0:        # same bytes: a tile reads x once per window instead of once per column, all of it on chip
         out.update(kernel_id=3 if mode == 2 else 4, lds_window_tiles=tiles[0], blocks_in_tiles=tiles[1], blocks_walked_singly=tiles[2])
+    chain = A.chain_plan() if hasattr(A, "chain_plan") else (0, 0, 0, 0)
+    if chain[0] > 0:
+        out.update(kernel_id=5, chain_tiles=chain[0], chain_segments=chain[1], chains=chain[2], blocks_in_chains=16 * chain[0],
+                   blocks_walked_singly=chain[3])
     return out
 
 
@@ -709,6 +716,8 @@ def main():
                            "how little of the HBM bandwidth it needs, BASELINE's CSR figure is roofline_plain_csr" if sinfo["mode"] == 2 and "kernel_id" not in sinfo else "")
                         + ("; the tile kernel stages each near x window once per 4096 rows (DESIGN.md §3): what it moves crosses the fabric at the rate a "
                            "pure read stream reaches on this chip (5.5 TB/s); BASELINE's CSR figure is roofline_plain_csr" if sinfo.get("kernel_id") == 3 else "")
+                        + ("; the chain kernel keeps three consecutive planes' x windows of a 2048-row column in LDS (DESIGN.md §3): x crosses the vector L1 "
+                           "1.5 times and no far load exists; BASELINE's CSR figure is roofline_plain_csr" if sinfo.get("kernel_id") == 5 else "")
                         + ("; N>1: the bracketed time includes the wait for the halo exchange of the boundary rows" if world > 1 else ""))
         out = dict(metric="BiCGStab iterations/s (f64, 50M-row 7-point 3-D Poisson) + CSR SpMV GB/s vs HBM roofline",
                    value=1e3 / ms_step, unit="iterations/s", n_gpus=world, steps=args.steps, warmup=args.warmup,

@@ -88,6 +88,10 @@ int sprs_version(void);
  *                   staged in LDS (near columns) + per-row-pair far loads, one launch with the remaining blocks:
  *                   -1 automatic = vectors of 44 MiB and more, 1 = every matrix with such runs, 0 = off
  *                   (sprs_csr_tile_plan reports what a handle got)                       (creation; 0 also at launch)
+ *   "spmv_chain"    f64 pair codes, patterns with one far slot a side at -P / +P (3-D stencils): a workgroup walks a
+ *                   column of 2048-row tiles plane by plane with the x windows of three consecutive tiles in LDS — no far
+ *                   load at all: -1 automatic = wherever "spmv_tile" applies and the chains fill the chip, 1 = wherever
+ *                   chains exist, 0 = off (sprs_csr_chain_plan reports what a handle got)  (creation; 0 also at launch)
  *   "spmv_eqrows"   plain CSR: blocks of equal-length rows do not read row_ptr                           (creation)
  *   "spmv_wideload" plain CSR, f64: 16-byte stream loads (4 entries per lane), 3 workgroups per CU on HBM-sized
  *                   matrices; 0 = the kernel with 4- / 8-byte loads                                      (creation)
@@ -150,6 +154,10 @@ int sprs_csr_wide_blocks(const sprs_csr *A, int64_t *n_blocks, int64_t *n_unifor
  * 128-row blocks the same launch walks one by one.  All zero when the handle has no tile plan (other streams, matrices
  * without long runs of one stencil pattern, cache-resident matrices under the automatic policy). */
 int sprs_csr_tile_plan(const sprs_csr *A, int64_t *n_tiles, int64_t *n_tile_blocks, int64_t *n_other_blocks);
+/* ... and of its plane-streaming chains (ctx knob "spmv_chain", csrc/spmv_chain.hip), which take precedence over the tiles
+ * where a handle has both (sprs_csr_tile_plan then reports zeros): chain tiles (2048 rows each), chain segments (the work
+ * items, about one per workgroup), chains, and the 128-row blocks the same launch walks one by one.  All zero otherwise. */
+int sprs_csr_chain_plan(const sprs_csr *A, int64_t *n_tiles, int64_t *n_segments, int64_t *n_chains, int64_t *n_other_blocks);
 
 /* MatVecMul::mul_vec / mul_vec_dot (mat.rs:49-64): host slices, checked — returns
  * SPRS_DIM_MISMATCH where the reference panics.  y = A x ; *dot_out = conj(x) . y

@@ -127,6 +127,7 @@ def _protos():
     P["sprs_csr_stream_format"] = [_vp, C.POINTER(_int), C.POINTER(_int)]
     P["sprs_csr_wide_blocks"] = [_vp, C.POINTER(_i64), C.POINTER(_i64)]
     P["sprs_csr_tile_plan"] = [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]
+    P["sprs_csr_chain_plan"] = [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]
     P["sprs_gauss_seidel_create"] = [_vp, _pp]
     P["sprs_gauss_seidel_destroy"] = [_vp]
     for s in ("d", "s"):

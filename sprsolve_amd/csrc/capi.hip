@@ -114,6 +114,7 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     else if (k == "spmv_triple") c->spmv_triple = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_seam") c->spmv_seam = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_tile") c->spmv_tile = value < 0 ? -1 : (value ? 1 : 0);
+    else if (k == "spmv_chain") c->spmv_chain = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "ew_chunk") c->ew_chunk = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "stream_nt") c->stream_nt = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_eqrows") c->spmv_eqrows = value < 0 ? -1 : (value ? 1 : 0);
@@ -137,6 +138,7 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     if (k == "spmv_triple") return c->spmv_triple;
     if (k == "spmv_seam") return c->spmv_seam;
     if (k == "spmv_tile") return c->spmv_tile;
+    if (k == "spmv_chain") return c->spmv_chain;
     if (k == "ew_chunk") return c->ew_chunk;
     if (k == "stream_nt") return c->stream_nt;
     if (k == "spmv_eqrows") return c->spmv_eqrows;
@@ -597,10 +599,19 @@ int sprs_csr_tile_plan(const sprs_csr *A, int64_t *n_tiles, int64_t *n_tile_bloc
         *n_other_blocks = (A->n_rowblk + 1) / 2 - *n_tile_blocks;
         return SPRS_OK;
     }
+    if (sprs::chain_plan_used(A)) return SPRS_OK;          // the chains run this handle's SpMV (sprs_csr_chain_plan)
     const sprs_tile_plan &TP = dm == 2 ? D->tile_pair : D->tile_off;
     if (TP.n_tile <= 0 || !sprs::tile_plan_used(A)) return SPRS_OK;
     // the other blocks in 128-row units (the offset stream walks them as 64-row blocks)
     *n_tiles = TP.n_tile; *n_tile_blocks = (int64_t)TP.n_tile * sprs::tile_blocks(); *n_other_blocks = dm == 2 ? TP.n_left : (TP.n_left + 1) / 2;
+    return SPRS_OK;
+}
+int sprs_csr_chain_plan(const sprs_csr *A, int64_t *n_tiles, int64_t *n_segments, int64_t *n_chains, int64_t *n_other_blocks) {
+    if (!A || !n_tiles || !n_segments || !n_chains || !n_other_blocks) return SPRS_INVALID_ARGUMENT;
+    *n_tiles = 0; *n_segments = 0; *n_chains = 0; *n_other_blocks = 0;
+    if (!A->dict || !sprs::chain_plan_used(A)) return SPRS_OK;
+    const sprs_chain_plan &CP = A->dict->chain_pair;
+    *n_tiles = CP.n_tile; *n_segments = CP.n_seg; *n_chains = CP.n_chain; *n_other_blocks = CP.n_left;
     return SPRS_OK;
 }
 int sprs_csr_stream_format(const sprs_csr *A, int *n_offsets, int *n_values) {

@@ -58,6 +58,7 @@ struct sprs_ctx {
     int spmv_triple = -1;  // f64 pair codes, uniform blocks: columns c - 1 and c + 1 read from column c's loads; 0 = off.  Read at creation
     int spmv_seam = -1;    // f64 pair codes: blocks that are uniform but for one or two adjacent rows lacking one slot run the uniform path; 0 = off.  Read at creation
     int spmv_tile = -1;    // f64 compressed streams: LDS x-window tiles for the near columns of uniform stencil runs (spmv_tile_kernel, spmv_tile_off_kernel): -1 automatic = vectors of 44 MiB and more (tile_wanted), 1 = every matrix that has such runs, 0 = off.  Read at creation; 0 also at launch
+    int spmv_chain = -1;   // f64 pair codes, 3-D stencils: plane-streaming chains (spmv_chain_kernel): -1 automatic = wherever the tile plan is wanted and the chains fill the chip, 1 = wherever chains exist, 0 = off.  Read at creation; 0 also at launch
     int ew_chunk = -1;     // fused recurrence kernels walk one contiguous eighth of the vectors per XCD: -1 automatic (fused_chunked), 0 / 1
     int stream_nt = -1;    // fused recurrence kernels access their vectors with non-temporal loads / stores: -1 auto (by vector size), 0 / 1
     int spmv_uniform = -1; // ... and blocks whose rows all repeat one code sequence read neither codes nor row_ptr; read at creation
@@ -144,6 +145,21 @@ struct sprs_tile_plan {
     std::vector<int32_t> h_list, h_xstart;         // host copies of list / xstart (the distributed operator cuts its interior plan from them)
 };
 
+// Plane-streaming CHAINS of the f64 pair-code stream (spmv_chain.hip, round 4): a pattern with exactly one far slot a side at
+// -Pf / +Pf (a 3-D stencil's plane neighbours).  A chain = tiles of CH_B uniform 128-row blocks at rows ts, ts + Pf, ts + 2 Pf, ...
+// (each within 127 rows of that, on the 128-row block grid); a workgroup walks a segment of a chain keeping the x windows of three
+// consecutive tiles in LDS, so the +-Pf operands come from the neighbouring tiles' windows: no far load at all.
+struct sprs_chain_plan {
+    int32_t *tiles = nullptr;      // device, int4 per tile: {first 128-row block, first row, first row of the NEXT window (the chain's next tile, or ts + Pf), 0}; segments contiguous
+    int32_t *segs = nullptr;       // device, int2 per segment: {first tile, tiles}
+    int32_t *xstart = nullptr;     // device, 9 entries: per-XCD ranges of segs
+    int32_t *left = nullptr;       // device: the 128-row blocks outside the chains, in the per-block kernel's walk order
+    int n_tile = 0, n_seg = 0, n_chain = 0, n_left = 0;
+    int ul = 0, tri = 0;           // pattern slots; tri: the near slots are (.., c - 1, c, c + 1, ..) around an even centre, the others even (16-byte LDS reads)
+    int32_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double val[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
 struct sprs_dist_info {
     sprs_comm *comm = nullptr;
     int64_t n_local = 0, n_ext = 0;
@@ -186,6 +202,7 @@ struct sprs_dict {
     // tile plans of spmv_tile_kernel (f64, HBM-sized stencil-like matrices): one for the pair-code stream, one for the
     // offset-code stream (values per entry) when that is the stream the handle multiplies with
     sprs_tile_plan tile_pair, tile_off;
+    sprs_chain_plan chain_pair;    // plane-streaming chains of the pair-code stream (preferred over tile_pair where it exists; knob "spmv_chain")
     void *owide_desc = nullptr;    // device: 128-row descriptors of the offset-code stream (uniform / seam blocks marked on its codes)
     int n_owide = 0;
     void *off_desc = nullptr;      // device: copy of blk_desc for the offset-code stream with the uniform blocks flagged (bit 30, nn = row length)
@@ -234,6 +251,7 @@ int launch_spmv(const sprs_csr *A, const T *x, T *y, int dot_mode, const T *u, T
                 bool conj_x = false, const Fin *fin = nullptr);
 int tile_blocks();   // 128-row blocks per LDS-window tile (spmv_dict.hip)
 bool tile_plan_used(const sprs_csr *A);   // the SpMV of this handle runs through its tile plan
+bool chain_plan_used(const sprs_csr *A);  // ... through its plane-streaming chains (spmv_chain.hip)
 int build_rowblocks(sprs_csr *A, const int32_t *host_row_ptr);   // host_row_ptr == null: row_ptr lives in HBM only (summaries first)
 int validate_cols_device(const sprs_csr *A);   // SPRS_INVALID_ARGUMENT if any col_idx is outside [0, ncols)
 int spmv_num_partials(const sprs_csr *A);  // workgroups launch_spmv uses == partials it writes

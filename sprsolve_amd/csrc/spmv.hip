@@ -628,7 +628,9 @@ static inline int base_grid(const sprs_csr *A) {
         g = A->ctx->num_cu * ((wide_loads(A) && !is_cache_resident(A)) ? 3 : 4);
         // LDS-window tiles are coarse work items (4096 rows): a matrix with few of them gets fewer workgroups, about three
         // tiles each, rather than 1024 workgroups with one or two (the N = 8 slab: 1525 tiles; profiles/r03_tuning.md §9)
-        if (tile_plan_used(A)) {
+        if (chain_plan_used(A)) {
+            g = A->ctx->num_cu * 2;           // plane-streaming chains: three x windows = 72 KiB of LDS, two workgroups per CU, about one chain segment each
+        } else if (tile_plan_used(A)) {
             const int nt = dict_mode(A) == 2 ? A->dict->tile_pair.n_tile : A->dict->tile_off.n_tile;
             g = std::min(g, std::max(64, (nt / 3) & ~7));
         }

@@ -531,12 +531,151 @@ template <class T> struct has_val_dict { static constexpr bool value = false; };
 template <> struct has_val_dict<double> { static constexpr bool value = true; };
 template <> struct has_val_dict<float> { static constexpr bool value = true; };
 
+// Chain plan (spmv_chain.hip) of the pair-code stream: flag[j] = 128-row block j is a full uniform (plain or seam) block of the
+// canonical pattern off[0..UL), which has exactly one far slot a side.  Tiles of CH_B blocks are placed greedily on the runs of
+// flagged blocks; a tile at row ts is linked to the tile that starts within 127 rows of ts + Pf (runs in consecutive planes start
+// at their own first full block, so the 128-row grid drifts against the plane by a few rows per plane); the linked lists are the
+// chains.  Every chain is cut into equal segments so that all chains together give about one segment per workgroup (2 per CU:
+// three windows are 72 KiB of LDS), XCD x takes a contiguous eighth of the chains ordered by their column position (neighbouring
+// columns share the 2W window margins through that XCD's L2), segment-of-all-its-chains by segment.  The plan is dropped unless it
+// covers most of the flagged blocks in segments long enough to amortise their two priming windows and fills the chip.
+template <class MakeLeft>
+static int build_chain_plan(sprs_csr *A, sprs_chain_plan &CP, const std::vector<BlkDescHost2> &wd, const std::vector<uint8_t> &flag, int UL,
+                            const int32_t *off, const double *val, MakeLeft &&make_left) {
+    sprs_ctx *c = A->ctx;
+    const int nw = (int)wd.size();
+    const int64_t Pf = off[UL - 1];
+    if (UL < 3 || UL > 7 || (UL & 1) == 0 || -(int64_t)off[0] != Pf || (Pf & 1) || Pf < 2 * (int64_t)TILE_W) return SPRS_OK;
+    for (int t = 1; t + 1 < UL; ++t) if (off[t] < -(TILE_W - 2) || off[t] > TILE_W - 2) return SPRS_OK;     // far, near.., far on the narrow window
+    bool shape_ok = false;
+#define SPRS_CH_HAS(U, TR) if (UL == U) shape_ok = true;
+    SPRS_CHAIN_SHAPES(SPRS_CH_HAS)
+#undef SPRS_CH_HAS
+    if (!shape_ok) return SPRS_OK;
+    const int CHR = CH_B * 2 * WAVE;
+    // TRI: near slots (.., c - 1, c, c + 1, ..) around an even centre, every other near offset even
+    const int NN = UL - 2, TC = NN / 2;
+    bool tri = (off[1 + TC] & 1) == 0;
+    for (int t = 0; t < NN && tri; ++t) {
+        if (t == TC - 1) tri = off[1 + t] == off[1 + TC] - 1;
+        else if (t == TC + 1) tri = off[1 + t] == off[1 + TC] + 1;
+        else tri = (off[1 + t] & 1) == 0;
+    }
+    if (!tri && UL == 3) return SPRS_OK;                                  // (only the 16-byte shape is built for UL = 3)
+    std::vector<int32_t> tb;                                              // first block of each tile, row order
+    std::vector<char> in_chain((size_t)nw, 0);
+    int64_t flagged = 0;
+    for (int j = 0; j < nw;) {
+        if (!flag[(size_t)j]) { ++j; continue; }
+        int e = j + 1;
+        while (e < nw && flag[(size_t)e] && wd[(size_t)e].ra == wd[(size_t)e - 1].ra + 2 * WAVE) ++e;
+        flagged += e - j;
+        for (int b = j; b + CH_B <= e; b += CH_B) {
+            const int64_t ra = wd[(size_t)b].ra;
+            if (ra - Pf < 0 || ra + CHR + Pf > A->ncols) continue;        // the -Pf / +Pf centres lie inside x (they do for every flagged block; belt and braces)
+            tb.push_back(b);
+        }
+        j = e;
+    }
+    const int nt = (int)tb.size();
+    if (nt < 64) return SPRS_OK;
+    // links: tile i -> the tile that starts within 127 rows of ra_i + Pf
+    std::vector<int32_t> next((size_t)nt, -1), prev((size_t)nt, -1);
+    {
+        std::vector<int64_t> ras((size_t)nt);
+        for (int i = 0; i < nt; ++i) ras[(size_t)i] = wd[(size_t)tb[(size_t)i]].ra;
+        for (int i = 0; i < nt; ++i) {
+            const int64_t want = ras[(size_t)i] + Pf;
+            const auto it = std::lower_bound(ras.begin(), ras.end(), want - 127);
+            if (it == ras.end() || *it > want + 127) continue;
+            const int j2 = (int)(it - ras.begin());
+            if (prev[(size_t)j2] >= 0) continue;
+            next[(size_t)i] = j2; prev[(size_t)j2] = i;
+        }
+    }
+    struct Chain { int head; int len; int64_t col; };
+    std::vector<Chain> chains;
+    for (int i = 0; i < nt; ++i) {
+        if (prev[(size_t)i] >= 0) continue;
+        int len = 0;
+        for (int q = i; q >= 0; q = next[(size_t)q]) ++len;
+        chains.push_back(Chain{i, len, (int64_t)wd[(size_t)tb[(size_t)i]].ra % Pf});
+    }
+    std::stable_sort(chains.begin(), chains.end(), [](const Chain &a, const Chain &b) { return a.col < b.col; });
+    const int nch = (int)chains.size();
+    const int G = 2 * c->num_cu;                                          // workgroups of the chain launch
+    // segments: q per chain, about G / nch, none shorter than 8 tiles (two priming windows each)
+    std::vector<int32_t> tiles, segs, xstart(9, 0);
+    int64_t covered = 0;
+    int n_seg = 0;
+    for (int xq = 0; xq < 8; ++xq) {
+        xstart[(size_t)xq] = n_seg;
+        const int c_lo = (int)((int64_t)nch * xq / 8), c_hi = (int)((int64_t)nch * (xq + 1) / 8);
+        std::vector<std::vector<std::pair<int, int>>> cs((size_t)(c_hi - c_lo));   // per chain: (first position in chain, count) of its segments
+        size_t maxq = 0;
+        for (int ci = c_lo; ci < c_hi; ++ci) {
+            const int len = chains[(size_t)ci].len;
+            int q = std::max(1, G / std::max(nch, 1));
+            q = std::max(1, std::min(q, len / 8));
+            for (int k = 0; k < q; ++k) {
+                const int a = (int)((int64_t)len * k / q), b = (int)((int64_t)len * (k + 1) / q);
+                if (b > a) cs[(size_t)(ci - c_lo)].push_back({a, b - a});
+            }
+            maxq = std::max(maxq, cs[(size_t)(ci - c_lo)].size());
+        }
+        // flatten every chain of this XCD once: tile ids in chain order
+        std::vector<std::vector<int32_t>> ids((size_t)(c_hi - c_lo));
+        for (int ci = c_lo; ci < c_hi; ++ci)
+            for (int q = chains[(size_t)ci].head; q >= 0; q = next[(size_t)q]) ids[(size_t)(ci - c_lo)].push_back(q);
+        for (size_t k = 0; k < maxq; ++k)
+            for (int ci = c_lo; ci < c_hi; ++ci) {
+                const auto &sv = cs[(size_t)(ci - c_lo)];
+                if (k >= sv.size()) continue;
+                const auto &idv = ids[(size_t)(ci - c_lo)];
+                segs.push_back((int32_t)(tiles.size() / 4)); segs.push_back(sv[k].second);
+                for (int p2 = sv[k].first; p2 < sv[k].first + sv[k].second; ++p2) {
+                    const int ti = idv[(size_t)p2];
+                    const int b0 = tb[(size_t)ti];
+                    const int32_t ra = wd[(size_t)b0].ra;
+                    const int32_t ra_next = next[(size_t)ti] >= 0 ? wd[(size_t)tb[(size_t)next[(size_t)ti]]].ra : (int32_t)(ra + Pf);
+                    tiles.push_back(b0); tiles.push_back(ra); tiles.push_back(ra_next); tiles.push_back(0);
+                    for (int qb = 0; qb < CH_B; ++qb) in_chain[(size_t)(b0 + qb)] = 1;
+                    covered += CH_B;
+                }
+                ++n_seg;
+            }
+    }
+    xstart[8] = n_seg;
+    const int n_tile = (int)(tiles.size() / 4);
+    // worth it?  (forced by knob 1 whenever chains exist)
+    const bool fills = n_seg * 2 >= G && covered * 2 >= flagged && n_tile >= 6 * n_seg;
+    if (n_tile == 0 || (c->spmv_chain < 0 && !fills)) return SPRS_OK;
+    std::vector<int32_t> left;
+    make_left(in_chain, left);
+    auto drop = [&]() { for (void *q : {(void *)CP.tiles, (void *)CP.segs, (void *)CP.xstart, (void *)CP.left}) if (q) (void)hipFree(q); CP = sprs_chain_plan(); };
+#define CH_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { snprintf(c->err, sizeof(c->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); drop(); return SPRS_ERR_HIP; } } while (0)
+    CH_TRY(hipMalloc((void **)&CP.tiles, sizeof(int32_t) * tiles.size()));
+    CH_TRY(hipMalloc((void **)&CP.segs, sizeof(int32_t) * segs.size()));
+    CH_TRY(hipMalloc((void **)&CP.xstart, sizeof(int32_t) * 9));
+    CH_TRY(hipMalloc((void **)&CP.left, sizeof(int32_t) * std::max<size_t>(left.size(), 1)));
+    CH_TRY(hipMemcpyAsync(CP.tiles, tiles.data(), sizeof(int32_t) * tiles.size(), hipMemcpyHostToDevice, c->stream));
+    CH_TRY(hipMemcpyAsync(CP.segs, segs.data(), sizeof(int32_t) * segs.size(), hipMemcpyHostToDevice, c->stream));
+    CH_TRY(hipMemcpyAsync(CP.xstart, xstart.data(), sizeof(int32_t) * 9, hipMemcpyHostToDevice, c->stream));
+    if (!left.empty()) CH_TRY(hipMemcpyAsync(CP.left, left.data(), sizeof(int32_t) * left.size(), hipMemcpyHostToDevice, c->stream));
+    CH_TRY(hipStreamSynchronize(c->stream));
+#undef CH_TRY
+    CP.n_tile = n_tile; CP.n_seg = n_seg; CP.n_chain = nch; CP.n_left = (int)left.size();
+    CP.ul = UL; CP.tri = tri ? 1 : 0;
+    for (int t = 0; t < 8; ++t) { CP.off[t] = t < UL ? off[t] : 0; CP.val[t] = t < UL ? val[t] : 0.0; }
+    return SPRS_OK;
+}
+
 // Tile plan of a stream's 128-row descriptors `desc_dev` (marked by mark_uniform_kernel on the codes `code_dev`; host copy of
 // the unmarked descriptors: wd).  off_tab / val_tab: host tables per code (val_tab null: a stream whose values are per entry).
 // make_left(in_tile, left) lists the blocks the tiles do not cover, in the walk order of the stream's per-block kernel.
 template <class MakeLeft>
 static int build_tile_plan(sprs_csr *A, sprs_tile_plan &TP, const BlkDesc *desc_dev, const uint8_t *code_dev, const std::vector<BlkDescHost2> &wd,
-                           const int32_t *off_tab, const double *val_tab, bool wide_window_ok, MakeLeft &&make_left) {
+                           const int32_t *off_tab, const double *val_tab, bool wide_window_ok, MakeLeft &&make_left, sprs_chain_plan *CP = nullptr) {
     sprs_ctx *c = A->ctx;
     const int nw = (int)wd.size();
     const int n_cand = nw / TILE_B;
@@ -599,6 +738,10 @@ static int build_tile_plan(sprs_csr *A, sprs_tile_plan &TP, const BlkDesc *desc_
     TILE_TRY(hipStreamSynchronize(c->stream));
     if (!val_tab)      // values per entry: 16-byte value loads may reach one entry past a block's last one — keep the matrix's last entries out
         for (int j = 0; j < nw; ++j) if ((int64_t)wd[(size_t)j].pa + 2 * WAVE * UL + 2 > A->nnz) flag[(size_t)j] = 0;
+    if (CP && c->spmv_chain != 0 && val_tab) {
+        // plane-streaming chains (spmv_chain.hip) on the same runs; the tile plan below is kept beside them (knob, distributed interior)
+        if (const int st = build_chain_plan(A, *CP, wd, flag, UL, TP.off, TP.val, make_left)) { drop(); return st; }
+    }
     std::vector<int32_t> starts;                            // first block of each tile, in row order
     std::vector<char> in_tile((size_t)nw, 0);
     for (int j = 0; j < nw;) {
@@ -860,7 +1003,7 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const std::vector
                                 const int j = ord.empty() ? pos : ord[(size_t)pos];
                                 if (!in_tile[(size_t)j]) left.push_back(j);
                             }
-                        })) { cleanup2(); free_dict(A); return st; }
+                        }, &D->chain_pair)) { cleanup2(); free_dict(A); return st; }
                     tr.lap("    tile plan");
                 }
             }
@@ -913,12 +1056,19 @@ bool tile_plan_used(const sprs_csr *A) {
     return dm == 1 && A->dict->tile_off.n_tile > 0 && A->tail != nullptr && c->spmv_wideload != 0 && c->spmv_uniform != 0;
 }
 
+bool chain_plan_used(const sprs_csr *A) {
+    const sprs_ctx *c = A->ctx;
+    if (!A->dict || A->dist || c->spmv_chain == 0 || c->spmv_tile == 0 || c->spmv_wide == 0 || c->spmv_uniform == 0) return false;
+    return dict_mode(A) == 2 && A->dict->chain_pair.n_tile > 0;
+}
+
 void free_dict(sprs_csr *A) {
     if (!A || !A->dict) return;
     sprs_dict *D = A->dict;
     for (void *q : {(void *)D->idx_code, (void *)D->pair_code, (void *)D->off_tab, (void *)D->pair_off, D->pair_val, D->wide_desc, D->off_desc, (void *)D->wide_order, (void *)D->off_order,
                     (void *)D->tile_pair.list, (void *)D->tile_pair.xstart, (void *)D->tile_pair.left,
-                    (void *)D->tile_off.list, (void *)D->tile_off.xstart, (void *)D->tile_off.left, D->owide_desc})
+                    (void *)D->tile_off.list, (void *)D->tile_off.xstart, (void *)D->tile_off.left, D->owide_desc,
+                    (void *)D->chain_pair.tiles, (void *)D->chain_pair.segs, (void *)D->chain_pair.xstart, (void *)D->chain_pair.left})
         if (q) (void)hipFree(q);
     delete D;
     A->dict = nullptr;
@@ -972,6 +1122,8 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
         const sprs_tile_plan *tpp = nullptr;
         if (pair && whole && D->tile_pair.n_tile > 0) tpp = &D->tile_pair;
         else if (pair && interior && !A->dist->tile_int_off) tpp = &A->dist->tile_int;
+        if (pair && whole && g % 8 == 0 && chain_plan_used(A))      // plane-streaming chains + the per-block walk over the blocks outside them, one launch (spmv_chain.hip)
+            return launch_chain_pair(A, D->chain_pair, g, x, y, dot_mode, u, part0, part1, status, fin);
         if (tpp && c->spmv_tile != 0 && c->spmv_wide != 0 && g % 8 == 0) {
             // LDS x-window tiles + the per-block walk over the blocks outside them, one launch (spmv_tile.hip)
             return launch_tile_pair(A, *tpp, g, x, y, dot_mode, u, part0, part1, status, fin);

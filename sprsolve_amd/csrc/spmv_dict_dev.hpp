@@ -623,8 +623,15 @@ struct TilePat { int32_t off[8]; double val[8]; };
 #define SPRS_TILE_SHAPES(X) X(7, 1, 1) X(5, 1, 1) X(5, 0, 0) X(3, 0, 0) X(3, 1, 1) X(7, 0, 0)
 // ... and with the wide window (pair-code stream only; grids whose lines are 511 to 1534 long)
 #define SPRS_TILE_SHAPES_WIDE(X) X(7, 1, 1) X(5, 1, 1) X(5, 0, 0) X(7, 0, 0)
+// plane-streaming chains (spmv_chain.hip): 128-row blocks per chain tile, and the (UL, TRI) shapes the kernel is built for
+constexpr int CH_B = 16;
+#define SPRS_CHAIN_SHAPES(X) X(7, true) X(7, false) X(5, true) X(5, false) X(3, true)
 }  // namespace
 
+// ---- spmv_chain.hip: the chains of plan CP + the per-block walk over the blocks outside them, one launch
+int launch_chain_pair(const sprs_csr *A, const sprs_chain_plan &CP, int g, const double *x, double *y, int dot_mode, const double *u,
+                      double *part0, double *part1, const int *status, const Fin &fin);
+int chain_rows();
 // ---- spmv_tile.hip / spmv_tile_off.hip: one launch = the tiles of plan TP + the per-block walk over the blocks outside them
 int launch_tile_pair(const sprs_csr *A, const sprs_tile_plan &TP, int g, const double *x, double *y, int dot_mode, const double *u,
                      double *part0, double *part1, const int *status, const Fin &fin);

@@ -110,6 +110,13 @@ class HipCsr(MatVecMul):
         check(_lib.lib().sprs_csr_tile_plan(self.h, C.byref(a), C.byref(b), C.byref(c)), self.ctx.h)
         return a.value, b.value, c.value
 
+    def chain_plan(self):
+        """(n_tiles, n_segments, n_chains, n_other_blocks) of the f64 pair-code stream's plane-streaming chains (knob spmv_chain;
+        they take precedence over the LDS-window tiles), else zeros."""
+        a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(_lib.lib().sprs_csr_chain_plan(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), self.ctx.h)
+        return a.value, b.value, c.value, d.value
+
     # -------------------------------------------------------------- MatVecMul
     def _s(self):
         return sfx(self.dtype)

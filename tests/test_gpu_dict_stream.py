@@ -705,6 +705,115 @@ def test_lds_window_tiles_bit_identical(sa, oracle, name):
         ctx.set("spmv_tile", -1)
 
 
+def _chain_cases():
+    from sprsolve_amd import gen
+    def p3(nx, ny, nz):
+        ip, ix, d, rhs = gen.poisson3d(nx, ny, nz)
+        return ip, ix, d, rhs, 1.0
+    def dirichlet(r):
+        ip, ix, d = gen.grid_laplacian_dirichlet(r, r)
+        return ip, ix, d, None, None
+    return {
+        "p3_160x128x24": lambda: p3(160, 128, 24),            # 9 chains of 22 tiles; plane = 160 x 128: the 128-row grid does not drift
+        "p3_500x100x14_seams_drift": lambda: p3(500, 100, 14),  # cfg 5's line length (seams in every block); plane 50000 = 390.6 blocks: tiles drift by 80 rows a plane
+        "p3_250x84x20_drift": lambda: p3(250, 84, 20),        # plane 21000 = 164.06 blocks: 8 rows a plane, chains survive all 18 planes
+        "p2_dirichlet_1200_far_lines": lambda: dirichlet(1200),   # UL = 5, far = +-1200 < a tile: no tile links to another — chains of one tile (both windows virtual)
+    }
+
+
+@pytest.mark.parametrize("name", list(_chain_cases()))
+def test_plane_streaming_chains_bit_identical(sa, oracle, name):
+    """Knob spmv_chain (csrc/spmv_chain.hip): for patterns with one far slot a side at -P / +P a workgroup walks a column of
+    2048-row tiles plane by plane with the x windows of three consecutive tiles in LDS — the +-P operands come from the
+    neighbouring tiles' windows, no far load exists.  Same products, same left-to-right fold per row (seam rows included): y
+    bit-identical to the oracle, to the tile kernel and to the per-block kernel, in every launch flavour a solve uses (plain; dot
+    with another vector; dot with the input vector; double dot with the input / with another vector)."""
+    ctx = sa.default_ctx(0)
+    indptr, cols, data, rhs, exact = _chain_cases()[name]()
+    n = indptr.size - 1
+    x = rand_vec(n, np.float64, 79)
+    ref = oracle.spmv(indptr, cols, data, x)
+    e = oracle.conj_dot(x, ref)
+    got = {}
+    try:
+        for chain, tile in ((1, 1), (0, 1), (0, 0)):
+            ctx.set("spmv_chain", chain); ctx.set("spmv_tile", tile)
+            A = sa.HipCsr.new((n, n), indptr, cols, data)
+            assert A.stream_format()[0] == 2
+            cp, tp = A.chain_plan(), A.tile_plan()
+            if chain:
+                assert cp[0] >= 64 and tp == (0, 0, 0), (cp, tp)
+                nb, _ = A.wide_blocks()
+                assert 16 * cp[0] + cp[3] == nb and 16 * cp[0] >= 0.3 * nb, (cp, nb)
+                if name.startswith("p3_"):
+                    assert cp[0] >= 6 * cp[2], cp                           # chains run through the planes (>= 6 tiles each on average)
+                else:
+                    assert cp[0] == cp[2] == cp[1], cp                      # chains of one tile
+            else:
+                assert cp == (0, 0, 0, 0) and (tp[0] >= 8) == bool(tile), (cp, tp)
+            y = np.full(n, 9.0)
+            A.mul_vec(x, y)
+            bad = np.flatnonzero(y != ref)
+            assert bad.size == 0, (chain, tile, bad[:8], bad.size)
+            assert np.array_equal(bits(y), bits(ref))
+            y2 = np.full(n, -3.0)
+            d = A.mul_vec_dot(x, y2)                                         # DOT 1, operand = the input vector (from the window)
+            assert np.array_equal(bits(y2), bits(ref))
+            assert abs(d - e) <= 1e-12 * max(1.0, float(np.sum(np.abs(x * ref))))
+            if rhs is not None:
+                s = sa.BiCGStab.new(A, n); s.set_trace(8)
+                sol = np.zeros(n)
+                its, res = s.solve(rhs, sol, 3000, 1e-9)                     # K2: DOT 1 with r0; K4: DOT 2 with its input
+                assert np.max(np.abs(sol - exact)) < 1e-6
+                sj = sa.BiCGStab.new(A, n); solj = np.zeros(n)
+                itsj, resj = sj.precond_solve(sa.DiagPrecond.new(np.full(n, 6.0)), rhs, solj, 3000, 1e-9)   # K4: DOT 2 with another vector
+                assert np.max(np.abs(solj - exact)) < 1e-6
+                m = sa.MinRes.new(A, n); sol2 = np.zeros(n)
+                its2, res2 = m.solve(rhs, sol2, 3000, 1e-9)
+                assert np.max(np.abs(sol2 - exact)) < 1e-5, (its2, res2)
+                got[(chain, tile)] = (its, res, bits(sol).copy(), s.trace().copy(), itsj, bits(solj).copy(), its2, bits(sol2).copy())
+        if rhs is not None:
+            # chains and tiles group the rows into the same workgroups' partials differently (the grids differ), so the solves agree
+            # to rounding; the iteration counts at 1e-9 must be close and the first trace rows equal to 1e-9
+            a, b = got[(1, 1)], got[(0, 1)]
+            # (BiCGStab's count at 1e-9 is reduction-order noise, SURVEY §6; MINRES' is not)
+            assert abs(a[0] - b[0]) <= max(3, b[0] // 4) and abs(a[4] - b[4]) <= max(3, b[4] // 4) and abs(a[6] - b[6]) <= max(2, b[6] // 20)
+            assert np.allclose(a[3][:4], b[3][:4], rtol=1e-9, atol=1e-12)
+    finally:
+        ctx.set("spmv_chain", -1); ctx.set("spmv_tile", -1)
+
+
+def test_plane_streaming_chains_policy(sa, oracle):
+    """Automatic policy: chains only where they fill the chip (about one segment of >= 6 tiles per workgroup) — a 6 M-row
+    500 x 200 x 60 grid (46 MiB vectors: tiles wanted, 48 chains cut into 7 segments each) qualifies; small grids keep the tile
+    plan under spmv_tile = 1; with spmv_chain = 0 at LAUNCH time a handle that has chains multiplies through its tile plan
+    instead (same y)."""
+    from sprsolve_amd import gen
+    ctx = sa.default_ctx(0)
+    try:
+        ctx.set("spmv_tile", 1)
+        ip, ix, d, rhs = gen.poisson3d(160, 128, 24)
+        n = rhs.size
+        A = sa.HipCsr.new((n, n), ip, ix, d)
+        assert A.chain_plan() == (0, 0, 0, 0) and A.tile_plan()[0] >= 8       # 18 segments would leave most of the chip idle
+        ctx.set("spmv_tile", -1)
+        ip, ix, d, rhs = gen.poisson3d(500, 200, 60)
+        n = rhs.size
+        A = sa.HipCsr.new((n, n), ip, ix, d)
+        cp = A.chain_plan()
+        assert cp[0] >= 2500 and cp[1] >= 256 and cp[0] >= 6 * cp[1] and A.tile_plan() == (0, 0, 0), cp
+        x = rand_vec(n, np.float64, 3)
+        ref = oracle.spmv(ip, ix, d, x)
+        y = np.zeros(n); A.mul_vec(x, y)
+        assert np.array_equal(bits(y), bits(ref))
+        ctx.set("spmv_chain", 0)                                               # launch-time: the same handle through its tiles
+        assert A.chain_plan() == (0, 0, 0, 0) and A.tile_plan()[0] >= 8
+        y = np.zeros(n); A.mul_vec(x, y)
+        assert np.array_equal(bits(y), bits(ref))
+    finally:
+        ctx.set("spmv_chain", -1); ctx.set("spmv_tile", -1)
+
+
 def test_lds_window_tiles_policy_and_fallbacks(sa, oracle):
     """Automatic policy: cache-resident matrices keep the per-block kernel (no plan); patterns the kernel is not built for
     (near slots beyond the window, unsorted far / near order, more than 8 slots) get no plan under spmv_tile = 1 either and
