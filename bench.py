@@ -171,10 +171,13 @@ def stream_info(A, n, nnz, s):
     return out
 
 
-def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8, dot_launches=0):
+def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8, dot_launches=0, fused=(0, 0)):
     """The roofline object of one measured SpMV kernel: fraction of the HBM peak on the bytes it READS AND WRITES.
-    dot_launches: how many of the `launches` read a dot operand that is not their input vector (n*s bytes each)."""
-    moved = sinfo["bytes_moved_per_launch"] + (n * s * dot_launches / launches if launches else 0.0)
+    dot_launches: how many of the `launches` read a dot operand that is not their input vector (n*s bytes each).
+    fused = (K2 launches, K4 launches) that formed their input on the fly (csrc/krylov.hip "fused SpMV input"): such a K4 also reads v
+    and writes s (2 more vectors), such a K2 also reads p and r and writes p' (3 more) — the passes of the K3 / K1 launches they replace."""
+    extra_vec = 3 * fused[0] + 2 * fused[1]
+    moved = sinfo["bytes_moved_per_launch"] + (n * s * (dot_launches + extra_vec) / launches if launches else 0.0)
     r = dict(bound="hbm", kernel=KERNEL_NAMES[sinfo.get("kernel_id", sinfo["mode"])], achieved=moved / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
              frac=moved / t_spmv / 1e9 / HBM_PEAK_GBS, traffic=None, stream=sinfo["stream"], bytes_per_nnz=sinfo["bytes_per_nnz"],
              algorithmic_bytes_per_launch=moved, bytes_moved_per_launch=moved,
@@ -185,6 +188,10 @@ def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8, dot_launches=0):
              format_bytes_per_launch=sinfo["format_bytes_per_launch"],
              frac_format_bytes=sinfo["format_bytes_per_launch"] / t_spmv / 1e9 / HBM_PEAK_GBS,
              avg_launch_us=t_spmv * 1e6, launches=launches)
+    if extra_vec:
+        r["fused_launches"] = dict(k2_with_k1=fused[0], k4_with_k3=fused[1],
+                                   note="these launches also form the vector update that produces their input (K1 / K3 of the five-launch iteration: "
+                                        "3 / 2 more vector passes each, counted in the bytes above); avg_launch_us is the mean over ALL timed SpMV launches")
     if sinfo["mode"] != 0:
         r["frac_format_bytes_note"] = "the format's size / time: counts code bytes and row_ptr the kernel does not read; NOT the roofline fraction"
         r["csr_equivalent_GBs"] = spmv_bytes(n, nnz, s) / t_spmv / 1e9
@@ -706,7 +713,7 @@ def main():
         it_bytes = 2 * spmv_bytes(n_glob, nnz_glob, 8) + 26 * n_glob * 8
         n_rank = sinfo.get("rows", n_glob)
         nnz_rank = sinfo.get("nnz", nnz_glob)
-        roof = roofline_of(sinfo, t_spmv, prof["spmv_launches"], n_rank, nnz_rank, 8, dot_l)
+        roof = roofline_of(sinfo, t_spmv, prof["spmv_launches"], n_rank, nnz_rank, 8, dot_l, (prof.get("fused_k2", 0), prof.get("fused_k4", 0)))
         if world == 1 and (nx, ny, nz) == (500, 500, 200) and not args.force_dist:
             key = {0: "cfg5_csr", 1: "cfg5_random", 2: "cfg5_pair"}[sinfo["mode"]]
             roof["traffic"], roof["traffic_note"], roof["traffic_stale"] = pmc_traffic(key)

@@ -92,6 +92,9 @@ int sprs_version(void);
  *                   column of 2048-row tiles plane by plane with the x windows of three consecutive tiles in LDS — no far
  *                   load at all: -1 automatic = wherever "spmv_tile" applies and the chains fill the chip, 1 = wherever
  *                   chains exist, 0 = off (sprs_csr_chain_plan reports what a handle got)  (creation; 0 also at launch)
+ *   "spmv_fuse"     BiCGStab, f64, no preconditioner, one GPU, SpMV through chains: the vector updates that produce an SpMV's
+ *                   input (r -= alpha v before t = A r; p = (v (-beta w) + p beta) + r before v = A p) are formed inside that
+ *                   SpMV — three launches per iteration instead of five, every scalar and element bit-identical; 0 = off (per solve)
  *   "spmv_eqrows"   plain CSR: blocks of equal-length rows do not read row_ptr                           (creation)
  *   "spmv_wideload" plain CSR, f64: 16-byte stream loads (4 entries per lane), 3 workgroups per CU on HBM-sized
  *                   matrices; 0 = the kernel with 4- / 8-byte loads                                      (creation)
@@ -427,6 +430,10 @@ int sprs_solver_trace_rows(const void *solver, int kind, size_t *rows_out);
 int sprs_solver_set_profile(void *solver, int kind, int enable);
 int sprs_solver_get_profile(const void *solver, int kind, double *spmv_ms_total, int64_t *spmv_launches,
                             double *solve_ms_total);
+/* How many SpMV launches of the last solve formed their input vector on the fly (ctx knob "spmv_fuse"): BiCGStab's K2 with K1's
+ * update p = (v (-beta w) + p beta) + r inside, K4 with K3's r -= alpha v inside (bicg_stab.rs:155-156,172).  Zero for the other
+ * solvers and wherever the five-launch iteration ran. */
+int sprs_solver_get_fused_launches(const void *solver, int kind, int64_t *k2_fused, int64_t *k4_fused);
 
 #ifdef __cplusplus
 }

@@ -54,7 +54,9 @@ class _SolverBase:
     def profile(self):
         ms = C.c_double(); n = C.c_int64(); tot = C.c_double()
         check(_lib.lib().sprs_solver_get_profile(self.h, self.KIND, C.byref(ms), C.byref(n), C.byref(tot)), self.A.ctx.h)
-        return dict(spmv_ms_total=ms.value, spmv_launches=n.value, solve_ms=tot.value)
+        k2 = C.c_int64(); k4 = C.c_int64()
+        check(_lib.lib().sprs_solver_get_fused_launches(self.h, self.KIND, C.byref(k2), C.byref(k4)), self.A.ctx.h)
+        return dict(spmv_ms_total=ms.value, spmv_launches=n.value, solve_ms=tot.value, fused_k2=k2.value, fused_k4=k4.value)
 
     # ---- the call itself
     def _solve(self, precond, rhs, x, max_iter, tol, want_precond):

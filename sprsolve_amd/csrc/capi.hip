@@ -115,6 +115,7 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     else if (k == "spmv_seam") c->spmv_seam = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_tile") c->spmv_tile = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_chain") c->spmv_chain = value < 0 ? -1 : (value ? 1 : 0);
+    else if (k == "spmv_fuse") c->spmv_fuse = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "ew_chunk") c->ew_chunk = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "stream_nt") c->stream_nt = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_eqrows") c->spmv_eqrows = value < 0 ? -1 : (value ? 1 : 0);
@@ -139,6 +140,7 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     if (k == "spmv_seam") return c->spmv_seam;
     if (k == "spmv_tile") return c->spmv_tile;
     if (k == "spmv_chain") return c->spmv_chain;
+    if (k == "spmv_fuse") return c->spmv_fuse;
     if (k == "ew_chunk") return c->ew_chunk;
     if (k == "stream_nt") return c->stream_nt;
     if (k == "spmv_eqrows") return c->spmv_eqrows;
@@ -749,6 +751,14 @@ int sprs_solver_get_profile(const void *solver, int kind, double *spmv_ms, int64
         if (spmv_ms) *spmv_ms = b->stats.spmv_ms;
         if (launches) *launches = b->stats.spmv_launches;
         if (solve_ms) *solve_ms = b->stats.solve_ms;
+        return (int)SPRS_OK;
+    });
+}
+
+int sprs_solver_get_fused_launches(const void *solver, int kind, int64_t *k2_fused, int64_t *k4_fused) {
+    return with_base(const_cast<void *>(solver), kind, [&](auto *b) {
+        if (k2_fused) *k2_fused = b->stats.fused_k2;
+        if (k4_fused) *k4_fused = b->stats.fused_k4;
         return (int)SPRS_OK;
     });
 }

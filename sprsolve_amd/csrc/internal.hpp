@@ -59,6 +59,7 @@ struct sprs_ctx {
     int spmv_seam = -1;    // f64 pair codes: blocks that are uniform but for one or two adjacent rows lacking one slot run the uniform path; 0 = off.  Read at creation
     int spmv_tile = -1;    // f64 compressed streams: LDS x-window tiles for the near columns of uniform stencil runs (spmv_tile_kernel, spmv_tile_off_kernel): -1 automatic = vectors of 44 MiB and more (tile_wanted), 1 = every matrix that has such runs, 0 = off.  Read at creation; 0 also at launch
     int spmv_chain = -1;   // f64 pair codes, 3-D stencils: plane-streaming chains (spmv_chain_kernel): -1 automatic = wherever the tile plan is wanted and the chains fill the chip, 1 = wherever chains exist, 0 = off.  Read at creation; 0 also at launch
+    int spmv_fuse = -1;    // BiCGStab (f64, no preconditioner, one GPU) on a handle whose SpMV runs through chains: K3 formed inside K4 and K1 inside K2 (krylov.hip, "fused SpMV input"); 0 = off.  Read per solve
     int ew_chunk = -1;     // fused recurrence kernels walk one contiguous eighth of the vectors per XCD: -1 automatic (fused_chunked), 0 / 1
     int stream_nt = -1;    // fused recurrence kernels access their vectors with non-temporal loads / stores: -1 auto (by vector size), 0 / 1
     int spmv_uniform = -1; // ... and blocks whose rows all repeat one code sequence read neither codes nor row_ptr; read at creation

@@ -22,7 +22,10 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <type_traits>
+#include <utility>
 
+#include "bicg_fuse.hpp"
 #include "device.hpp"
 
 namespace sprs {
@@ -65,104 +68,8 @@ static int launch_fused(sprs_ctx *c, size_t n, int grid, int chunked_walk, F f) 
     return SPRS_OK;
 }
 
-__device__ __forceinline__ bool first_thread() { return blockIdx.x == 0 && threadIdx.x == 0; }
-
-// ======================================================================= BiCGStab kernels
-// K1  bicg_stab.rs:123-156 (+ :321-328 with a preconditioner)
-//   r_norm = norm2(r); converged?  rho = r0.r; restart?  beta = (rho/rho_old)*(alpha/w)
-//   p = v*(-beta*w) + p*beta ;  p += r*1 ;  [y = M^-1 p]
-template <class T, class V, bool PC>
-struct BicgK1 {
-    BicgState<T> *S; const Real<T> *partN; const T *partRho; int P; int mode;
-    const T *v; const T *r; T *p; const V *dinv; T *y;
-    T a, beta;
-    __device__ __forceinline__ bool prologue() {
-        __shared__ Real<T> smD[NWAVE];
-        __shared__ T smT[NWAVE];
-        // every load of the prologue is issued before any is consumed (state words, then both partial arrays): one
-        // memory round trip where the literal order (status -> |r| partials -> tol -> rho partials -> ...) paid four.
-        // Only fields that no workgroup of THIS launch writes are read (rho / r_norm / beta are written below).
-        const int status = S->status;
-        const Real<T> tol2 = S->tol2, r0_norm_tol = S->r0_norm_tol;
-        const T w = S->w, rho_old = S->rho_old, alpha = S->alpha;
-        T rho; Real<T> r_norm;
-        if (mode == 0) {
-            Real<T> sN; T sR;
-            reduce_partials2(partN, partRho, P, smD, smT, sN, sR);  // :123 |r|^2, :128 r0.r
-            if (status != ST_RUNNING) return false;
-            r_norm = ssqrt(sN);                                      // :123
-            if (r_norm <= tol2) {                                    // :124
-                if (first_thread()) { S->r_norm = r_norm; S->status = ST_CONVERGED; }
-                return false;
-            }
-            rho = sR;                                                // :128
-            if (sabs(rho) < r0_norm_tol) {                           // :131 -> host runs :132-145
-                if (first_thread()) { S->r_norm = r_norm; S->status = ST_RESTART; }
-                return false;
-            }
-        } else {  // resumed after the host-side restart: rho, r0_norm_tol already updated
-            if (status != ST_RUNNING) return false;
-            rho = S->rho; r_norm = S->r_norm;
-        }
-        beta = smul(sdiv(rho, rho_old), sdiv(alpha, w));             // :146
-        a = smul(sneg(beta), w);                                     // :155  -beta * w
-        if (first_thread()) { S->rho = rho; S->r_norm = r_norm; S->beta = beta; }
-        return true;
-    }
-    template <int PK, bool NT> __device__ __forceinline__ void run(int64_t i) const {
-        auto vv = ldp<T, PK, NT>(v, i); auto pv = ldp<T, PK, NT>(p, i); auto rv = ldp<T, PK, NT>(r, i);
-        Pack<T, PK> yv;
-        [[maybe_unused]] Pack<V, PK> dv;
-        if (PC) dv = ldp<V, PK, NT>(dinv, i);
-#pragma unroll
-        for (int e = 0; e < PK; ++e) {
-            T t = sadd(smul(vv.v[e], a), smul(pv.v[e], beta));      // :155 axpby
-            t = sadd(t, smul(rv.v[e], sone<T>()));                  // :156 axpy(one, r, p)
-            pv.v[e] = t;
-            if (PC) yv.v[e] = smulv(t, dv.v[e]);                    // :328
-        }
-        stp<T, PK, NT>(p, i, pv);
-        if (PC) stp<T, PK, NT>(y, i, yv);
-    }
-    __device__ __forceinline__ void epilogue() const {}
-};
-
-// K3  bicg_stab.rs:163-172 (+ :343):  alpha = rho / (r0.v) ; r -= alpha*v ; [z = M^-1 r]
-template <class T, class V, bool PC>
-struct BicgK3 {
-    BicgState<T> *S; const T *partB; int P; int check_breakdown;
-    const T *v; T *r; const V *dinv; T *z;
-    T na;
-    __device__ __forceinline__ bool prologue() {
-        __shared__ T smT[NWAVE];
-        const int status = S->status;                               // requested together with the partials
-        const T rho = S->rho;
-        const T tmp = reduce_partials(partB, P, smT);               // :163
-        if (status != ST_RUNNING) return false;
-        if (check_breakdown && sabs(tmp) <= 0.0) {                  // :164-167
-            if (first_thread()) S->status = ST_BREAKDOWN;
-            return false;
-        }
-        const T alpha = sdiv(rho, tmp);                             // :169
-        na = sneg(alpha);
-        if (first_thread()) S->alpha = alpha;
-        return true;
-    }
-    template <int PK, bool NT> __device__ __forceinline__ void run(int64_t i) const {
-        auto vv = ldp<T, PK, NT>(v, i); auto rv = ldp<T, PK, NT>(r, i);
-        Pack<T, PK> zv;
-        [[maybe_unused]] Pack<V, PK> dv;
-        if (PC) dv = ldp<V, PK, NT>(dinv, i);
-#pragma unroll
-        for (int e = 0; e < PK; ++e) {
-            rv.v[e] = sadd(rv.v[e], smul(vv.v[e], na));             // :172
-            if (PC) zv.v[e] = smulv(rv.v[e], dv.v[e]);              // :343
-        }
-        stp<T, PK, NT>(r, i, rv);
-        if (PC) stp<T, PK, NT>(z, i, zv);
-    }
-    __device__ __forceinline__ void epilogue() const {}
-};
+// (first_thread(), BicgK1 and BicgK3 live in bicg_fuse.hpp: the plane-streaming chain SpMV runs their prologues and their
+// element-wise updates inside its own launch — "fused SpMV input" below)
 
 // K5  bicg_stab.rs:178-196:  w = (t.t > 0) ? t.r / t.t : 0 ; x -= alpha*y ; x -= w*s ; r -= w*t
 //     + partials of norm2(r)^2 and r0.r for the next iteration's K1 (:123,:128)
@@ -465,10 +372,15 @@ int KrylovBase<T>::spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, con
         }
         x = xe;
     }
-    auto run = [&]() -> int {
+    return profiled([&]() -> int {
         if (A->dist) return dist_spmv<T>(A, const_cast<T *>(x), y, dot, u, p0, p1, status, conj_x, fin);
         return launch_spmv<T>(A, x, y, dot, u, p0, p1, status, conj_x, fin);
-    };
+    }, !A->dist);
+}
+
+template <class T>
+template <class F>
+int KrylovBase<T>::profiled(F &&run, bool one_kernel) {
     if (!profile) return run();
     if (ev_used + 2 > ev.size()) {
         for (int k = 0; k < 2; ++k) {
@@ -478,7 +390,7 @@ int KrylovBase<T>::spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, con
         }
     }
     int st;
-    if (!A->dist) {
+    if (one_kernel) {
         // one kernel per SpMV: the launch records its own begin / end (what rocprofv3 reports as the kernel's duration)
         ctx->prof_start = ev[ev_used]; ctx->prof_stop = ev[ev_used + 1];
         st = run();
@@ -597,7 +509,18 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
     T *v = pc ? this->vec(4) : this->vec(3);
     T *t = pc ? this->vec(5) : this->vec(4);
     T *z = pc ? this->vec(6) : nullptr;
-    const T *sz = pc ? z : r;
+    // ---- fused SpMV input (f64, no preconditioner, one GPU, plane-streaming chains; knob "spmv_fuse"): the two vector updates
+    // whose results are SpMV inputs are formed INSIDE those SpMVs (spmv_chain.hip, FUSE) — K3 (r -= alpha v, :172) in K4, K1
+    // (p = (v (-beta w) + p beta) + r, :155-156) in K2 — with K3's / K1's own prologues (bicg_fuse.hpp) and rounding sequence, so
+    // every scalar, every element and every dot partial is bit-identical to the five-launch iteration; an iteration is three
+    // launches and two passes over a vector shorter.  A tile reads its operands' windows while other tiles are still reading them, so
+    // a fused launch writes the updated vector to ANOTHER buffer: r and p alternate with the two work vectors the unpreconditioned
+    // solve leaves unused (:28 allocates seven), v and t swap roles every iteration (t is dead when K2 writes v', v when K4 writes t).
+    bool fuse = false;
+    if constexpr (std::is_same<T, double>::value && std::is_same<V, double>::value)
+        fuse = !pc && !this->A->dist && c->spmv_fuse != 0 && chain_plan_used(this->A);
+    T *ralt = fuse ? this->vec(5) : nullptr, *palt = fuse ? this->vec(6) : nullptr;
+    int pend_k1 = -1, pend_k3 = -1;          // fused: the mode / breakdown flag of the update that the next SpMV forms
 
     SPRS_TRY(this->spmv(x, r, 0, nullptr, nullptr, nullptr, nullptr));      // :73
     SPRS_TRY((launch_axpy<T, T>(c, n, sneg(sone<T>()), rhs, r)));           // :75
@@ -630,16 +553,38 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
     typename KrylovBase<T>::PartD qN{partN, G};
     auto K2 = [&]() -> int {                                                                 // :93/:160  v = A y ; r0.v
         const Fin f = this->fin_for(0, partB, nullptr, GS);
+        if constexpr (std::is_same<T, double>::value && std::is_same<V, double>::value) {
+            if (fuse && pend_k1 >= 0) {
+                const BicgK1<double, double, false> k1{d_state, qN.p, qRho.p, qN.P, pend_k1, v, r, p, nullptr, y, 0.0, 0.0};
+                pend_k1 = -1;
+                SPRS_TRY(this->profiled([&]() -> int { return launch_chain_k2f(this->A, GS, k1, v, p, r, palt, t, r0, partB, d_status); }, true));
+                this->stats.fused_k2 += 1;
+                std::swap(p, palt); y = p;   // p' lives in the other buffer
+                std::swap(v, t);             // v' was written where t was
+                return this->red1(partB, GS, 0, &qB);
+            }
+        }
         SPRS_TRY(this->spmv(y, v, 1, r0, partB, nullptr, d_status, false, &f));
         return this->red1(partB, GS, 0, &qB);
     };
     auto K3 = [&](int check) -> int {
+        if (fuse) { pend_k3 = check; return (int)SPRS_OK; }     // formed by the next K4
         if (pc) return launch_fused<T>(c, n, G, cw, BicgK3<T, V, true>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()});
         return launch_fused<T>(c, n, G, cw, BicgK3<T, V, false>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()});
     };
     auto K4 = [&]() -> int {                                                                 // :104/:175 t = A s ; t.t, t.r
         const Fin f = this->fin_for(1, partTT, partTR, GS);
-        SPRS_TRY(this->spmv(sz, t, 2, r, partTT, partTR, d_status, false, &f));
+        if constexpr (std::is_same<T, double>::value && std::is_same<V, double>::value) {
+            if (fuse && pend_k3 >= 0) {
+                const BicgK3<double, double, false> k3{d_state, qB.p, qB.P, pend_k3, v, r, nullptr, nullptr, 0.0};
+                pend_k3 = -1;
+                SPRS_TRY(this->profiled([&]() -> int { return launch_chain_k4f(this->A, GS, k3, r, v, ralt, t, partTT, partTR, d_status); }, true));
+                this->stats.fused_k4 += 1;
+                std::swap(r, ralt);          // r now names s
+                return this->red2(partTT, partTR, GS, 1, &qTT, &qTR);
+            }
+        }
+        SPRS_TRY(this->spmv(pc ? z : r, t, 2, r, partTT, partTR, d_status, false, &f));
         return this->red2(partTT, partTR, GS, 1, &qTT, &qTR);
     };
     auto K5 = [&]() -> int {
@@ -649,6 +594,7 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
         return this->redDT(partN, partRho, G, 3, &qN, &qRho);
     };
     auto K1 = [&](int mode) -> int {
+        if (fuse) { pend_k1 = mode; return (int)SPRS_OK; }      // formed by the next K2
         if (pc) return launch_fused<T>(c, n, G, cw, BicgK1<T, V, true>{d_state, qN.p, qRho.p, qN.P, mode, v, r, p, dinv, y, T(), T()});
         return launch_fused<T>(c, n, G, cw, BicgK1<T, V, false>{d_state, qN.p, qRho.p, qN.P, mode, v, r, p, dinv, y, T(), T()});
     };

@@ -31,6 +31,7 @@ struct MinresDev {
 struct SolverStats {
     double spmv_ms = 0.0, solve_ms = 0.0;
     int64_t spmv_launches = 0;
+    int64_t fused_k2 = 0, fused_k4 = 0;   // of those (enqueued, profiled or not): chain launches that formed their input on the fly (K1 into K2 / K3 into K4)
 };
 
 template <class T>
@@ -65,6 +66,7 @@ class KrylovBase {
     int spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, const int *status, bool conj_x = false, const sprs::Fin *fin = nullptr);
     // distributed: descriptor that makes the producing launch reduce its partials into red[2*slot ..] (empty otherwise)
     sprs::Fin fin_for(int slot, const void *base0, const void *base1, int P) const;
+    template <class F> int profiled(F &&run, bool one_kernel);   // run() = one SpMV-class step, bracketed by the profile's events when a profile is taken
     void profile_discard_last(size_t launches);   // the last `launches` profiled SpMVs were no-ops (status word set): keep them out of the mean
     int begin_solve();
     int end_solve();

@@ -15,6 +15,7 @@
 // remainders of runs) are walked by the same launch afterwards (pair2_walk), so a launch writes all of y and one dot partial per
 // workgroup.
 #include "spmv_dict_dev.hpp"
+#include "bicg_fuse.hpp"
 
 namespace sprs {
 namespace {
@@ -26,7 +27,13 @@ constexpr int CH_WL = CH_ROWS + 2 * CH_W;         // 3072 doubles per window, th
 // UX: the dot operand is the input vector itself (taken from the window).  TRI: the near slots are (.., c - 1, c, c + 1, ..)
 // around an even centre offset and all other near offsets are even (every stencil with sorted columns on a grid of even line
 // length): 16-byte LDS reads, the centre's pair serves the +-1 columns' inner halves.
-template <int DOT, bool UX, int UL, bool TRI>
+// FUSE (krylov.hip, "fused SpMV input"): 0 = x is a vector in memory.  2 = x is BiCGStab's s = r + v * (-alpha) (K3 into K4:
+// x = r, in1 = v), 3 = its p' = (v * (-beta w) + p * beta) + r (K1 into K2: x = v, in1 = p, in2 = r): `pro` is that update's kernel
+// structure — its prologue (the scalars of the recurrence and its convergence / restart / breakdown decisions, taken identically by
+// every workgroup from the same partials) runs at the top of this launch, the update itself while a window is staged, with the
+// update's own rounding sequence; the updated vector is written for the launch's own rows to `own` and never read back.
+struct NoPro { __device__ __forceinline__ bool prologue() { return true; } };
+template <int FUSE, class PRO, int DOT, bool UX, int UL, bool TRI>
 __global__ __launch_bounds__(BLOCK) void spmv_chain_kernel(const int4 *__restrict__ tiles, const int2 *__restrict__ segs, const int32_t *__restrict__ xstart,
                                                            const BlkDesc *__restrict__ desc, const TilePat pat,
                                                            int n_left, const int32_t *__restrict__ left_order,
@@ -34,8 +41,12 @@ __global__ __launch_bounds__(BLOCK) void spmv_chain_kernel(const int4 *__restric
                                                            const int32_t *__restrict__ off_tab, const double *__restrict__ val_tab,
                                                            const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ u,
                                                            double *__restrict__ part0, double *__restrict__ part1,
-                                                           const int *__restrict__ status, int nrows, int ncols, const Fin fin) {
+                                                           const int *__restrict__ status, int nrows, int ncols, const Fin fin,
+                                                           PRO pro, const double *__restrict__ in1, const double *__restrict__ in2,
+                                                           double *__restrict__ own) {
     using T = double;
+    constexpr int NV = FUSE == 0 ? 1 : FUSE;            // input vectors
+    static_assert(FUSE == 0 || (FUSE == 2 && DOT == 2 && UX) || (FUSE == 3 && DOT == 1 && !UX), "fused flavours: K3 into K4, K1 into K2");
     constexpr int W = CH_W, WL = CH_WL;
     constexpr int NW = WL / 2 / BLOCK;                  // 16-byte window pieces per lane (6)
     constexpr int NQ = CH_B / NWAVE;                    // 128-row blocks per wavefront and tile (4)
@@ -52,6 +63,11 @@ __global__ __launch_bounds__(BLOCK) void spmv_chain_kernel(const int4 *__restric
     s_pair[tid] = PairEnt<T>{off_tab[tid] * 8, val_tab[tid]};                  // BLOCK == TAB (the seam rows' own values; the walk below)
     __syncthreads();
     if (run_state != ST_RUNNING) { fin_idle(fin, DOT == 2); return; }
+    [[maybe_unused]] T c0 = 0.0, c1 = 0.0;              // coefficients of the fused update
+    if constexpr (FUSE != 0) {
+        if (!pro.prologue()) return;                    // converged / restart requested / breakdown: the same decision in every workgroup
+        if constexpr (FUSE == 2) c0 = pro.na; else { c0 = pro.a; c1 = pro.beta; }
+    }
     T d0 = 0.0, d1 = 0.0;
 
     const int Pf = pat.off[UL - 1];                     // == -pat.off[0]
@@ -60,6 +76,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_chain_kernel(const int4 *__restric
     const int sstep = gridDim.x >> 3;
     const int send = xstart[xcd + 1];
     u4v wreg[NW];
+    [[maybe_unused]] u4v wreg1[NV >= 2 ? NW : 1], wreg2[NV == 3 ? NW : 1];
     // raw window of the tile that starts at row tw: [tw - W, tw + CH_ROWS + W).  The margins of a window at either end of x are
     // clamped piece by piece — what they hold is never folded (every column a tile's rows have is inside x)
     auto issue = [&](int tw) {
@@ -67,12 +84,25 @@ __global__ __launch_bounds__(BLOCK) void spmv_chain_kernel(const int4 *__restric
         for (int i = 0; i < NW; ++i) {
             int g = tw - W + 2 * (tid + i * BLOCK);
             g = g < 0 ? 0 : (g > xhi ? xhi : g);
-            wreg[i] = *reinterpret_cast<const u4v *>(x + g);
+            wreg[i] = *reinterpret_cast<const u4v *>(x + g);             // (non-temporal window loads, allocating result stores: no difference, profiles/r04_tuning.md §3)
+            if constexpr (NV >= 2) wreg1[i] = *reinterpret_cast<const u4v *>(in1 + g);
+            if constexpr (NV == 3) wreg2[i] = *reinterpret_cast<const u4v *>(in2 + g);
         }
     };
     auto stage = [&](int slot) {
 #pragma unroll
-        for (int i = 0; i < NW; ++i) *reinterpret_cast<u4v *>(&win[slot][2 * (tid + i * BLOCK)]) = wreg[i];
+        for (int i = 0; i < NW; ++i) {
+            if constexpr (FUSE == 0) {
+                *reinterpret_cast<u4v *>(&win[slot][2 * (tid + i * BLOCK)]) = wreg[i];
+            } else {
+                D2 a, b, cc{0.0, 0.0};
+                __builtin_memcpy(&a, &wreg[i], 16); __builtin_memcpy(&b, &wreg1[i], 16);
+                if constexpr (NV == 3) __builtin_memcpy(&cc, &wreg2[i], 16);
+                const D2 o = FUSE == 2 ? D2{comb_k3(a.lo, b.lo, c0), comb_k3(a.hi, b.hi, c0)}
+                                       : D2{comb_k1(a.lo, b.lo, cc.lo, c0, c1), comb_k1(a.hi, b.hi, cc.hi, c0, c1)};
+                *reinterpret_cast<D2 *>(&win[slot][2 * (tid + i * BLOCK)]) = o;
+            }
+        }
     };
     for (int s = xstart[xcd] + (blockIdx.x >> 3); s < send; s += sstep) {
         const int2 sg = segs[s];
@@ -134,7 +164,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_chain_kernel(const int4 *__restric
 #pragma unroll
                     for (int t = 0; t < NN; ++t) { opl[1 + t] = wc[l + pat.off[1 + t]]; oph[1 + t] = wc[l + pat.off[1 + t] + 1]; }
                 }
-                if (DOT != 0 && UX) { const D2 c2 = *reinterpret_cast<const D2 *>(wc + l); ux0 = c2.lo; ux1 = c2.hi; }
+                if ((DOT != 0 && UX) || FUSE != 0) { const D2 c2 = *reinterpret_cast<const D2 *>(wc + l); ux0 = c2.lo; ux1 = c2.hi; }
             };
             read_ops(0);
 #pragma unroll
@@ -145,6 +175,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_chain_kernel(const int4 *__restric
 #pragma unroll
                 for (int t = 0; t < UL; ++t) { pl[t] = opl[t]; ph[t] = oph[t]; }
                 const T u0 = (DOT != 0 && !UX) ? uu[q].lo : ux0, u1 = (DOT != 0 && !UX) ? uu[q].hi : ux1;
+                [[maybe_unused]] const D2 mine{ux0, ux1};              // FUSE: the formed vector at the lane's own two rows
                 if (q + 1 < NQ) read_ops(q + 1);
                 T acc0 = 0.0, acc1 = 0.0;
                 if (!seam) {
@@ -188,6 +219,11 @@ __global__ __launch_bounds__(BLOCK) void spmv_chain_kernel(const int4 *__restric
                 u4v qv;
                 __builtin_memcpy(&qv, &yy, 16);
                 __builtin_nontemporal_store(qv, reinterpret_cast<u4v *>(y + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
+                if constexpr (FUSE != 0) {
+                    u4v ov;
+                    __builtin_memcpy(&ov, &mine, 16);
+                    __builtin_nontemporal_store(ov, reinterpret_cast<u4v *>(own + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
+                }
                 if (DOT == 1) { d0 = d0 + u0 * acc0; d0 = d0 + u1 * acc1; }
                 if (DOT == 2) { d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * u0; d0 = d0 + acc1 * acc1; d1 = d1 + acc1 * u1; }
             }
@@ -200,7 +236,12 @@ __global__ __launch_bounds__(BLOCK) void spmv_chain_kernel(const int4 *__restric
         __syncthreads();
         uint32_t (*s_c)[CW2] = reinterpret_cast<uint32_t (*)[CW2]>(&win[0][0]);
         for (int i = lane; i < CW2; i += WAVE) s_c[wv][i] = 0;                 // (wavefront-private slices: no barrier)
-        pair2_walk<DOT, true>(n_left, 0, desc, left_order, row_ptr, code, x, y, u, nrows, ncols, s_pair, s_c, d0, d1);
+        if constexpr (FUSE == 0)
+            pair2_walk<DOT, true>(n_left, 0, desc, left_order, row_ptr, code, XPlain{reinterpret_cast<const char *>(x)}, y, u, nrows, ncols, s_pair, s_c, d0, d1);
+        else
+            pair2_walk<DOT, true, XFused<NV>>(n_left, 0, desc, left_order, row_ptr, code,
+                                              XFused<NV>{reinterpret_cast<const char *>(x), reinterpret_cast<const char *>(in1), reinterpret_cast<const char *>(in2), c0, c1},
+                                              y, UX ? nullptr : u, nrows, ncols, s_pair, s_c, d0, d1, own);
     }
     if (DOT >= 1) {
         d0 = block_sum(d0, red);
@@ -226,9 +267,9 @@ int launch_chain_pair(const sprs_csr *A, const sprs_chain_plan &CP, int g, const
     TilePat tp;
     for (int t = 0; t < 8; ++t) { tp.off[t] = CP.off[t]; tp.val[t] = CP.val[t]; }
     const bool ux = dot_mode != 0 && u == x;
-#define SPRS_CSPMV(DM, UXV, U, TR) SPRS_LAUNCH_SPMV(c, (spmv_chain_kernel<DM, UXV, U, TR>), g, reinterpret_cast<const int4 *>(CP.tiles), reinterpret_cast<const int2 *>(CP.segs), \
+#define SPRS_CSPMV(DM, UXV, U, TR) SPRS_LAUNCH_SPMV(c, (spmv_chain_kernel<0, NoPro, DM, UXV, U, TR>), g, reinterpret_cast<const int4 *>(CP.tiles), reinterpret_cast<const int2 *>(CP.segs), \
                                                     CP.xstart, wd, tp, CP.n_left, CP.left, A->row_ptr, D->pair_code, D->pair_off, pvd, x, y, u, part0, part1, status,   \
-                                                    (int)A->nrows, (int)A->ncols, fin)
+                                                    (int)A->nrows, (int)A->ncols, fin, NoPro{}, nullptr, nullptr, nullptr)
 #define SPRS_CSHAPE(U, TR)                                                                                           \
     if (CP.ul == U && (CP.tri != 0) == TR) {                                                                         \
         if (dot_mode == 0) SPRS_CSPMV(0, false, U, TR);                                                              \
@@ -238,6 +279,49 @@ int launch_chain_pair(const sprs_csr *A, const sprs_chain_plan &CP, int g, const
     SPRS_CHAIN_SHAPES(SPRS_CSHAPE)
 #undef SPRS_CSHAPE
 #undef SPRS_CSPMV
+    SPRS_HIP_TRY(c, hipGetLastError());
+    return SPRS_OK;
+}
+
+
+int launch_chain_k4f(const sprs_csr *A, int g, const BicgK3<double, double, false> &pro, const double *r, const double *v, double *s_out,
+                     double *t, double *partTT, double *partTR, const int *status) {
+    sprs_ctx *c = A->ctx;
+    const sprs_dict *D = A->dict;
+    const sprs_chain_plan &CP = D->chain_pair;
+    const BlkDesc *wd = reinterpret_cast<const BlkDesc *>(D->wide_desc);
+    const double *pvd = reinterpret_cast<const double *>(D->pair_val);
+    TilePat tp;
+    for (int k = 0; k < 8; ++k) { tp.off[k] = CP.off[k]; tp.val[k] = CP.val[k]; }
+    typedef BicgK3<double, double, false> K3;
+#define SPRS_C4F(U, TR)                                                                                                 \
+    if (CP.ul == U && (CP.tri != 0) == TR)                                                                              \
+        SPRS_LAUNCH_SPMV(c, (spmv_chain_kernel<2, K3, 2, true, U, TR>), g, reinterpret_cast<const int4 *>(CP.tiles), reinterpret_cast<const int2 *>(CP.segs), \
+                         CP.xstart, wd, tp, CP.n_left, CP.left, A->row_ptr, D->pair_code, D->pair_off, pvd, r, t, (const double *)nullptr, partTT, partTR, status, \
+                         (int)A->nrows, (int)A->ncols, Fin{}, pro, v, (const double *)nullptr, s_out);
+    SPRS_CHAIN_SHAPES(SPRS_C4F)
+#undef SPRS_C4F
+    SPRS_HIP_TRY(c, hipGetLastError());
+    return SPRS_OK;
+}
+
+int launch_chain_k2f(const sprs_csr *A, int g, const BicgK1<double, double, false> &pro, const double *v_old, const double *p, const double *r,
+                     double *p_out, double *v_out, const double *r0, double *partB, const int *status) {
+    sprs_ctx *c = A->ctx;
+    const sprs_dict *D = A->dict;
+    const sprs_chain_plan &CP = D->chain_pair;
+    const BlkDesc *wd = reinterpret_cast<const BlkDesc *>(D->wide_desc);
+    const double *pvd = reinterpret_cast<const double *>(D->pair_val);
+    TilePat tp;
+    for (int k = 0; k < 8; ++k) { tp.off[k] = CP.off[k]; tp.val[k] = CP.val[k]; }
+    typedef BicgK1<double, double, false> K1;
+#define SPRS_C2F(U, TR)                                                                                                 \
+    if (CP.ul == U && (CP.tri != 0) == TR)                                                                              \
+        SPRS_LAUNCH_SPMV(c, (spmv_chain_kernel<3, K1, 1, false, U, TR>), g, reinterpret_cast<const int4 *>(CP.tiles), reinterpret_cast<const int2 *>(CP.segs), \
+                         CP.xstart, wd, tp, CP.n_left, CP.left, A->row_ptr, D->pair_code, D->pair_off, pvd, v_old, v_out, r0, partB, (double *)nullptr, status, \
+                         (int)A->nrows, (int)A->ncols, Fin{}, pro, p, r, p_out);
+    SPRS_CHAIN_SHAPES(SPRS_C2F)
+#undef SPRS_C2F
     SPRS_HIP_TRY(c, hipGetLastError());
     return SPRS_OK;
 }

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
     if (run_state != ST_RUNNING) { fin_idle(fin, DOT == 2); return; }
 
     T d0 = 0.0, d1 = 0.0;
-    pair2_walk<DOT, YNT>(n_wide, xcd_chunk, desc, order, row_ptr, code, x, y, u, nrows, ncols, s_pair, s_c, d0, d1);
+    pair2_walk<DOT, YNT>(n_wide, xcd_chunk, desc, order, row_ptr, code, XPlain{reinterpret_cast<const char *>(x)}, y, u, nrows, ncols, s_pair, s_c, d0, d1);
     if (DOT >= 1) {
         d0 = block_sum(d0, red);
         if (tid == 0) st_partial(fin, part0 + blockIdx.x, d0);

@@ -262,6 +262,45 @@ constexpr int CW2 = (CAP2 + 3 + CPAD + 15) / 16 * 4;      // dwords of a wavefro
 constexpr int UNI_OFF_MAXLEN = 32;          // offset-code stream: the pattern is read from the staged first row, chunk by chunk
 constexpr int UNI2_MAXLEN = 8;              // ... of at most this many codes; the descriptor's nn then holds that length
 
+// Where the two-rows-per-lane kernels take x from.  XPlain: a vector in memory.  XFused<NV>: x is the RESULT of the vector update
+// that precedes the SpMV in BiCGStab's recurrence, formed on the fly from that update's operands with the update's own rounding
+// sequence (krylov.hip, "fused SpMV input": K3 into K4, s = r + v * (-alpha), bicg_stab.rs:172; K1 into K2,
+// p = (v * (-beta w) + p * beta) + r * 1, bicg_stab.rs:155-156) — the updated vector is never read back from memory.
+// ld2(soff, voff): the pair at byte offset soff (wave-uniform) + voff (per lane); ld1: one element; lds: one element at a
+// wave-uniform offset (a scalar load where the compiler can prove it).
+__device__ __forceinline__ double comb_k3(double r, double v, double na) { return r + v * na; }
+__device__ __forceinline__ double comb_k1(double v, double p, double r, double a, double beta) { double t = v * a + p * beta; t = t + r * 1.0; return t; }
+struct XPlain {
+    static constexpr bool FUSED = false;
+    const char *xb;
+    __device__ __forceinline__ D2 ld2(int64_t soff, uint32_t voff) const { return *reinterpret_cast<const D2 *>(xb + soff + voff); }
+    __device__ __forceinline__ double ld1(uint32_t voff) const { return *reinterpret_cast<const double *>(xb + voff); }
+    __device__ __forceinline__ double lds(int64_t soff) const { return *reinterpret_cast<const double *>(xb + soff); }
+};
+template <int NV>
+struct XFused {
+    static constexpr bool FUSED = true;
+    const char *b0, *b1, *b2;      // NV = 2: r, v;  NV = 3: v, p, r
+    double c0, c1;                 // NV = 2: -alpha;  NV = 3: -beta w, beta
+    __device__ __forceinline__ double one(double a, double b, double c) const { return NV == 2 ? comb_k3(a, b, c0) : comb_k1(a, b, c, c0, c1); }
+    __device__ __forceinline__ D2 ld2(int64_t soff, uint32_t voff) const {
+        const D2 a = *reinterpret_cast<const D2 *>(b0 + soff + voff), b = *reinterpret_cast<const D2 *>(b1 + soff + voff);
+        D2 c{0.0, 0.0};
+        if (NV == 3) c = *reinterpret_cast<const D2 *>(b2 + soff + voff);
+        return D2{one(a.lo, b.lo, c.lo), one(a.hi, b.hi, c.hi)};
+    }
+    __device__ __forceinline__ double ld1(uint32_t voff) const {
+        const double a = *reinterpret_cast<const double *>(b0 + voff), b = *reinterpret_cast<const double *>(b1 + voff);
+        const double c = NV == 3 ? *reinterpret_cast<const double *>(b2 + voff) : 0.0;
+        return one(a, b, c);
+    }
+    __device__ __forceinline__ double lds(int64_t soff) const {
+        const double a = *reinterpret_cast<const double *>(b0 + soff), b = *reinterpret_cast<const double *>(b1 + soff);
+        const double c = NV == 3 ? *reinterpret_cast<const double *>(b2 + soff) : 0.0;
+        return one(a, b, c);
+    }
+};
+
 // FULL uniform block of the two-rows-per-lane kernels (every lane has both rows — the interior of a stencil): no row
 // masks, and no clamp either: the second row's column r0 + 1 + off is valid, so the 16-byte load at r0 + off stays
 // inside x.  Offset and value of a slot are wave-uniform: made scalars, the gather is SGPR base + lane offset and the
@@ -285,8 +324,8 @@ __device__ __forceinline__ double wave_shift_down(double next_for_last_lane, dou
     const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(q >> 32), 0x130, 0xf, 0xf, false);
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
-template <int UL, int SC, class AfterLoads>
-__device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair, uint64_t pat, int ulen, bool seam, int seam1, int seam2, const char *xbytes,
+template <int UL, int SC, class XS, class AfterLoads>
+__device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair, uint64_t pat, int ulen, bool seam, int seam1, int seam2, const XS &xs,
                                                    uint32_t r8, uint32_t ra8, int lane, AfterLoads &&after_loads,
                                                    double &acc0, double &acc1) {
     using T = double;
@@ -303,7 +342,7 @@ __device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair
         const uint32_t vhi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(__double_as_longlong(e.val) >> 32));
         av[t] = __longlong_as_double((long long)(((uint64_t)vhi << 32) | vlo));
         if (SC > 0 && (t == SC - 1 || t == SC + 1)) continue;
-        const D2 px = *reinterpret_cast<const D2 *>(xbytes + (int64_t)off8 + r8);
+        const D2 px = xs.ld2((int64_t)off8, r8);
         pl[t] = px.lo; ph[t] = px.hi;
         if (SC > 0 && t == SC) off8c = off8;
     }
@@ -312,8 +351,8 @@ __device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair
     // 64-lane load of them would cost the vector-memory pipe as much as a gather
     T e_lo = 0.0, e_hi = 0.0;
     if (SC > 0) {
-        const T *xe = reinterpret_cast<const T *>(xbytes + (int64_t)off8c + ra8);
-        e_lo = xe[-1]; e_hi = xe[2 * WAVE];
+        const int64_t xe = (int64_t)off8c + ra8;
+        e_lo = xs.lds(xe - 8); e_hi = xs.lds(xe + 2 * WAVE * 8);
     }
     after_loads();
     __builtin_amdgcn_sched_barrier(0);
@@ -349,15 +388,15 @@ __device__ __forceinline__ void full_uniform_block(const PairEnt<double> *s_pair
         }
     }
 }
-template <class AfterLoads>
-__device__ __forceinline__ void full_uniform_dispatch(const PairEnt<double> *s_pair, uint64_t pat, int ulen, int sc, bool seam, int seam1, int seam2, const char *xbytes,
+template <class XS, class AfterLoads>
+__device__ __forceinline__ void full_uniform_dispatch(const PairEnt<double> *s_pair, uint64_t pat, int ulen, int sc, bool seam, int seam1, int seam2, const XS &xs,
                                                       uint32_t r8, uint32_t ra8, int lane, AfterLoads &&after_loads,
                                                       double &acc0, double &acc1) {
     // (scalar branches) the stencils: 7-point 3-D, 5-point 2-D, 3-point 1-D with sorted columns; anything else generic
-    if (ulen == 7 && sc == 3) full_uniform_block<7, 3>(s_pair, pat, ulen, seam, seam1, seam2, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
-    else if (ulen == 5 && sc == 2) full_uniform_block<5, 2>(s_pair, pat, ulen, seam, seam1, seam2, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
-    else if (ulen == 3 && sc == 1) full_uniform_block<3, 1>(s_pair, pat, ulen, seam, seam1, seam2, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
-    else full_uniform_block<0, 0>(s_pair, pat, ulen, seam, seam1, seam2, xbytes, r8, ra8, lane, after_loads, acc0, acc1);
+    if (ulen == 7 && sc == 3) full_uniform_block<7, 3>(s_pair, pat, ulen, seam, seam1, seam2, xs, r8, ra8, lane, after_loads, acc0, acc1);
+    else if (ulen == 5 && sc == 2) full_uniform_block<5, 2>(s_pair, pat, ulen, seam, seam1, seam2, xs, r8, ra8, lane, after_loads, acc0, acc1);
+    else if (ulen == 3 && sc == 1) full_uniform_block<3, 1>(s_pair, pat, ulen, seam, seam1, seam2, xs, r8, ra8, lane, after_loads, acc0, acc1);
+    else full_uniform_block<0, 0>(s_pair, pat, ulen, seam, seam1, seam2, xs, r8, ra8, lane, after_loads, acc0, acc1);
 }
 
 
@@ -368,6 +407,7 @@ struct Blk2Loads {
     bool is_seam; int seam1, seam2;   // ... or uniform but for one or two rows (mark_uniform_kernel's encoding: nn >> 16, rb's low bits)
     int a, b;                // row_ptr[i0], row_ptr[i0 + 1], i0 = min(ra + 2 lane, rb - 1)
     double u0, u1;           // dot operands of the lane's two rows
+    double o0, o1;           // XFused: the formed vector at the lane's two rows (stored by the walk)
     u4v wc;                  // 16 code bytes
     int di;                  // ... and the b128 slot they go to
 };
@@ -378,18 +418,21 @@ struct Blk2Loads {
 // lane's running dot partials (DOT as in launch_spmv).  s_pair: the staged (byte offset, value) table; s_c: NWAVE
 // zero-initialised code slices.
 // YNT: y is written with non-temporal stores (HBM-sized vectors: the result is not read again before it has been evicted)
-template <int DOT, bool YNT>
+// XS: where x comes from (XPlain: memory; XFused: formed on the fly).  With XFused the walk also STORES the formed vector for the
+// rows it owns (`own`), and where `u` is null the dot operand is that vector (K4's t.s).
+template <int DOT, bool YNT, class XS = XPlain>
 __device__ __forceinline__ void pair2_walk(int n_wide, int xcd_chunk, const BlkDesc *__restrict__ desc,
                                            const int32_t *__restrict__ order, const int32_t *__restrict__ row_ptr,
-                                           const uint8_t *__restrict__ code, const double *__restrict__ x,
+                                           const uint8_t *__restrict__ code, const XS xs,
                                            double *__restrict__ y, const double *__restrict__ u, int nrows, int ncols,
-                                           const PairEnt<double> *s_pair, uint32_t (*s_c)[CW2], double &d0, double &d1) {
+                                           const PairEnt<double> *s_pair, uint32_t (*s_c)[CW2], double &d0, double &d1,
+                                           double *__restrict__ own = nullptr) {
     using T = double;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint8_t *cb = reinterpret_cast<const uint8_t *>(s_c[wv]);
-    const char *xbytes = reinterpret_cast<const char *>(x);
     const uint32_t xlast_pair = (uint32_t)(ncols - 2) * 8u;                    // last byte offset a 16-byte x load may start at
+    const bool u_is_x = XS::FUSED && u == nullptr;                             // the dot operand is the vector formed on the fly
 
     int b, bstep, bend;
     if (xcd_chunk) {
@@ -431,11 +474,18 @@ __device__ __forceinline__ void pair2_walk(int n_wide, int xcd_chunk, const BlkD
             const int2 ab = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(row_ptr) + (uint32_t)i0 * 4u);
             L.a = ab.x; L.b = ab.y;
         }
-        if (DOT != 0) {
+        if (DOT != 0 && !u_is_x) {
             const int p0 = min(r0, nrows - 2);                                  // the pair (u[p0], u[p0 + 1]) is inside u
             const D2 uu = *reinterpret_cast<const D2 *>(reinterpret_cast<const char *>(u) + (uint32_t)p0 * 8u);
             L.u0 = r0 == p0 ? uu.lo : uu.hi;                                    // r0 == nrows - 1: its operand is the pair's second half
             L.u1 = uu.hi;
+        }
+        if constexpr (XS::FUSED) {                                              // the formed vector at the lane's own rows
+            const int p0 = min(r0, nrows - 2);
+            const D2 oo = xs.ld2(0, (uint32_t)p0 * 8u);
+            L.o0 = r0 == p0 ? oo.lo : oo.hi;
+            L.o1 = oo.hi;
+            if (DOT != 0 && u_is_x) { L.u0 = L.o0; L.u1 = L.o1; }
         }
         const int shift = L.pa & 3;
         const int nq = L.uni ? 1 : max((shift + L.nn + 15) >> 4, 1);            // 16-byte pieces covering the codes, <= 65 (uniform: the first row's only)
@@ -449,9 +499,11 @@ __device__ __forceinline__ void pair2_walk(int n_wide, int xcd_chunk, const BlkD
     bool c_seam = false;     // ... or uniform but for one or two rows:
     int c_seam1 = 0, c_seam2 = 0;
     T c_u0 = 0.0, c_u1 = 0.0;
+    [[maybe_unused]] T c_o0 = 0.0, c_o1 = 0.0;
     auto stage = [&](const Blk2Loads &L) {
         const int shift = L.pa & 3;
         c_uni = L.uni;
+        if constexpr (XS::FUSED) { c_o0 = L.o0; c_o1 = L.o1; }
         if (L.uni) {
             // every lane holds the same 16 bytes [pa - shift, pa - shift + 16): the pattern starts `shift` bytes in
             const uint64_t lo = (uint64_t)__builtin_amdgcn_readfirstlane(L.wc.x) | ((uint64_t)__builtin_amdgcn_readfirstlane(L.wc.y) << 32);
@@ -516,7 +568,7 @@ __device__ __forceinline__ void pair2_walk(int n_wide, int xcd_chunk, const BlkD
 #pragma unroll
             for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; av[t] = 0.0; }
             if (c_rb - c_ra == 2 * WAVE) {
-                full_uniform_dispatch(s_pair, c_pat, ulen, c_tri, c_seam, c_seam1, c_seam2, xbytes, r8, (uint32_t)c_ra * 8u, lane, after_gathers, acc0, acc1);
+                full_uniform_dispatch(s_pair, c_pat, ulen, c_tri, c_seam, c_seam1, c_seam2, xs, r8, (uint32_t)c_ra * 8u, lane, after_gathers, acc0, acc1);
             } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -526,7 +578,7 @@ __device__ __forceinline__ void pair2_walk(int n_wide, int xcd_chunk, const BlkD
                 const uint32_t vo0 = len0 > 0 ? r8 + (uint32_t)e.off8 : 0u;
                 const uint32_t vp = min(vo0, xlast_pair);                       // only a single-row lane at the matrix end is ever clamped
                 hi_bits |= (vo0 != vp ? 1u : 0u) << t;
-                const D2 px = *reinterpret_cast<const D2 *>(xbytes + vp);
+                const D2 px = xs.ld2(0, vp);
                 pl[t] = px.lo; ph[t] = px.hi;
             }
             after_gathers();
@@ -544,10 +596,10 @@ __device__ __forceinline__ void pair2_walk(int n_wide, int xcd_chunk, const BlkD
             const uint8_t *cp0 = cb + c_shift + min(c_s0 + j0, CAP2);
             const uint8_t *cp1 = cb + c_shift + min(c_s1 + j0, CAP2);
             T pl[8], ph[8];           // the 16-byte gather of the slot: x[col0], x[col0 + 1]
-            T xs[8];                  // row 1's own gather where its column is not row 0's + 1
+            T xg1[8];                 // row 1's own gather where its column is not row 0's + 1
             uint32_t same_bits = 0, hi_bits = 0;      // per slot: row 1 shares the gather / row 0's x is the pair's second half
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; xs[t] = 0.0; }
+            for (int t = 0; t < 8; ++t) { pl[t] = 0.0; ph[t] = 0.0; xg1[t] = 0.0; }
             const uint64_t m4 = __builtin_amdgcn_ballot_w64(j0 + 4 < lenm), m5 = __builtin_amdgcn_ballot_w64(j0 + 5 < lenm),
                            m6 = __builtin_amdgcn_ballot_w64(j0 + 6 < lenm), m7 = __builtin_amdgcn_ballot_w64(j0 + 7 < lenm);
 #pragma unroll
@@ -563,11 +615,11 @@ __device__ __forceinline__ void pair2_walk(int n_wide, int xcd_chunk, const BlkD
                 const uint32_t vp = min(vo0, xlast_pair);                       // a 16-byte load must start at or before x[ncols - 2]
                 same_bits |= (same ? 1u : 0u) << t;
                 hi_bits |= (vo0 != vp ? 1u : 0u) << t;                          // col0 == ncols - 1: it is the pair's second half
-                const D2 px = *reinterpret_cast<const D2 *>(xbytes + vp);
+                const D2 px = xs.ld2(0, vp);
                 pl[t] = px.lo; ph[t] = px.hi;
                 const bool need1 = v1 && !same;
                 if (__builtin_amdgcn_ballot_w64(need1) != 0)                    // scalar branch: interior stencil blocks skip it
-                    xs[t] = *reinterpret_cast<const T *>(xbytes + (need1 ? r8 + 8u + (uint32_t)off1 : 0u));
+                    xg1[t] = xs.ld1(need1 ? r8 + 8u + (uint32_t)off1 : 0u);
             }
             if (j0 == 0) after_gathers();
             __builtin_amdgcn_sched_barrier(0);                                  // every gather out before the first product
@@ -575,7 +627,7 @@ __device__ __forceinline__ void pair2_walk(int n_wide, int xcd_chunk, const BlkD
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 if (j0 + t < len0) acc0 = acc0 + (((hi_bits >> t) & 1u) ? ph[t] : pl[t]) * s_pair[cp0[t]].val;
-                if (j0 + t < len1) acc1 = acc1 + (((same_bits >> t) & 1u) ? ph[t] : xs[t]) * s_pair[cp1[t]].val;
+                if (j0 + t < len1) acc1 = acc1 + (((same_bits >> t) & 1u) ? ph[t] : xg1[t]) * s_pair[cp1[t]].val;
             }
         }
         }
@@ -590,7 +642,9 @@ __device__ __forceinline__ void pair2_walk(int n_wide, int xcd_chunk, const BlkD
             }
             if (DOT == 1) { d0 = d0 + c_u0 * acc0; d0 = d0 + c_u1 * acc1; }
             if (DOT == 2) { d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * c_u0; d0 = d0 + acc1 * acc1; d1 = d1 + acc1 * c_u1; }
+            if constexpr (XS::FUSED) *reinterpret_cast<D2 *>(reinterpret_cast<char *>(own) + r8) = D2{c_o0, c_o1};
         } else if (r0 < c_rb) {
+            if constexpr (XS::FUSED) *reinterpret_cast<T *>(reinterpret_cast<char *>(own) + r8) = c_o0;
             *reinterpret_cast<T *>(reinterpret_cast<char *>(y) + r8) = acc0;
             if (DOT == 1) d0 = d0 + c_u0 * acc0;
             if (DOT == 2) { d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * c_u0; }

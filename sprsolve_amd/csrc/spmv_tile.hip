@@ -158,7 +158,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(const int2 *__restrict
     }
     if (n_left > 0) {
         __syncthreads();
-        pair2_walk<DOT, true>(n_left, 0, desc, left_order, row_ptr, code, x, y, u, nrows, ncols, s_pair, s_c, d0, d1);
+        pair2_walk<DOT, true>(n_left, 0, desc, left_order, row_ptr, code, XPlain{reinterpret_cast<const char *>(x)}, y, u, nrows, ncols, s_pair, s_c, d0, d1);
     }
     if (DOT >= 1) {
         d0 = block_sum(d0, red);

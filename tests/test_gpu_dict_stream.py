@@ -783,6 +783,51 @@ def test_plane_streaming_chains_bit_identical(sa, oracle, name):
         ctx.set("spmv_chain", -1); ctx.set("spmv_tile", -1)
 
 
+@pytest.mark.parametrize("name", [k for k in _chain_cases() if k.startswith("p3_")])
+def test_fused_spmv_input_is_bit_identical(sa, oracle, name):
+    """Knob spmv_fuse (csrc/krylov.hip "fused SpMV input", csrc/spmv_chain.hip FUSE): on a handle whose SpMV runs through chains
+    BiCGStab forms K3's r -= alpha v inside K4 and K1's p = (v (-beta w) + p beta) + r inside K2 (bicg_stab.rs:155-156,172) — the
+    same prologues, the same rounding sequence per element, the same dot partials.  So the three-launch iteration must reproduce
+    the five-launch one BIT FOR BIT: iteration count, residual, every traced scalar, x — to convergence and for a fixed number
+    of iterations (tol = 0), with a non-zero initial guess, and through the breakdown / early-convergence exits."""
+    ctx = sa.default_ctx(0)
+    indptr, cols, data, rhs, exact = _chain_cases()[name]()
+    n = indptr.size - 1
+    rng = np.random.default_rng(5)
+    rhs2 = rng.uniform(-1, 1, n)
+    x0 = rng.uniform(-1, 1, n)
+    out = {}
+    try:
+        ctx.set("spmv_chain", 1); ctx.set("spmv_tile", 1)
+        A = sa.HipCsr.new((n, n), indptr, cols, data)
+        assert A.chain_plan()[0] >= 64
+        for fuse in (1, 0):
+            ctx.set("spmv_fuse", fuse)
+            res = []
+            for b, start, max_iter, tol in ((rhs, None, 3000, 1e-10), (rhs2, x0, 3000, 1e-9), (rhs2, None, 37, 0.0), (rhs, None, 1, 0.0),
+                                            (rhs2, None, 2, 0.0), (rhs, None, 3000, 0.5)):
+                s = sa.BiCGStab.new(A, n); s.set_trace(64); s.set_profile(True)
+                x = np.zeros(n) if start is None else start.copy()
+                try:
+                    its, rr = s.solve(b, x, max_iter, tol)
+                    st = "ok"
+                except sa.error.InsufficientIterNum as e:
+                    its, rr, st = e.iters, None, "insufficient"
+                prof = s.profile()
+                res.append((st, its, rr, bits(x).copy(), bits(s.trace()).copy(), prof["fused_k2"], prof["fused_k4"], prof["spmv_launches"]))
+            out[fuse] = res
+        for a, b in zip(out[1], out[0]):
+            assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], (a[:3], b[:3])
+            assert np.array_equal(a[3], b[3]), "x differs between the fused and the five-launch iteration"
+            assert np.array_equal(a[4], b[4]), "a traced scalar differs"
+            assert b[5] == 0 and b[6] == 0
+            assert a[6] >= 1 and (a[5] >= 1 or a[1] <= 1), a[5:]          # K4 is fused from the first iteration on, K2 from the second
+            assert a[7] == b[7]                                             # the same number of SpMV launches either way
+        assert out[1][0][0] == "ok" and np.max(np.abs(out[1][0][3].view(np.float64) - exact)) < 1e-6
+    finally:
+        ctx.set("spmv_chain", -1); ctx.set("spmv_tile", -1); ctx.set("spmv_fuse", -1)
+
+
 def test_plane_streaming_chains_policy(sa, oracle):
     """Automatic policy: chains only where they fill the chip (about one segment of >= 6 tiles per workgroup) — a 6 M-row
     500 x 200 x 60 grid (46 MiB vectors: tiles wanted, 48 chains cut into 7 segments each) qualifies; small grids keep the tile
