@@ -95,6 +95,10 @@ int sprs_version(void);
  *   "spmv_fuse"     BiCGStab, f64, no preconditioner, one GPU, SpMV through chains: the vector updates that produce an SpMV's
  *                   input (r -= alpha v before t = A r; p = (v (-beta w) + p beta) + r before v = A p) are formed inside that
  *                   SpMV — three launches per iteration instead of five, every scalar and element bit-identical; 0 = off (per solve)
+ *   "p2p_allreduce" distributed solves: the scalar hand-offs go through peer-to-peer mailboxes (no stream operation) instead of
+ *                   ncclAllReduce: -1 / 1 wherever the communicator has them (sprs_comm_p2p), 0 = RCCL
+ *                   (communicator creation: 0 sets none up; per solve)
+ *   "p2p_timeout_ms" how long a consumer kernel polls its mailbox before the solve fails with SPRS_ERR_RCCL (default 20000)
  *   "spmv_eqrows"   plain CSR: blocks of equal-length rows do not read row_ptr                           (creation)
  *   "spmv_wideload" plain CSR, f64: 16-byte stream loads (4 entries per lane), 3 workgroups per CU on HBM-sized
  *                   matrices; 0 = the kernel with 4- / 8-byte loads                                      (creation)
@@ -369,6 +373,10 @@ int sprs_dist_mul_vec_dev_c(const sprs_csr *A, sprs_c32 *x_ext_dev, sprs_c32 *y_
 int sprs_comm_unique_id(void *id128_out);  /* rank 0: 128-byte RCCL id to broadcast to the other ranks */
 int sprs_comm_create(sprs_ctx *ctx, int world, int rank, const void *id128, sprs_comm **out); /* collective */
 int sprs_comm_destroy(sprs_comm *comm);
+/* 1 when the ranks of this communicator mapped each other's mailboxes at creation (same node, hipIpc): the distributed solvers'
+ * scalar hand-offs then need no stream operation — the producing kernel's last workgroup posts its reduced values into every
+ * rank's mailbox, the consumer kernels sum the entries in rank order (ctx knobs "p2p_allreduce", "p2p_timeout_ms"); 0: ncclAllReduce. */
+int sprs_comm_p2p(const sprs_comm *comm, int *enabled_out);
 int sprs_comm_count(const sprs_comm *comm, int *count_out); /* ncclCommCount: the number of ranks RCCL itself reports */
 int sprs_comm_allreduce_sum_f64(sprs_comm *comm, double *dev, size_t count); /* in place; blocking */
 /* mean time of `reps` back-to-back in-place all-reduces of `count` doubles on the context's stream (HIP events): the

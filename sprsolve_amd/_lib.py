@@ -114,6 +114,7 @@ def _protos():
     P["sprs_comm_create"] = [_vp, _int, _int, _vp, _pp]
     P["sprs_comm_destroy"] = [_vp]
     P["sprs_comm_count"] = [_vp, C.POINTER(_int)]
+    P["sprs_comm_p2p"] = [_vp, C.POINTER(_int)]
     P["sprs_comm_allreduce_sum_f64"] = [_vp, _vp, _sz]
     P["sprs_comm_allreduce_timed_f64"] = [_vp, _vp, _sz, _int, _pd]
     for s in ("d", "z", "s", "c"):

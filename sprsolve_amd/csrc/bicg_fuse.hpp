@@ -19,6 +19,7 @@ struct BicgK1 {
     BicgState<T> *S; const Real<T> *partN; const T *partRho; int P; int mode;
     const T *v; const T *r; T *p; const V *dinv; T *y;
     T a, beta;
+    unsigned int tag = 0; unsigned long long mb_timeout = 0;     // peer-to-peer hand-off: partN = this rank's mailbox entries, P = world (device.hpp, mbox_sum2)
     __device__ __forceinline__ bool prologue() {
         __shared__ Real<T> smD[NWAVE];
         __shared__ T smT[NWAVE];
@@ -31,8 +32,16 @@ struct BicgK1 {
         T rho; Real<T> r_norm;
         if (mode == 0) {
             Real<T> sN; T sR;
-            reduce_partials2(partN, partRho, P, smD, smT, sN, sR);  // :123 |r|^2, :128 r0.r
-            if (status != ST_RUNNING) return false;
+            if (tag != 0) {                                          // (status first: a stopped solve's producers posted nothing)
+                if (status != ST_RUNNING) return false;
+                if (!mbox_sum2(MboxSrc{reinterpret_cast<const unsigned long long *>(partN), P, tag, mb_timeout}, sN, sR)) {
+                    if (first_thread()) S->status = ST_COMM_TIMEOUT;
+                    return false;
+                }
+            } else {
+                reduce_partials2(partN, partRho, P, smD, smT, sN, sR);  // :123 |r|^2, :128 r0.r
+                if (status != ST_RUNNING) return false;
+            }
             r_norm = ssqrt(sN);                                      // :123
             if (r_norm <= tol2) {                                    // :124
                 if (first_thread()) { S->r_norm = r_norm; S->status = ST_CONVERGED; }
@@ -76,12 +85,22 @@ struct BicgK3 {
     BicgState<T> *S; const T *partB; int P; int check_breakdown;
     const T *v; T *r; const V *dinv; T *z;
     T na;
+    unsigned int tag = 0; unsigned long long mb_timeout = 0;     // peer-to-peer hand-off (see BicgK1)
     __device__ __forceinline__ bool prologue() {
         __shared__ T smT[NWAVE];
         const int status = S->status;                               // requested together with the partials
         const T rho = S->rho;
-        const T tmp = reduce_partials(partB, P, smT);               // :163
-        if (status != ST_RUNNING) return false;
+        T tmp;
+        if (tag != 0) {
+            if (status != ST_RUNNING) return false;
+            if (!mbox_sum1(MboxSrc{reinterpret_cast<const unsigned long long *>(partB), P, tag, mb_timeout}, tmp)) {
+                if (first_thread()) S->status = ST_COMM_TIMEOUT;
+                return false;
+            }
+        } else {
+            tmp = reduce_partials(partB, P, smT);                   // :163
+            if (status != ST_RUNNING) return false;
+        }
         if (check_breakdown && sabs(tmp) <= 0.0) {                  // :164-167
             if (first_thread()) S->status = ST_BREAKDOWN;
             return false;

@@ -116,6 +116,8 @@ int sprs_ctx_set(sprs_ctx *c, const char *key, int64_t value) {
     else if (k == "spmv_tile") c->spmv_tile = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_chain") c->spmv_chain = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_fuse") c->spmv_fuse = value < 0 ? -1 : (value ? 1 : 0);
+    else if (k == "p2p_allreduce") c->p2p_allreduce = value < 0 ? -1 : (value ? 1 : 0);
+    else if (k == "p2p_timeout_ms") c->p2p_timeout_ms = value < 1 ? 1 : value;
     else if (k == "ew_chunk") c->ew_chunk = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "stream_nt") c->stream_nt = value < 0 ? -1 : (value ? 1 : 0);
     else if (k == "spmv_eqrows") c->spmv_eqrows = value < 0 ? -1 : (value ? 1 : 0);
@@ -141,6 +143,8 @@ int64_t sprs_ctx_get(const sprs_ctx *c, const char *key) {
     if (k == "spmv_tile") return c->spmv_tile;
     if (k == "spmv_chain") return c->spmv_chain;
     if (k == "spmv_fuse") return c->spmv_fuse;
+    if (k == "p2p_allreduce") return c->p2p_allreduce;
+    if (k == "p2p_timeout_ms") return c->p2p_timeout_ms;
     if (k == "ew_chunk") return c->ew_chunk;
     if (k == "stream_nt") return c->stream_nt;
     if (k == "spmv_eqrows") return c->spmv_eqrows;

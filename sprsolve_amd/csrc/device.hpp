@@ -132,15 +132,75 @@ __device__ __forceinline__ void finalize_last_block(const Fin &fin, bool two, TA
     for (int i = threadIdx.x; i < fin.P; i += BLOCK) a = sadd(a, ld_through(pa + i));
     a = block_sum(a, smA);
     if (threadIdx.x == 0) *reinterpret_cast<TA *>(fin.out0) = a;
+    TB b = szero<TB>();
     if (two) {
         const TB *pb = reinterpret_cast<const TB *>(fin.base1);
-        TB b = szero<TB>();
         for (int i = threadIdx.x; i < fin.P; i += BLOCK) b = sadd(b, ld_through(pb + i));
         b = block_sum(b, smB);
         if (threadIdx.x == 0) *reinterpret_cast<TB *>(fin.out1) = b;
     }
+    if (fin.tag != 0) mbox_post(fin, a, b);               // peer-to-peer hand-off: every rank's mailbox gets this rank's values
     if (threadIdx.x == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
+
+// ---- peer-to-peer hand-off (struct P2pBox, internal.hpp): posted by finalize_last_block, summed by the consumers' prologues
+// One 16-byte cell per reduced value (a real scalar: the value and a zero pad; a complex one: re, im — the layout of `red`).
+template <class TV> __device__ __forceinline__ void to_cell(TV v, unsigned int *w) {          // 4 words
+    w[0] = w[1] = w[2] = w[3] = 0u;
+    __builtin_memcpy(w, &v, sizeof(TV));
+}
+// All threads of the posting workgroup hold the same (a, b): thread t writes granule t % 8 of the entry of THIS rank in rank
+// (t / 8)'s mailbox — one naturally aligned 8-byte system-scope store {data word, tag}: whole or absent on the other side.
+template <class TA, class TB>
+__device__ __forceinline__ void mbox_post(const Fin &fin, TA a, TB b) {
+    const P2pBox *bx = fin.box;
+    const int world = bx->world;
+    if ((int)threadIdx.x >= world * MB_GRAN) return;
+    unsigned int w[8];
+    to_cell(a, w); to_cell(b, w + 4);
+    const int dst = threadIdx.x / MB_GRAN, g = threadIdx.x % MB_GRAN;
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(bx->peer[dst] + fin.mb_off + (size_t)bx->rank * MB_ENTRY) + g;
+    unsigned int word = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) word = g == k ? w[k] : word;
+    __hip_atomic_store(p, (unsigned long long)word | ((unsigned long long)fin.tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// What a consumer reads instead of partials when its producer posted to the mailboxes: `entries` = this rank's mailbox at the
+// hand-off's [slot][parity] (one MB_ENTRY per source rank).  Every workgroup of every rank polls the `world` entries until each
+// granule carries the hand-off's tag (bounded: `timeout` ticks of the 100 MHz wall clock), then sums cell `cell` of the entries
+// in rank order from zero — the same bits in every workgroup of every rank, i.e. the same branch decisions everywhere.
+struct MboxSrc { const unsigned long long *entries; int world; unsigned int tag; unsigned long long timeout; };
+template <class TA, class TB>
+__device__ __forceinline__ bool mbox_sum2(const MboxSrc &m, TA &ra, TB &rb) {
+    __shared__ unsigned int s_mb[MB_RANKS][MB_GRAN];
+    __shared__ int s_fail;
+    if (threadIdx.x == 0) s_fail = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < m.world * MB_GRAN) {
+        const unsigned long long *p = m.entries + threadIdx.x;          // entries are contiguous: [src][granule]
+        const unsigned long long t0 = wall_clock64();
+        unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        while ((unsigned int)(v >> 32) != m.tag) {
+            if (wall_clock64() - t0 > m.timeout) { s_fail = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+            v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        s_mb[threadIdx.x / MB_GRAN][threadIdx.x % MB_GRAN] = (unsigned int)v;
+    }
+    __syncthreads();
+    if (s_fail) return false;
+    ra = szero<TA>(); rb = szero<TB>();
+    for (int src = 0; src < m.world; ++src) {
+        TA a; TB b;
+        __builtin_memcpy(&a, &s_mb[src][0], sizeof(TA));
+        __builtin_memcpy(&b, &s_mb[src][4], sizeof(TB));
+        ra = sadd(ra, a); rb = sadd(rb, b);
+    }
+    __syncthreads();                                                    // s_mb may be reused by a later call
+    return true;
+}
+template <class TA>
+__device__ __forceinline__ bool mbox_sum1(const MboxSrc &m, TA &ra) { TA dummy; return mbox_sum2<TA, TA>(m, ra, dummy); }
 
 // 16-byte packs: 2 doubles or 1 complex per lane per access (global_load_dwordx4).
 template <class T, int PK>

@@ -657,6 +657,8 @@ int sprs_comm_unique_id(void *id128) {
     return SPRS_OK;
 }
 
+static int p2p_setup(sprs_comm *c);
+static void p2p_release(sprs_comm *c);
 int sprs_comm_create(sprs_ctx *ctx, int world, int rank, const void *id128, sprs_comm **out) {
     if (!ctx || !out || !id128 || world < 1 || rank < 0 || rank >= world) return SPRS_INVALID_ARGUMENT;
     *out = nullptr;
@@ -671,13 +673,85 @@ int sprs_comm_create(sprs_ctx *ctx, int world, int rank, const void *id128, sprs
     SPRS_NCCL_TRY(ctx, rccl().CommInitRank(&nc, world, id, rank));
     sprs_comm *c = new sprs_comm();
     c->ctx = ctx; c->nccl = nc; c->world = world; c->rank = rank;
+    if (const int st = p2p_setup(c)) { p2p_release(c); (void)rccl().CommDestroy(nc); delete c; return st; }
     *out = c;
+    return SPRS_OK;
+}
+
+// Peer-to-peer mailboxes (internal.hpp, P2pBox): COLLECTIVE.  Every rank allocates its mailbox in uncached device memory, exports
+// it (hipIpcGetMemHandle), the 64-byte handles travel in one ncclAllGather together with a "so far so good" byte, every rank opens
+// the others' (same node: hipIpcOpenMemHandle maps the peer's HBM over xGMI; the dmabuf IPC mode HSA_ENABLE_IPC_MODE_LEGACY=0 is
+// what this pool's driver supports) and a last one-word all-reduce agrees on the outcome: either EVERY rank has every mailbox
+// mapped and the hand-offs may use them, or none does and they stay on ncclAllReduce.  Nothing here is an error: a rank that cannot
+// export or map (another node, an IPC-less driver) just votes no.
+static void p2p_release(sprs_comm *c) {
+    for (int q = 0; q < 8; ++q)
+        if (c->peer_map[q] && q != c->rank) (void)hipIpcCloseMemHandle(c->peer_map[q]);
+    for (auto &q : c->peer_map) q = nullptr;
+    if (c->d_box) (void)hipFree(c->d_box);
+    if (c->mbox) (void)hipFree(c->mbox);
+    c->d_box = nullptr; c->mbox = nullptr; c->p2p = false;
+}
+static int p2p_setup(sprs_comm *c) {
+    sprs_ctx *ctx = c->ctx;
+    if (ctx->p2p_allreduce == 0 || c->world > MB_RANKS) return SPRS_OK;
+    struct Card { hipIpcMemHandle_t h; unsigned char ok; unsigned char pad[7]; };
+    static_assert(sizeof(Card) == 72, "handle card");
+    Card mine; memset(&mine, 0, sizeof(mine));
+    bool ok = true;
+    if (hipExtMallocWithFlags(&c->mbox, MB_BYTES, hipDeviceMallocUncached) != hipSuccess) { c->mbox = nullptr; ok = hipMalloc(&c->mbox, MB_BYTES) == hipSuccess; }
+    ok = ok && hipMemsetAsync(c->mbox, 0, MB_BYTES, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (ok && c->world > 1) ok = hipIpcGetMemHandle(&mine.h, c->mbox) == hipSuccess;
+    (void)hipGetLastError();
+    mine.ok = ok ? 1 : 0;
+    std::vector<Card> all((size_t)c->world);
+    void *d_cards = nullptr;
+    SPRS_HIP_TRY(ctx, hipMalloc(&d_cards, sizeof(Card) * ((size_t)c->world + 1)));
+    struct Free { void *p; ~Free() { if (p) (void)hipFree(p); } } guard{d_cards};
+    Card *d_mine = reinterpret_cast<Card *>(d_cards) + c->world;
+    SPRS_HIP_TRY(ctx, hipMemcpyAsync(d_mine, &mine, sizeof(Card), hipMemcpyHostToDevice, ctx->stream));
+    SPRS_NCCL_TRY(ctx, rccl().AllGather(d_mine, d_cards, sizeof(Card), ncclInt8, (ncclComm_t)c->nccl, ctx->stream));
+    SPRS_HIP_TRY(ctx, hipMemcpyAsync(all.data(), d_cards, sizeof(Card) * (size_t)c->world, hipMemcpyDeviceToHost, ctx->stream));
+    SPRS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < c->world; ++q) ok = ok && all[(size_t)q].ok;
+    if (ok) {
+        c->peer_map[c->rank] = c->mbox;
+        for (int q = 0; q < c->world && ok; ++q) {
+            if (q == c->rank) continue;
+            ok = hipIpcOpenMemHandle(&c->peer_map[q], all[(size_t)q].h, hipIpcMemLazyEnablePeerAccess) == hipSuccess;
+            if (!ok) c->peer_map[q] = nullptr;
+        }
+        (void)hipGetLastError();
+    }
+    // the vote: how many ranks could NOT map everything
+    double *d_vote = reinterpret_cast<double *>(d_cards);
+    const double mine_bad = ok ? 0.0 : 1.0;
+    SPRS_HIP_TRY(ctx, hipMemcpyAsync(d_vote, &mine_bad, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SPRS_NCCL_TRY(ctx, rccl().AllReduce(d_vote, d_vote, 1, ncclDouble, ncclSum, (ncclComm_t)c->nccl, ctx->stream));
+    double bad = 1.0;
+    SPRS_HIP_TRY(ctx, hipMemcpyAsync(&bad, d_vote, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SPRS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad != 0.0) { p2p_release(c); return SPRS_OK; }
+    P2pBox box; memset(&box, 0, sizeof(box));
+    for (int q = 0; q < c->world; ++q) box.peer[q] = (unsigned long long)reinterpret_cast<uintptr_t>(c->peer_map[q]);
+    box.world = c->world; box.rank = c->rank;
+    SPRS_HIP_TRY(ctx, hipMalloc((void **)&c->d_box, sizeof(P2pBox)));
+    SPRS_HIP_TRY(ctx, hipMemcpyAsync(c->d_box, &box, sizeof(P2pBox), hipMemcpyHostToDevice, ctx->stream));
+    SPRS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    c->p2p = true;
+    return SPRS_OK;
+}
+
+int sprs_comm_p2p(const sprs_comm *comm, int *enabled_out) {
+    if (!comm || !enabled_out) return SPRS_INVALID_ARGUMENT;
+    *enabled_out = comm->p2p ? 1 : 0;
     return SPRS_OK;
 }
 
 int sprs_comm_destroy(sprs_comm *comm) {
     if (!comm) return SPRS_OK;
     if (comm->ctx) (void)hipStreamSynchronize(comm->ctx->stream);
+    p2p_release(comm);
     if (comm->nccl && rccl().ok) (void)rccl().CommDestroy((ncclComm_t)comm->nccl);
     delete comm;
     return SPRS_OK;

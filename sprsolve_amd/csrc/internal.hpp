@@ -21,18 +21,37 @@ constexpr uint32_t SEAM2 = 0x20000000u; // ... bit 29 (with UNI2, full 128-row b
 constexpr int MAX_GRID = 4096; // upper bound of the streaming-kernel grid (= max partials per reduction)
 
 // device-side status word of a running solve
-enum : int { ST_RUNNING = 0, ST_CONVERGED = 1, ST_RESTART = 2, ST_BREAKDOWN = 3, ST_INVALID_PC = 4 };
+enum : int { ST_RUNNING = 0, ST_CONVERGED = 1, ST_RESTART = 2, ST_BREAKDOWN = 3, ST_INVALID_PC = 4,
+             ST_COMM_TIMEOUT = 5 };   // a peer's hand-off never arrived in this rank's mailbox (device.hpp, mbox_sum)
 
 // Hand-off of a fused reduction whose FINAL value is computed inside the producing launch (device.hpp,
 // finalize_last_block): the workgroup that arrives last re-reduces all partials in the library's fixed order and writes
 // the scalars to out0 / out1.  Used by the distributed solves, whose consumer is an ncclAllReduce of those scalars: one
 // stream operation per hand-off instead of a finalize launch plus the collective.  counter == nullptr: no finalize (the
 // consumer kernel re-reduces the partials itself, the single-GPU hand-off).
+// Peer-to-peer mailboxes of a communicator (dist.hip, p2p_setup; SURVEY §8e's deterministic all-reduce): every rank owns one
+// mailbox of MB_BYTES in uncached device memory, mapped into every other rank of the node (hipIpcOpenMemHandle).  A hand-off's
+// producer writes its reduced scalars into EVERY rank's mailbox — entry [slot][parity][source rank], eight 8-byte granules
+// {32 data bits, 32-bit tag}, each one naturally aligned store, so a granule is seen whole or not at all whatever the link —
+// and the consumer kernels of all ranks sum the `world` entries in rank order: bit-identical on every rank, no stream operation.
+constexpr int MB_SLOTS = 4, MB_RANKS = 8, MB_GRAN = 8;
+constexpr size_t MB_ENTRY = MB_GRAN * 8;                                  // 64 B: two 16-byte cells (out0, out1) as 8 granules
+constexpr size_t MB_BYTES = (size_t)MB_SLOTS * 2 * MB_RANKS * MB_ENTRY;   // 4 KiB
+inline size_t mb_offset(int slot, int parity) { return ((size_t)slot * 2 + (size_t)parity) * MB_RANKS * MB_ENTRY; }
+struct P2pBox {
+    unsigned long long peer[MB_RANKS];   // rank q's mailbox as mapped on this device (own rank: the local allocation)
+    int world, rank;
+};
+
 struct Fin {
     unsigned int *counter = nullptr;   // agent-scope arrival counter, zero between launches
     const void *base0 = nullptr, *base1 = nullptr;   // first partial of the WHOLE reduction (an earlier launch may have written the head)
     void *out0 = nullptr, *out1 = nullptr;           // the reduced values (16-byte slots of the solver's `red` buffer)
     int P = 0;                         // partials of the whole reduction
+    // peer-to-peer hand-off: the last workgroup also posts the values into every rank's mailbox (tag != 0)
+    const P2pBox *box = nullptr;
+    unsigned int tag = 0;              // this hand-off's sequence number on its slot (never 0)
+    unsigned int mb_off = 0;           // byte offset of [slot][parity] inside a mailbox
 };
 
 }  // namespace sprs
@@ -65,6 +84,8 @@ struct sprs_ctx {
     int spmv_uniform = -1; // ... and blocks whose rows all repeat one code sequence read neither codes nor row_ptr; read at creation
     int halo_overlap = 1;  // distributed SpMV: run the halo-free rows while the halo travels
     int gs_graph = 0;    // Gauss-Seidel: 1 = replay a sweep's level launches from a hipGraph (tests/test_gpu_gauss_seidel.py; no gain measured, r01_tuning.md)
+    int p2p_allreduce = -1; // distributed hand-offs through the peer-to-peer mailboxes instead of ncclAllReduce: -1 / 1 wherever the communicator has them, 0 = RCCL.  Read at communicator creation (0: no mailboxes are set up) and per solve
+    int p2p_timeout_ms = 20000; // a consumer that has polled its mailbox this long gives up (status ST_COMM_TIMEOUT -> SPRS_ERR_RCCL)
     int poll = 16;       // iterations between host polls of the device status word
     double *d_part = nullptr;  // reduction partials for the stand-alone vecalg entry points
     double *d_scal = nullptr;  // small device result buffer
@@ -127,6 +148,12 @@ struct sprs_comm {
     sprs_ctx *ctx = nullptr;
     void *nccl = nullptr;   // ncclComm_t
     int world = 1, rank = 0;
+    // peer-to-peer mailboxes (sprs::P2pBox): set up collectively at creation when every rank could map every other's
+    bool p2p = false;
+    void *mbox = nullptr;                 // this rank's mailbox (uncached device memory, MB_BYTES)
+    void *peer_map[8] = {nullptr};        // the other ranks' mailboxes as opened here (hipIpcOpenMemHandle); [rank] = mbox
+    sprs::P2pBox *d_box = nullptr;        // device copy of the table
+    unsigned int seq[4] = {0, 0, 0, 0};   // hand-offs issued per slot: the host recurrences are replicated, so every rank counts alike
 };
 
 // Row-partition metadata of a distributed CSR operator: which local x entries each peer needs

@@ -80,13 +80,22 @@ struct BicgK5 {
     Fin fin;                    // distributed: the last workgroup reduces (partN, partRho) for the all-reduce
     T na, nw, w;
     Real<T> accN; T accR;
+    unsigned int tag = 0; unsigned long long mb_timeout = 0;     // peer-to-peer hand-off (see BicgK1): partTT = this rank's mailbox entries
     __device__ __forceinline__ bool prologue() {
         __shared__ T smT[NWAVE];
         __shared__ T smT2[NWAVE];
         const int status = S->status;                               // requested together with the partials
         const T alpha = S->alpha;
         T tt, tr;
-        reduce_partials2(partTT, partTR, P, smT, smT2, tt, tr);     // :178, :183
+        if (tag != 0) {
+            if (status != ST_RUNNING) { fin_idle(fin, true); return false; }
+            if (!mbox_sum2(MboxSrc{reinterpret_cast<const unsigned long long *>(partTT), P, tag, mb_timeout}, tt, tr)) {
+                if (first_thread()) S->status = ST_COMM_TIMEOUT;
+                return false;
+            }
+        } else {
+            reduce_partials2(partTT, partTR, P, smT, smT2, tt, tr); // :178, :183
+        }
         if (status != ST_RUNNING) { fin_idle(fin, true); return false; }
         w = (sre(tt) > 0.0) ? sdiv(tr, tt) : szero<T>();            // :179-186
         na = sneg(alpha); nw = sneg(w);
@@ -131,11 +140,21 @@ struct MinresM2 {
     const T *v_old; const T *v; T *v_new; const V *dinv; T *w_new; Real<T> *partBeta; T *partBeta2;
     Fin fin;                    // distributed: the last workgroup reduces partBeta / partBeta2 for the all-reduce
     T nb, na; Real<T> accD; T accT;
+    unsigned int tag = 0; unsigned long long mb_timeout = 0;     // peer-to-peer hand-off (see BicgK1): partAlpha = this rank's mailbox entries
     __device__ __forceinline__ bool prologue() {
         __shared__ T smT[NWAVE];
         const int status = D->status;                               // requested together with the partials
         const Real<T> beta = D->st[par].beta;
-        const T alpha = reduce_partials(partAlpha, P, smT);         // :116
+        T alpha;
+        if (tag != 0) {
+            if (status != ST_RUNNING) { fin_idle(fin, false); return false; }
+            if (!mbox_sum1(MboxSrc{reinterpret_cast<const unsigned long long *>(partAlpha), P, tag, mb_timeout}, alpha)) {
+                if (first_thread()) D->status = ST_COMM_TIMEOUT;
+                return false;
+            }
+        } else {
+            alpha = reduce_partials(partAlpha, P, smT);             // :116
+        }
         if (status != ST_RUNNING) { fin_idle(fin, false); return false; }
         nb = sfromr<T>(-beta);                                      // :117 T::from_real(-beta)
         na = sneg(alpha);                                           // :118
@@ -186,6 +205,7 @@ struct MinresM3 {
     MinresDev<T> *D; int par; long long its; const Real<T> *partBeta; const T *partBeta2; int P;
     T *v_new; T *w_new; const T *q; const T *p_old; const T *p_oold; T *p; T *x;
     Real<T> inv, r1_inv, beta_new, s_new; T nr2, nr3, coef, c_new;
+    unsigned int tag = 0; unsigned long long mb_timeout = 0;     // peer-to-peer hand-off (see BicgK1): partBeta / partBeta2 = this rank's mailbox entries
     // This launch's own epilogue sets the status to "converged at `its`" when workgroup 0 is done — possibly before another
     // workgroup of the SAME launch has read the status word.  That workgroup must still do its share of this iteration (the
     // reference updates x, then tests: minres.rs:162-167), so the event carries its iteration and this launch does not
@@ -197,8 +217,17 @@ struct MinresM3 {
         __shared__ T smT[NWAVE];
         const int status = D->status;                               // state words requested together with the partials
         const MinresState<T> S = D->st[par];                        // (a copy: st[par] is not written by this launch)
+        if (tag != 0 && stopped(status)) return false;              // (status first: a stopped solve's producers posted nothing)
         if (PC) {
-            const T b2 = reduce_partials(partBeta2, P, smT);        // :278
+            T b2;
+            if (tag != 0) {
+                if (!mbox_sum1(MboxSrc{reinterpret_cast<const unsigned long long *>(partBeta2), P, tag, mb_timeout}, b2)) {
+                    if (first_thread()) D->status = ST_COMM_TIMEOUT;
+                    return false;
+                }
+            } else {
+                b2 = reduce_partials(partBeta2, P, smT);            // :278
+            }
             if (stopped(status)) return false;
             if (sre(b2) < seps<Real<T>>() || sim(b2) > seps<Real<T>>() * sre(b2)) {         // :279-287
                 if (first_thread()) { D->st[par].pc_re = sre(b2); D->its = its; D->status = ST_INVALID_PC; }
@@ -206,7 +235,16 @@ struct MinresM3 {
             }
             beta_new = ssqrt(sre(b2));                               // :288
         } else {
-            beta_new = ssqrt(reduce_partials(partBeta, P, smD));     // :120
+            Real<T> bsq;
+            if (tag != 0) {
+                if (!mbox_sum1(MboxSrc{reinterpret_cast<const unsigned long long *>(partBeta), P, tag, mb_timeout}, bsq)) {
+                    if (first_thread()) D->status = ST_COMM_TIMEOUT;
+                    return false;
+                }
+            } else {
+                bsq = reduce_partials(partBeta, P, smD);
+            }
+            beta_new = ssqrt(bsq);                                   // :120
             if (stopped(status)) return false;
         }
         inv = Real<T>(1) / beta_new;                                       // :121 / :289
@@ -313,7 +351,9 @@ int KrylovBase<T>::ew_grid() const {
 }
 
 // Hand-offs of the distributed case.  The producing launch's last-arriving workgroup has already reduced the partials
-// into `red` (struct Fin / finalize_last_block): all that is left per hand-off is ONE stream operation, the all-reduce.
+// into `red` (struct Fin / finalize_last_block): all that is left per hand-off is ONE stream operation, the all-reduce — or
+// NONE where the communicator has peer-to-peer mailboxes (knob "p2p_allreduce"): that workgroup also posts the
+// values into every rank's mailbox and the consumer kernels of all ranks sum the `world` entries in rank order (device.hpp).
 template <class T>
 Fin KrylovBase<T>::fin_for(int slot, const void *base0, const void *base1, int P) const {
     if (!A->dist) return Fin{};
@@ -322,11 +362,25 @@ Fin KrylovBase<T>::fin_for(int slot, const void *base0, const void *base1, int P
     f.base0 = base0; f.base1 = base1;
     f.out0 = red + 2 * slot; f.out1 = red + 2 * slot + 2;
     f.P = P;
+    if (use_p2p()) {
+        // one more hand-off on this slot: its tag and the half of the slot it uses.  A fast rank can be at most one hand-off of
+        // a slot ahead of a slow one (to post hand-off h + 2 it must have consumed h + 1, which the slow rank posts only after
+        // all its workgroups consumed h), so two halves suffice.
+        sprs_comm *cm = A->dist->comm;
+        const unsigned int h = ++cm->seq[slot];
+        f.box = cm->d_box; f.tag = h; f.mb_off = (unsigned int)mb_offset(slot, (int)(h & 1u));
+    }
     return f;
+}
+template <class T>
+const void *KrylovBase<T>::mbox_entries(int slot) const {
+    const sprs_comm *cm = A->dist->comm;
+    return reinterpret_cast<const char *>(cm->mbox) + mb_offset(slot, (int)(cm->seq[slot] & 1u));
 }
 template <class T>
 int KrylovBase<T>::red1(const T *a, int P, int slot, PartT *oa) {
     if (!A->dist) { *oa = PartT{a, P}; return SPRS_OK; }
+    if (use_p2p()) { *oa = PartT{reinterpret_cast<const T *>(mbox_entries(slot)), comm()->world, comm()->seq[slot]}; return SPRS_OK; }
     double *ra = red + 2 * slot;
     SPRS_TRY(allreduce_sum(comm(), ra, 16 / sizeof(Real<T>), sizeof(Real<T>) == 4));
     *oa = PartT{reinterpret_cast<const T *>(ra), 1};
@@ -335,6 +389,11 @@ int KrylovBase<T>::red1(const T *a, int P, int slot, PartT *oa) {
 template <class T>
 int KrylovBase<T>::red2(const T *a, const T *b, int P, int slot, PartT *oa, PartT *ob) {
     if (!A->dist) { *oa = PartT{a, P}; *ob = PartT{b, P}; return SPRS_OK; }
+    if (use_p2p()) {
+        *oa = PartT{reinterpret_cast<const T *>(mbox_entries(slot)), comm()->world, comm()->seq[slot]};
+        *ob = *oa;
+        return SPRS_OK;
+    }
     double *ra = red + 2 * slot, *rb = red + 2 * slot + 2;
     SPRS_TRY(allreduce_sum(comm(), ra, 32 / sizeof(Real<T>), sizeof(Real<T>) == 4));
     *oa = PartT{reinterpret_cast<const T *>(ra), 1};
@@ -344,6 +403,7 @@ int KrylovBase<T>::red2(const T *a, const T *b, int P, int slot, PartT *oa, Part
 template <class T>
 int KrylovBase<T>::redD1(const Real<T> *a, int P, int slot, PartD *oa) {
     if (!A->dist) { *oa = PartD{a, P}; return SPRS_OK; }
+    if (use_p2p()) { *oa = PartD{reinterpret_cast<const Real<T> *>(mbox_entries(slot)), comm()->world, comm()->seq[slot]}; return SPRS_OK; }
     double *ra = red + 2 * slot;
     SPRS_TRY(allreduce_sum(comm(), ra, 16 / sizeof(Real<T>), sizeof(Real<T>) == 4));
     *oa = PartD{reinterpret_cast<const Real<T> *>(ra), 1};
@@ -352,6 +412,11 @@ int KrylovBase<T>::redD1(const Real<T> *a, int P, int slot, PartD *oa) {
 template <class T>
 int KrylovBase<T>::redDT(const Real<T> *a, const T *b, int P, int slot, PartD *oa, PartT *ob) {
     if (!A->dist) { *oa = PartD{a, P}; *ob = PartT{b, P}; return SPRS_OK; }
+    if (use_p2p()) {
+        *oa = PartD{reinterpret_cast<const Real<T> *>(mbox_entries(slot)), comm()->world, comm()->seq[slot]};
+        *ob = PartT{reinterpret_cast<const T *>(mbox_entries(slot)), comm()->world, comm()->seq[slot]};
+        return SPRS_OK;
+    }
     double *ra = red + 2 * slot, *rb = red + 2 * slot + 2;
     SPRS_TRY(allreduce_sum(comm(), ra, 32 / sizeof(Real<T>), sizeof(Real<T>) == 4));
     *oa = PartD{reinterpret_cast<const Real<T> *>(ra), 1};
@@ -569,8 +634,8 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
     };
     auto K3 = [&](int check) -> int {
         if (fuse) { pend_k3 = check; return (int)SPRS_OK; }     // formed by the next K4
-        if (pc) return launch_fused<T>(c, n, G, cw, BicgK3<T, V, true>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()});
-        return launch_fused<T>(c, n, G, cw, BicgK3<T, V, false>{d_state, qB.p, qB.P, check, v, r, dinv, z, T()});
+        if (pc) return launch_fused<T>(c, n, G, cw, BicgK3<T, V, true>{d_state, qB.p, qB.P, check, v, r, dinv, z, T(), qB.tag, this->mb_timeout()});
+        return launch_fused<T>(c, n, G, cw, BicgK3<T, V, false>{d_state, qB.p, qB.P, check, v, r, dinv, z, T(), qB.tag, this->mb_timeout()});
     };
     auto K4 = [&]() -> int {                                                                 // :104/:175 t = A s ; t.t, t.r
         const Fin f = this->fin_for(1, partTT, partTR, GS);
@@ -589,14 +654,14 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
     };
     auto K5 = [&]() -> int {
         const Fin f = this->fin_for(3, partN, partRho, G);
-        if (pc) SPRS_TRY(launch_fused<T>(c, n, G, cw, BicgK5<T, true>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, f, T(), T(), T(), 0.0, T()}));
-        else SPRS_TRY(launch_fused<T>(c, n, G, cw, BicgK5<T, false>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, f, T(), T(), T(), 0.0, T()}));
+        if (pc) SPRS_TRY(launch_fused<T>(c, n, G, cw, BicgK5<T, true>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, f, T(), T(), T(), 0.0, T(), qTT.tag, this->mb_timeout()}));
+        else SPRS_TRY(launch_fused<T>(c, n, G, cw, BicgK5<T, false>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, f, T(), T(), T(), 0.0, T(), qTT.tag, this->mb_timeout()}));
         return this->redDT(partN, partRho, G, 3, &qN, &qRho);
     };
     auto K1 = [&](int mode) -> int {
         if (fuse) { pend_k1 = mode; return (int)SPRS_OK; }      // formed by the next K2
-        if (pc) return launch_fused<T>(c, n, G, cw, BicgK1<T, V, true>{d_state, qN.p, qRho.p, qN.P, mode, v, r, p, dinv, y, T(), T()});
-        return launch_fused<T>(c, n, G, cw, BicgK1<T, V, false>{d_state, qN.p, qRho.p, qN.P, mode, v, r, p, dinv, y, T(), T()});
+        if (pc) return launch_fused<T>(c, n, G, cw, BicgK1<T, V, true>{d_state, qN.p, qRho.p, qN.P, mode, v, r, p, dinv, y, T(), T(), qN.tag, this->mb_timeout()});
+        return launch_fused<T>(c, n, G, cw, BicgK1<T, V, false>{d_state, qN.p, qRho.p, qN.P, mode, v, r, p, dinv, y, T(), T(), qN.tag, this->mb_timeout()});
     };
     auto fetch = [&]() -> int {
         SPRS_HIP_TRY(c, hipMemcpyAsync(&H, d_state, sizeof(H), hipMemcpyDeviceToHost, c->stream));
@@ -639,6 +704,10 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
             if (H.status == ST_BREAKDOWN) {                                 // :164-167
                 *its_out = (size_t)H.its;
                 return SPRS_BREAKDOWN;
+            }
+            if (H.status == ST_COMM_TIMEOUT) {
+                snprintf(c->err, sizeof(c->err), "a peer's hand-off did not reach this rank's mailbox within %d ms (p2p_timeout_ms)", c->p2p_timeout_ms);
+                return SPRS_ERR_RCCL;
             }
             if (H.status == ST_RESTART) {                                   // :131-145, executed at iteration H.its
                 // K2 / K4 of the iterations enqueued from the requesting one on returned at their first instruction
@@ -888,17 +957,17 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> t
             typename KrylovBase<T>::PartD qBt{partBeta, G};
             SPRS_TRY(this->red1(partAlpha, GS, 0, &qA));
             if (pc) {
-                SPRS_TRY(launch_fused<T>(c, n, G, cw, MinresM2<T, V, true>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, this->fin_for(1, partBeta2, nullptr, G), T(), T(), 0.0, T()}));
+                SPRS_TRY(launch_fused<T>(c, n, G, cw, MinresM2<T, V, true>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, this->fin_for(1, partBeta2, nullptr, G), T(), T(), 0.0, T(), qA.tag, this->mb_timeout()}));
                 SPRS_TRY(this->red1(partBeta2, G, 1, &qB2));
             } else {
-                SPRS_TRY(launch_fused<T>(c, n, G, cw, MinresM2<T, V, false>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, this->fin_for(1, partBeta, nullptr, G), T(), T(), 0.0, T()}));
+                SPRS_TRY(launch_fused<T>(c, n, G, cw, MinresM2<T, V, false>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, this->fin_for(1, partBeta, nullptr, G), T(), T(), 0.0, T(), qA.tag, this->mb_timeout()}));
                 SPRS_TRY(this->redD1(partBeta, G, 1, &qBt));
             }
             { T *tp = p_oold; p_oold = p_old; p_old = p; p = tp; }           // :151-154
 #define SPRS_M3(PCF, SAF)                                                                                        \
     launch_fused<T>(c, n, G, cw, MinresM3<T, PCF, SAF>{d_state, par, (long long)its, qBt.p, qB2.p, pc ? qB2.P : qBt.P, v_new,  \
                                                    w_new, q, p_old, p_oold, p, x, 0.0, 0.0, 0.0, 0.0, T(), T(),  \
-                                                   T(), T()})
+                                                   T(), T(), pc ? qB2.tag : qBt.tag, this->mb_timeout()})
             if (pc) SPRS_TRY(SPRS_M3(true, false));
             else if (sau) SPRS_TRY(SPRS_M3(false, true));
             else SPRS_TRY(SPRS_M3(false, false));
@@ -921,6 +990,10 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> t
             if (H.status == ST_INVALID_PC) {                                // :279-287
                 *its_out = (size_t)H.its; *res_out = H.st[H.its & 1].pc_re;
                 return SPRS_INVALID_PRECOND;
+            }
+            if (H.status == ST_COMM_TIMEOUT) {
+                snprintf(c->err, sizeof(c->err), "a peer's hand-off did not reach this rank's mailbox within %d ms (p2p_timeout_ms)", c->p2p_timeout_ms);
+                return SPRS_ERR_RCCL;
             }
             if (done_enqueue) break;
             if (tracing) {

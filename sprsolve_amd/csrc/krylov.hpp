@@ -80,8 +80,11 @@ class KrylovBase {
     // P partials itself.  Distributed: the producer's last workgroup has reduced them into `red`
     // (fixed order; fin_for), these all-reduce over the ranks, and the consumer reads one value.
     // `slot` picks a 16-byte cell of `red`.
-    struct PartT { const T *p; int P; };
-    struct PartD { const Real<T> *p; int P; };
+    struct PartT { const T *p; int P; unsigned int tag = 0; };            // tag != 0: p = this rank's mailbox entries of the hand-off, P = world
+    struct PartD { const Real<T> *p; int P; unsigned int tag = 0; };
+    bool use_p2p() const { return A->dist && A->dist->comm->p2p && ctx->p2p_allreduce != 0; }
+    unsigned long long mb_timeout() const { return (unsigned long long)(ctx->p2p_timeout_ms < 1 ? 1 : ctx->p2p_timeout_ms) * 100000ull; }   // ticks of the 100 MHz wall clock
+    const void *mbox_entries(int slot) const;    // this rank's mailbox at the CURRENT hand-off of `slot`
     int red1(const T *a, int P, int slot, PartT *oa);
     int red2(const T *a, const T *b, int P, int slot, PartT *oa, PartT *ob);
     int redD1(const Real<T> *a, int P, int slot, PartD *oa);

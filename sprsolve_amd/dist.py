@@ -44,6 +44,13 @@ class Comm:
         check(_lib.lib().sprs_comm_count(self.h, C.byref(n)), self.ctx.h)
         return int(n.value)
 
+    def p2p(self):
+        """True when the ranks mapped each other's mailboxes at creation: the solvers' scalar hand-offs then need no stream
+        operation (csrc/dist.hip p2p_setup, ctx knob "p2p_allreduce")."""
+        n = C.c_int(0)
+        check(_lib.lib().sprs_comm_p2p(self.h, C.byref(n)), self.ctx.h)
+        return bool(n.value)
+
     def close(self):
         if self.h:
             _lib.lib().sprs_comm_destroy(self.h)
@@ -205,8 +212,13 @@ def bench_poisson3d(torch, tdist, ctx, rank, world, nx, ny, nz, steps, warmup, t
     # what one dot-product hand-off costs on this communicator: an all-reduce of 4 doubles on the solver's stream
     scratch = torch.zeros(4, dtype=torch.float64, device=dev)
     ar_us = comm.allreduce_us(scratch, 4, 200)
+    p2p_on = bool(comm.p2p()) and ctx.get("p2p_allreduce") != 0
     dist_info = dict(rccl_ranks=min(p["rccl_ranks"] for p in per_rank), exchange=exchange,
                      halo_bytes=[p["halo_recv_bytes"] for p in per_rank], allreduce_us=ar_us,
-                     allreduce_note="mean of 200 back-to-back ncclAllReduce(4 x f64) on the solver's stream; a BiCGStab iteration has 3",
+                     allreduce_note="mean of 200 back-to-back ncclAllReduce(4 x f64) on the solver's stream; a BiCGStab iteration has 3 scalar hand-offs"
+                                    + (" — which this run did NOT pay: scalar_handoff = peer-to-peer mailboxes" if p2p_on else ""),
+                     scalar_handoff=("peer-to-peer mailboxes: the producing kernel's last workgroup posts its reduced values into every rank's "
+                                     "mailbox (hipIpc-mapped, uncached), the consumer kernels sum the entries in rank order; no stream operation "
+                                     "(csrc/device.hpp mbox_post / mbox_sum2)" if p2p_on else "ncclAllReduce on the solver's stream, 3 per iteration"),
                      per_rank=per_rank, ms_per_step=ms_step, timing=trec, create_ms=create_ms)
     return dt, prof, t_spmv, bs, check_, nx * ny * nz, int(tot), sinfo, dist_info

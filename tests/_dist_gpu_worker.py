@@ -96,11 +96,16 @@ def main(rank, world, rdzv, kind, outdir, exchange="halo"):
     A.mul_vec_ext(x_ext, y)
     # distributed solves: plain and Jacobi (BiCGStab) / plain (MINRES), fused and literal
     res = {}
-    for mode in ("fused", "literal"):
-        s = solver_cls.new(A, n_loc); s.set_mode(mode); s.set_trace(6)
+    p2p = bool(comm.p2p())          # the ranks mapped each other's mailboxes (real hipIpc handles between these processes)
+    for mode in ("fused", "literal", "fused_rccl"):
+        # "fused": the scalar hand-offs go through the peer-to-peer mailboxes (no stream operation; csrc/device.hpp mbox_post /
+        # mbox_sum2); "fused_rccl": the same solve with ncclAllReduce hand-offs (here: the mock's rank-order sum)
+        ctx.set("p2p_allreduce", 0 if mode == "fused_rccl" else -1)
+        s = solver_cls.new(A, n_loc); s.set_mode("fused" if mode == "fused_rccl" else mode); s.set_trace(6)
         xs = torch.zeros(n_loc, dtype=torch.float64, device=dev)
         its, rr = s.solve(t(rhs), xs, 3000, 1e-10)
         res[mode] = (its, rr, xs.cpu().numpy(), s.trace())
+    ctx.set("p2p_allreduce", -1)
     extra = None
     if pdiag is not None:
         P = sa.DiagPrecond.new(pdiag)
@@ -111,6 +116,7 @@ def main(rank, world, rdzv, kind, outdir, exchange="halo"):
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), y=y.cpu().numpy(),
              x_fused=res["fused"][2], its_fused=res["fused"][0], res_fused=res["fused"][1], trace_fused=res["fused"][3],
              x_lit=res["literal"][2], its_lit=res["literal"][0], trace_lit=res["literal"][3],
+             x_rccl=res["fused_rccl"][2], its_rccl=res["fused_rccl"][0], res_rccl=res["fused_rccl"][1], trace_rccl=res["fused_rccl"][3], p2p=int(p2p),
              x_pc=extra[2] if extra else np.zeros(0), its_pc=extra[0] if extra else -1,
              n_ext=plan["n_ext"], n_loc=n_loc, overlap=int(A.h is not None), tiles=np.array(A.tile_plan() if hasattr(A, "tile_plan") else (0, 0, 0)))
     tdist.barrier()

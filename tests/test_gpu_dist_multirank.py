@@ -76,6 +76,14 @@ def test_real_ranks_match_single_process(oracle, mock_lib, world, kind, exchange
         for r in res[1:]:
             assert np.array_equal(r["trace_" + key], tr), "ranks must hold bit-identical scalars"
         assert np.allclose(tr[:4], ref.trace[:4], rtol=1e-9, atol=1e-12)
+    # the peer-to-peer hand-off (default wherever the ranks could map each other's mailboxes — here: real hipIpc mappings between
+    # the 2 / 3 processes) against the ncclAllReduce one: both sum the ranks' values in rank order, so the solves must agree BIT
+    # FOR BIT — iteration count, residual, every traced scalar, x — on every rank
+    assert all(int(r["p2p"]) == 1 for r in res), "the ranks could not map each other's mailboxes"
+    for r in res:
+        assert int(r["its_fused"]) == int(r["its_rccl"]) and float(r["res_fused"]) == float(r["res_rccl"])
+        assert np.array_equal(r["trace_fused"].view(np.uint64), r["trace_rccl"].view(np.uint64)), "a scalar differs between the mailbox and the RCCL hand-off"
+        assert np.array_equal(r["x_fused"].view(np.uint64), r["x_rccl"].view(np.uint64))
     if refpc is not None:
         x = np.concatenate([r["x_pc"] for r in res])
         assert np.max(np.abs(x - refpc.x)) <= 1e-7
