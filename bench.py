@@ -204,7 +204,8 @@ def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8, dot_launches=0, fused=(0, 
     return r
 
 
-SPMV_SOURCES = ("device.hpp", "internal.hpp", "scalar.hpp", "spmv.hip", "spmv_dict.hip")
+SPMV_SOURCES = ("device.hpp", "internal.hpp", "scalar.hpp", "spmv.hip", "spmv_dict.hip", "spmv_dict_dev.hpp", "spmv_tile.hip", "spmv_tile_off.hip",
+                "spmv_chain.hip", "bicg_fuse.hpp")
 
 
 def csrc_digest():
@@ -223,7 +224,7 @@ def pmc_traffic(key):
     """HBM-side bytes per SpMV launch from the committed rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE passes
     of this bench command, gfx950 x2 FETCH correction) — measured off-line, so it goes stale when the kernels change:
     the summary records the digest of csrc/ it was taken with, and the note says whether that is still the code running."""
-    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
