@@ -82,6 +82,22 @@ void rccl_load(Rccl &r) {
         }                                                                                               \
     } while (0)
 
+// One round trip through the mailboxes at communicator creation (p2p_setup): every rank posts {rank + 1, 2 rank + 1} with the
+// self-test's tag into every rank's mailbox and sums what arrives in its own.  result[0] = 1 when all `world` entries arrived in
+// time and the sums are the expected ones — otherwise the communicator keeps ncclAllReduce for its hand-offs.
+__global__ __launch_bounds__(sprs::BLOCK) void mbox_selftest_kernel(const sprs::P2pBox *box, unsigned int tag, unsigned int mb_off,
+                                                                    const unsigned long long *own_entries, unsigned long long timeout,
+                                                                    int *result) {
+    using namespace sprs;
+    Fin f;
+    f.box = box; f.tag = tag; f.mb_off = mb_off;
+    const int world = box->world, rank = box->rank;
+    mbox_post<double, double>(f, (double)(rank + 1), (double)(2 * rank + 1));
+    double a = 0.0, b = 0.0;
+    const bool ok = mbox_sum2<double, double>(MboxSrc{own_entries, world, tag, timeout}, a, b);
+    if (threadIdx.x == 0) result[0] = (ok && a == 0.5 * world * (world + 1) && b == (double)world * world) ? 1 : 0;
+}
+
 template <class T>
 __global__ __launch_bounds__(sprs::BLOCK) void pack_kernel(int64_t n, const int32_t *__restrict__ idx,
                                                            const T *__restrict__ x, T *__restrict__ buf) {
@@ -737,7 +753,27 @@ static int p2p_setup(sprs_comm *c) {
     box.world = c->world; box.rank = c->rank;
     SPRS_HIP_TRY(ctx, hipMalloc((void **)&c->d_box, sizeof(P2pBox)));
     SPRS_HIP_TRY(ctx, hipMemcpyAsync(c->d_box, &box, sizeof(P2pBox), hipMemcpyHostToDevice, ctx->stream));
-    SPRS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // self-test: one real round trip (every rank has mapped every mailbox by now: the vote above was a barrier).  Its granules carry
+    // a tag no solve reaches (2^31 - 1 hand-offs on one slot) in the last slot's second half, so nothing has to be cleaned up.
+    {
+        int *d_res = reinterpret_cast<int *>(reinterpret_cast<char *>(d_cards) + 16);
+        SPRS_HIP_TRY(ctx, hipMemsetAsync(d_res, 0, sizeof(int), ctx->stream));
+        const unsigned int off = (unsigned int)mb_offset(MB_SLOTS - 1, 1);
+        hipLaunchKernelGGL(mbox_selftest_kernel, dim3(1), dim3(BLOCK), 0, ctx->stream, c->d_box, 0x7fffffffu, off,
+                           reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(c->mbox) + off),
+                           (unsigned long long)3000 * 100000ull, d_res);
+        SPRS_HIP_TRY(ctx, hipGetLastError());
+        int res = 0;
+        SPRS_HIP_TRY(ctx, hipMemcpyAsync(&res, d_res, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SPRS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const double failed = res == 1 ? 0.0 : 1.0;
+        SPRS_HIP_TRY(ctx, hipMemcpyAsync(d_vote, &failed, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        SPRS_NCCL_TRY(ctx, rccl().AllReduce(d_vote, d_vote, 1, ncclDouble, ncclSum, (ncclComm_t)c->nccl, ctx->stream));
+        double any = 1.0;
+        SPRS_HIP_TRY(ctx, hipMemcpyAsync(&any, d_vote, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SPRS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (any != 0.0) { p2p_release(c); return SPRS_OK; }      // some rank did not see every post: the hand-offs stay on ncclAllReduce
+    }
     c->p2p = true;
     return SPRS_OK;
 }

@@ -75,29 +75,33 @@ __global__ __launch_bounds__(BLOCK) void spmv_chain_kernel(const int4 *__restric
     const int xcd = blockIdx.x & 7;
     const int sstep = gridDim.x >> 3;
     const int send = xstart[xcd + 1];
-    u4v wreg[NW];
-    [[maybe_unused]] u4v wreg1[NV >= 2 ? NW : 1], wreg2[NV == 3 ? NW : 1];
+    // PF windows are in flight while a tile is folded: the register sets R[0 .. PF).  Two for the plain kernel and K3-in-K4; K1-in-K2
+    // holds three vectors per window and keeps one (a second set would spill).
+    constexpr int PF = FUSE == 3 ? 1 : 2;
+    struct WinRegs { u4v a[NW]; u4v b[NV >= 2 ? NW : 1]; u4v c[NV == 3 ? NW : 1]; };
+    WinRegs R0;
+    [[maybe_unused]] WinRegs R1;
     // raw window of the tile that starts at row tw: [tw - W, tw + CH_ROWS + W).  The margins of a window at either end of x are
     // clamped piece by piece — what they hold is never folded (every column a tile's rows have is inside x)
-    auto issue = [&](int tw) {
+    auto issue = [&](int tw, WinRegs &R) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             int g = tw - W + 2 * (tid + i * BLOCK);
             g = g < 0 ? 0 : (g > xhi ? xhi : g);
-            wreg[i] = *reinterpret_cast<const u4v *>(x + g);             // (non-temporal window loads, allocating result stores: no difference, profiles/r04_tuning.md §3)
-            if constexpr (NV >= 2) wreg1[i] = *reinterpret_cast<const u4v *>(in1 + g);
-            if constexpr (NV == 3) wreg2[i] = *reinterpret_cast<const u4v *>(in2 + g);
+            R.a[i] = *reinterpret_cast<const u4v *>(x + g);              // (non-temporal window loads, allocating result stores: no difference, profiles/r04_tuning.md §3)
+            if constexpr (NV >= 2) R.b[i] = *reinterpret_cast<const u4v *>(in1 + g);
+            if constexpr (NV == 3) R.c[i] = *reinterpret_cast<const u4v *>(in2 + g);
         }
     };
-    auto stage = [&](int slot) {
+    auto stage = [&](int slot, const WinRegs &R) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             if constexpr (FUSE == 0) {
-                *reinterpret_cast<u4v *>(&win[slot][2 * (tid + i * BLOCK)]) = wreg[i];
+                *reinterpret_cast<u4v *>(&win[slot][2 * (tid + i * BLOCK)]) = R.a[i];
             } else {
                 D2 a, b, cc{0.0, 0.0};
-                __builtin_memcpy(&a, &wreg[i], 16); __builtin_memcpy(&b, &wreg1[i], 16);
-                if constexpr (NV == 3) __builtin_memcpy(&cc, &wreg2[i], 16);
+                __builtin_memcpy(&a, &R.a[i], 16); __builtin_memcpy(&b, &R.b[i], 16);
+                if constexpr (NV == 3) __builtin_memcpy(&cc, &R.c[i], 16);
                 const D2 o = FUSE == 2 ? D2{comb_k3(a.lo, b.lo, c0), comb_k3(a.hi, b.hi, c0)}
                                        : D2{comb_k1(a.lo, b.lo, cc.lo, c0, c1), comb_k1(a.hi, b.hi, cc.hi, c0, c1)};
                 *reinterpret_cast<D2 *>(&win[slot][2 * (tid + i * BLOCK)]) = o;
@@ -114,19 +118,21 @@ __global__ __launch_bounds__(BLOCK) void spmv_chain_kernel(const int4 *__restric
         __syncthreads();                                // the previous segment's windows have been read
         int ts_prev = __builtin_amdgcn_readfirstlane(ent.y) - Pf;      // the segment's first tile takes its -Pf operands from the window at ts - Pf
         int sp = 0, sc = 1, sn = 2;                     // slots of the previous / current / next window
-        issue(ts_prev); stage(sp);
-        issue(__builtin_amdgcn_readfirstlane(ent.y)); stage(sc);
-        issue(__builtin_amdgcn_readfirstlane(ent.z));
-        for (int k = 0; k < L; ++k) {
+        issue(ts_prev, R0); stage(sp, R0);
+        issue(__builtin_amdgcn_readfirstlane(ent.y), R0); stage(sc, R0);
+        issue(__builtin_amdgcn_readfirstlane(ent.z), R0);                                        // tile 0's next window
+        if constexpr (PF == 2) { if (L > 1) issue(tiles[t0 + 1].z, R1); }                       // tile 1's next window
+        // one tile: stage its next window from RS (issued PF tiles ago), then refill RS with the next window of tile k + PF
+        auto body = [&](int k, WinRegs &RS) {
             const int ts = __builtin_amdgcn_readfirstlane(ent.y), ts_next = __builtin_amdgcn_readfirstlane(ent.z);
             uint32_t rbc[NQ]; int nnc[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) { rbc[q] = rbw[q]; nnc[q] = nnw[q]; }
-            stage(sn);                                  // the next tile's window (its loads flew over the previous fold)
+            stage(sn, RS);                              // the next tile's window (its loads flew over the previous folds)
             __syncthreads();
+            if (k + PF < L) issue(tiles[t0 + k + PF].z, RS);
             if (k + 1 < L) {
                 ent = tiles[t0 + k + 1];
-                issue(__builtin_amdgcn_readfirstlane(ent.z));           // the window after next
                 const int b1 = __builtin_amdgcn_readfirstlane(ent.x);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) { const BlkDesc d = desc[b1 + q * NWAVE + wv]; rbw[q] = (uint32_t)d.rb; nnw[q] = d.nn; }
@@ -230,6 +236,11 @@ __global__ __launch_bounds__(BLOCK) void spmv_chain_kernel(const int4 *__restric
             __syncthreads();                            // the previous window's slot is free for the window after next
             ts_prev = ts;
             const int o = sp; sp = sc; sc = sn; sn = o;
+        };
+        if constexpr (PF == 2) {
+            for (int k = 0; k < L; k += 2) { body(k, R0); if (k + 1 < L) body(k + 1, R1); }
+        } else {
+            for (int k = 0; k < L; ++k) body(k, R0);
         }
     }
     if (n_left > 0) {
