@@ -712,6 +712,11 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
             if (H.status == ST_RESTART) {                                   // :131-145, executed at iteration H.its
                 // K2 / K4 of the iterations enqueued from the requesting one on returned at their first instruction
                 this->profile_discard_last(2 * (its - (size_t)H.its));
+                if (fuse && ((its - (size_t)H.its) & 1)) {
+                    // ... but the host rotated the buffers once for each of them as it enqueued: an odd number of idle iterations
+                    // leaves every pair of names exchanged against what the last EXECUTED launches wrote
+                    std::swap(p, palt); y = p; std::swap(v, t); std::swap(r, ralt);
+                }
                 SPRS_TRY(this->spmv(x, r, 0, nullptr, nullptr, nullptr, nullptr));  // :134
                 SPRS_TRY((launch_axpy<T, T>(c, n, sneg(sone<T>()), rhs, r)));       // :137
                 SPRS_TRY(dcopy(c, r0, r, n));                                       // :140
