@@ -843,6 +843,52 @@ def test_fused_spmv_input_is_bit_identical(sa, oracle, name):
         ctx.set("spmv_chain", -1); ctx.set("spmv_tile", -1); ctx.set("spmv_fuse", -1); ctx.set("poll", 16)
 
 
+def test_fused_spmv_input_randomised(sa, oracle):
+    """The three-launch iteration against the five-launch one on random chain-capable grids (line lengths with seams in different
+    positions, plane sizes that drift against the 128-row block grid by different amounts), random right-hand sides, initial
+    guesses, iteration limits, tolerances and poll intervals: outcome, iteration count, residual and x bit for bit; the solution
+    against the oracle's where the solve converges."""
+    from sprsolve_amd import gen
+    ctx = sa.default_ctx(0)
+    rng = np.random.default_rng(2024)
+    try:
+        ctx.set("spmv_chain", 1); ctx.set("spmv_tile", 1)
+        for case in range(10):
+            nx = int(rng.integers(75, 126)) * 2; ny = int(rng.integers(60, 91)); nz = int(rng.integers(18, 27))
+            ip, ix, d, rhs1 = gen.poisson3d(nx, ny, nz)
+            n = rhs1.size
+            A = sa.HipCsr.new((n, n), ip, ix, d)
+            assert A.chain_plan()[0] >= 64, (nx, ny, nz, A.chain_plan())
+            rhs = rhs1 if case % 3 == 0 else rng.uniform(-1, 1, n)
+            x0 = rng.uniform(-1, 1, n) if case % 4 == 1 else np.zeros(n)
+            max_iter = int(rng.choice([1, 2, 3, 17, 64, 400, 900]))
+            tol = float(rng.choice([0.0, 1e-3, 1e-10]))
+            poll = int(rng.integers(1, 17))
+            ctx.set("poll", poll)
+            got = []
+            for fuse in (1, 0):
+                ctx.set("spmv_fuse", fuse)
+                s = sa.BiCGStab.new(A, n); s.set_profile(True)
+                x = x0.copy()
+                try:
+                    its, rr = s.solve(rhs, x, max_iter, tol); st = "ok"
+                except sa.error.InsufficientIterNum as e:
+                    its, rr, st = e.iters, None, "insufficient"
+                except sa.error.BreakDown as e:
+                    its, rr, st = e.its, None, "breakdown"
+                got.append((st, its, rr, bits(x).copy(), s.profile()["fused_k4"]))
+            a, b = got
+            assert a[:3] == b[:3], (case, nx, ny, nz, max_iter, tol, poll, a[:3], b[:3])
+            assert np.array_equal(a[3], b[3]), (case, nx, ny, nz, max_iter, tol, poll)
+            assert a[4] >= 1 and b[4] == 0
+            if a[0] == "ok" and tol == 1e-10:
+                ref = oracle.bicgstab(ip, ix, d, rhs, x0, max_iter, tol)
+                assert ref.status == oracle.OK
+                assert np.max(np.abs(a[3].view(np.float64) - ref.x)) <= 1e-7 * max(1.0, float(np.max(np.abs(ref.x))))
+    finally:
+        ctx.set("spmv_chain", -1); ctx.set("spmv_tile", -1); ctx.set("spmv_fuse", -1); ctx.set("poll", 16)
+
+
 def test_plane_streaming_chains_policy(sa, oracle):
     """Automatic policy: chains only where they fill the chip (about one segment of >= 6 tiles per workgroup) — a 6 M-row
     500 x 200 x 60 grid (46 MiB vectors: tiles wanted, 48 chains cut into 7 segments each) qualifies; small grids keep the tile
