@@ -175,8 +175,8 @@ def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8, dot_launches=0, fused=(0, 
     """The roofline object of one measured SpMV kernel: fraction of the HBM peak on the bytes it READS AND WRITES.
     dot_launches: how many of the `launches` read a dot operand that is not their input vector (n*s bytes each).
     fused = (K2 launches, K4 launches) that formed their input on the fly (csrc/krylov.hip "fused SpMV input"): such a K4 also reads v
-    and writes s (2 more vectors), such a K2 also reads p and r and writes p' (3 more) — the passes of the K3 / K1 launches they replace."""
-    extra_vec = 3 * fused[0] + 2 * fused[1]
+    (1 more vector; it does not store s — K5 forms it again), such a K2 also reads p and r and writes p' (3 more)."""
+    extra_vec = 3 * fused[0] + 1 * fused[1]
     moved = sinfo["bytes_moved_per_launch"] + (n * s * (dot_launches + extra_vec) / launches if launches else 0.0)
     r = dict(bound="hbm", kernel=KERNEL_NAMES[sinfo.get("kernel_id", sinfo["mode"])], achieved=moved / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
              frac=moved / t_spmv / 1e9 / HBM_PEAK_GBS, traffic=None, stream=sinfo["stream"], bytes_per_nnz=sinfo["bytes_per_nnz"],
@@ -191,7 +191,7 @@ def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8, dot_launches=0, fused=(0, 
     if extra_vec:
         r["fused_launches"] = dict(k2_with_k1=fused[0], k4_with_k3=fused[1],
                                    note="these launches also form the vector update that produces their input (K1 / K3 of the five-launch iteration: "
-                                        "3 / 2 more vector passes each, counted in the bytes above); avg_launch_us is the mean over ALL timed SpMV launches")
+                                        "3 / 1 more vector passes each, counted in the bytes above); avg_launch_us is the mean over ALL timed SpMV launches")
     if sinfo["mode"] != 0:
         r["frac_format_bytes_note"] = "the format's size / time: counts code bytes and row_ptr the kernel does not read; NOT the roofline fraction"
         r["csr_equivalent_GBs"] = spmv_bytes(n, nnz, s) / t_spmv / 1e9

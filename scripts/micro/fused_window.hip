@@ -331,7 +331,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(long r_begin, long n, int nx, l
                 o.hi = fold7(c, fm.hi, a.hi, cc.lo, cc.hi, xr, b.hi, fp.hi);
                 const long r0 = ts + ((q * 4 + wv) << 7) + 2 * lane;
                 stnt2(y + r0, o);
-                if (NV >= 2) stnt2(own + r0, cc);
+                if (NV >= 2 && own != nullptr) stnt2(own + r0, cc);
                 if (DOT == 1) { d0 = d0 + uu[q].lo * o.lo; d0 = d0 + uu[q].hi * o.hi; }
                 if (DOT == 2) { d0 = d0 + o.lo * o.lo; d1 = d1 + o.lo * cc.lo; d0 = d0 + o.hi * o.hi; d1 = d1 + o.hi * cc.hi; }
             }
@@ -340,6 +340,44 @@ __global__ __launch_bounds__(BLOCK) void k_chain(long r_begin, long n, int nx, l
     }
     for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o, 64); d1 += __shfl_xor(d1, o, 64); }
     if (lane == 0) { part[blockIdx.x * 4 + wv] = d0; part[4096 + blockIdx.x * 4 + wv] = d1; }
+}
+
+// ---- the consumer that follows K4 in the iteration: fused_kernel<BicgK5> — x += y na + s nw ; r = s + t nw ; partials of |r|^2, r0.r
+// (5 reads + 2 writes, non-temporal, grid-stride).  REV: the same pass from the last element to the first.
+template <bool REV, bool NTL>
+__global__ __launch_bounds__(BLOCK) void k5_like(long n, double na, double nw, const double *__restrict__ yv, const double *__restrict__ tv,
+                                                 const double *__restrict__ r0v, double *xv, double *sv, double *__restrict__ part) {
+    const long n2 = n >> 1;
+    double d0 = 0.0, d1 = 0.0;
+    for (long g0 = blockIdx.x * (long)BLOCK + threadIdx.x; g0 < n2; g0 += (long)gridDim.x * BLOCK) {
+        const long g = REV ? n2 - 1 - g0 : g0;
+        D2 x2 = NTL ? ldnt2(xv + 2 * g) : ldg2(xv + 2 * g), y2 = NTL ? ldnt2(yv + 2 * g) : ldg2(yv + 2 * g), s2 = NTL ? ldnt2(sv + 2 * g) : ldg2(sv + 2 * g);
+        const D2 t2 = NTL ? ldnt2(tv + 2 * g) : ldg2(tv + 2 * g), q2 = NTL ? ldnt2(r0v + 2 * g) : ldg2(r0v + 2 * g);
+        x2.lo = (x2.lo + y2.lo * na) + s2.lo * nw; x2.hi = (x2.hi + y2.hi * na) + s2.hi * nw;
+        s2.lo = s2.lo + t2.lo * nw; s2.hi = s2.hi + t2.hi * nw;
+        d0 = d0 + s2.lo * s2.lo; d0 = d0 + s2.hi * s2.hi; d1 = d1 + q2.lo * s2.lo; d1 = d1 + q2.hi * s2.hi;
+        stnt2(xv + 2 * g, x2); stnt2(sv + 2 * g, s2);
+    }
+    for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o, 64); d1 += __shfl_xor(d1, o, 64); }
+    if ((threadIdx.x & 63) == 0) { part[8192 + blockIdx.x * 4 + (threadIdx.x >> 6)] = d0; part[12288 + blockIdx.x * 4 + (threadIdx.x >> 6)] = d1; }
+}
+
+// the same consumer when the fused K4 does NOT store s: s = r + v na is formed again here (6 reads + 2 writes; r' in place of r)
+__global__ __launch_bounds__(BLOCK) void k5_like6(long n, double na, double nal, double nw, const double *__restrict__ yv, const double *__restrict__ tv,
+                                                  const double *__restrict__ r0v, const double *__restrict__ vv, double *xv, double *rv, double *__restrict__ part) {
+    const long n2 = n >> 1;
+    double d0 = 0.0, d1 = 0.0;
+    for (long g = blockIdx.x * (long)BLOCK + threadIdx.x; g < n2; g += (long)gridDim.x * BLOCK) {
+        D2 x2 = ldnt2(xv + 2 * g), y2 = ldnt2(yv + 2 * g), r2 = ldnt2(rv + 2 * g);
+        const D2 v2 = ldnt2(vv + 2 * g), t2 = ldnt2(tv + 2 * g), q2 = ldnt2(r0v + 2 * g);
+        D2 s2{r2.lo + v2.lo * nal, r2.hi + v2.hi * nal};
+        x2.lo = (x2.lo + y2.lo * na) + s2.lo * nw; x2.hi = (x2.hi + y2.hi * na) + s2.hi * nw;
+        s2.lo = s2.lo + t2.lo * nw; s2.hi = s2.hi + t2.hi * nw;
+        d0 = d0 + s2.lo * s2.lo; d0 = d0 + s2.hi * s2.hi; d1 = d1 + q2.lo * s2.lo; d1 = d1 + q2.hi * s2.hi;
+        stnt2(xv + 2 * g, x2); stnt2(rv + 2 * g, s2);
+    }
+    for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o, 64); d1 += __shfl_xor(d1, o, 64); }
+    if ((threadIdx.x & 63) == 0) { part[8192 + blockIdx.x * 4 + (threadIdx.x >> 6)] = d0; part[12288 + blockIdx.x * 4 + (threadIdx.x >> 6)] = d1; }
 }
 
 int main(int argc, char **argv) {
@@ -478,6 +516,49 @@ int main(int argc, char **argv) {
     CH(2048, 3, 1, 25, 1024, "K1+K2 fused chain", true, r, v, p, ca, cb, r0v)
     CH(1024, 3, 1, 25, 1024, "K1+K2 fused chain", true, r, v, p, ca, cb, r0v)
     CH(1024, 3, 1, 50, 1024, "K1+K2 fused chain", true, r, v, p, ca, cb, r0v)
+    // ================= what the consumer K5 pays behind each producer (time of the K5-like pass alone, producer launched right before it)
+    if (filt.empty() || filt.find("k5") != std::string::npos) {
+        double *xx; CK(hipMalloc(&xx, n * 8)); fill_vec<<<2048, 256>>>(n, xx, 41);
+        auto after = [&](const std::string &name, std::function<void()> producer, std::function<void()> consumer) {
+            for (int i = 0; i < 2; ++i) { producer(); consumer(); }
+            double tot = 0; float ms = 0;
+            for (int i = 0; i < reps; ++i) {
+                producer();
+                CK(hipEventRecord(e0)); consumer(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms * 1e3;
+            }
+            printf("%-64s %8.1f us\n", name.c_str(), tot / reps); fflush(stdout);
+        };
+        auto k5f = [&] { k5_like<false, true><<<512, 256>>>(n, -0.3, -0.2, p, y, r0v, xx, s_out, part); };
+        auto k5r = [&] { k5_like<true, true><<<512, 256>>>(n, -0.3, -0.2, p, y, r0v, xx, s_out, part); };
+        auto k5fa = [&] { k5_like<false, false><<<512, 256>>>(n, -0.3, -0.2, p, y, r0v, xx, s_out, part); };
+        auto k5ra = [&] { k5_like<true, false><<<512, 256>>>(n, -0.3, -0.2, p, y, r0v, xx, s_out, part); };
+        auto prod_unf = [&] { upd2<<<512, 256>>>(n, na, v, r, s_out); k_chain<2048, W, 1, 2><<<512, 256>>>(r_begin, n, nx, P, (int)(P / 2048), nz - 2, 50, c, 0.0, 0.0, s_out, nullptr, nullptr, s_out, y, nullptr, part); };
+        auto prod_fus = [&] { k_chain<2048, W, 2, 2><<<512, 256>>>(r_begin, n, nx, P, (int)(P / 2048), nz - 2, 50, c, na, 0.0, r, v, nullptr, s_out, y, nullptr, part); };
+        auto prod_str = [&] { upd3<<<512, 256>>>(n, 0.5, 0.25, junk_a, junk_b, junk_a, junk_a); };
+        auto prod_fus_nos = [&] { k_chain<2048, W, 2, 2><<<512, 256>>>(r_begin, n, nx, P, (int)(P / 2048), nz - 2, 50, c, na, 0.0, r, v, nullptr, nullptr, y, nullptr, part); };
+        auto k6 = [&] { k5_like6<<<512, 256>>>(n, -0.3, na, -0.2, p, y, r0v, v, xx, r, part); };
+        {   // the producers alone, for the sums
+            auto tm = [&](const char *nm, std::function<void()> f) {
+                for (int i = 0; i < 3; ++i) f();
+                CK(hipEventRecord(e0)); for (int i = 0; i < reps; ++i) f(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); printf("%-64s %8.1f us (back to back)\n", nm, ms * 1e3 / reps);
+            };
+            tm("producer: update + chain SpMV (five-launch flow)", prod_unf);
+            tm("producer: fused chain SpMV storing s", prod_fus);
+            tm("producer: fused chain SpMV NOT storing s", prod_fus_nos);
+        }
+        after("k5 6R+2W (s formed again from r, v) | cold", prod_str, k6);
+        after("k5 6R+2W (s formed again from r, v) | behind the fused chain SpMV NOT storing s", prod_fus_nos, k6);
+        after("k5 forward, nt loads | behind a streaming pass (cold)", prod_str, k5f);
+        after("k5 forward, nt loads | behind update + chain SpMV reading s (five-launch flow)", prod_unf, k5f);
+        after("k5 forward, nt loads | behind the fused chain SpMV writing s (three-launch flow)", prod_fus, k5f);
+        after("k5 REVERSE, nt loads | behind update + chain SpMV reading s", prod_unf, k5r);
+        after("k5 REVERSE, nt loads | behind the fused chain SpMV writing s", prod_fus, k5r);
+        after("k5 forward, plain loads | behind update + chain SpMV reading s", prod_unf, k5fa);
+        after("k5 forward, plain loads | behind the fused chain SpMV writing s", prod_fus, k5fa);
+        after("k5 REVERSE, plain loads | behind the fused chain SpMV writing s", prod_fus, k5ra);
+    }
     CK(hipDeviceSynchronize());
     return 0;
 }

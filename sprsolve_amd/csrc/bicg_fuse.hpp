@@ -127,8 +127,8 @@ struct BicgK3 {
 };
 
 // ---- spmv_chain.hip: the chain SpMV with the preceding vector update formed on the fly (f64, no preconditioner, single GPU)
-// K3 into K4 (bicg_stab.rs:163-178):  alpha from partB (pro's prologue) ; s = r + v * (-alpha) -> s_out (for the rows the launch
-//   owns: all of them) ; t = A s ; partials of t.t and t.s
+// K3 into K4 (bicg_stab.rs:163-178):  alpha from partB (pro's prologue) ; s = r + v * (-alpha), formed on the fly and — s_out ==
+//   nullptr — not stored (the pair2 walk of the blocks outside the chains honours a non-null s_out) ; t = A s ; partials of t.t and t.s
 int launch_chain_k4f(const sprs_csr *A, int g, const BicgK3<double, double, false> &pro, const double *r, const double *v, double *s_out,
                      double *t, double *partTT, double *partTR, const int *status);
 // K1 into K2 (bicg_stab.rs:123-163):  norm / convergence / restart / beta (pro's prologue) ; p' = (v * (-beta w) + p * beta) + r -> p_out ;

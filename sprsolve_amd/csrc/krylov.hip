@@ -73,7 +73,11 @@ static int launch_fused(sprs_ctx *c, size_t n, int grid, int chunked_walk, F f) 
 
 // K5  bicg_stab.rs:178-196:  w = (t.t > 0) ? t.r / t.t : 0 ; x -= alpha*y ; x -= w*s ; r -= w*t
 //     + partials of norm2(r)^2 and r0.r for the next iteration's K1 (:123,:128)
-template <class T, bool PC>
+// SV (fused SpMV input, below): K4 formed s = r + v (-alpha) on the fly and did NOT store it — a store of s costs the fused K4
+// 80 of its 294 us (scripts/micro/fused_window.hip, profiles/r04_tuning.md §3) — so s is formed again here from r and v with the
+// same expression (K3's, bicg_stab.rs:172): one more read, which finds r and v in the Infinity Cache behind K4's reads; r' = s - w t
+// is written over r.
+template <class T, bool PC, bool SV = false>
 struct BicgK5 {
     BicgState<T> *S; const T *partTT; const T *partTR; int P;
     const T *y; const T *z; const T *t; const T *r0; T *x; T *r; Real<T> *partN; T *partRho;
@@ -81,6 +85,7 @@ struct BicgK5 {
     T na, nw, w;
     Real<T> accN; T accR;
     unsigned int tag = 0; unsigned long long mb_timeout = 0;     // peer-to-peer hand-off (see BicgK1): partTT = this rank's mailbox entries
+    const T *sv = nullptr;                                       // SV: the v of s = r + v (-alpha)
     __device__ __forceinline__ bool prologue() {
         __shared__ T smT[NWAVE];
         __shared__ T smT2[NWAVE];
@@ -107,6 +112,11 @@ struct BicgK5 {
         auto tv = ldp<T, PK, NT>(t, i); auto qv = ldp<T, PK, NT>(r0, i);
         [[maybe_unused]] Pack<T, PK> zv;
         if (PC) zv = ldp<T, PK, NT>(z, i);
+        if constexpr (SV) {
+            const auto vv = ldp<T, PK, NT>(sv, i);
+#pragma unroll
+            for (int e = 0; e < PK; ++e) rv.v[e] = sadd(rv.v[e], smul(vv.v[e], na));    // :172  s = r - alpha v (K3's expression)
+        }
 #pragma unroll
         for (int e = 0; e < PK; ++e) {
             T xx = sadd(xv.v[e], smul(yv.v[e], na));                // :188
@@ -578,14 +588,16 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
     // whose results are SpMV inputs are formed INSIDE those SpMVs (spmv_chain.hip, FUSE) — K3 (r -= alpha v, :172) in K4, K1
     // (p = (v (-beta w) + p beta) + r, :155-156) in K2 — with K3's / K1's own prologues (bicg_fuse.hpp) and rounding sequence, so
     // every scalar, every element and every dot partial is bit-identical to the five-launch iteration; an iteration is three
-    // launches and two passes over a vector shorter.  A tile reads its operands' windows while other tiles are still reading them, so
-    // a fused launch writes the updated vector to ANOTHER buffer: r and p alternate with the two work vectors the unpreconditioned
-    // solve leaves unused (:28 allocates seven), v and t swap roles every iteration (t is dead when K2 writes v', v when K4 writes t).
+    // launches.  K4 does not even store s: K5 forms it again from r and v (BicgK5<SV>) and writes r' = s - w t over r.  A tile reads
+    // its operands' windows while other tiles are still reading them, so K2 writes p' to ANOTHER buffer: p alternates with a work
+    // vector the unpreconditioned solve leaves unused (:28 allocates seven), and v and t swap roles every iteration (t is dead when K2
+    // writes v', v when K4 writes t).
     bool fuse = false;
     if constexpr (std::is_same<T, double>::value && std::is_same<V, double>::value)
         fuse = !pc && !this->A->dist && c->spmv_fuse != 0 && chain_plan_used(this->A);
-    T *ralt = fuse ? this->vec(5) : nullptr, *palt = fuse ? this->vec(6) : nullptr;
+    T *palt = fuse ? this->vec(5) : nullptr;
     int pend_k1 = -1, pend_k3 = -1;          // fused: the mode / breakdown flag of the update that the next SpMV forms
+    bool s_pending = false;                  // fused: K4 formed s without storing it (K5 forms it again)
 
     SPRS_TRY(this->spmv(x, r, 0, nullptr, nullptr, nullptr, nullptr));      // :73
     SPRS_TRY((launch_axpy<T, T>(c, n, sneg(sone<T>()), rhs, r)));           // :75
@@ -643,9 +655,9 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
             if (fuse && pend_k3 >= 0) {
                 const BicgK3<double, double, false> k3{d_state, qB.p, qB.P, pend_k3, v, r, nullptr, nullptr, 0.0};
                 pend_k3 = -1;
-                SPRS_TRY(this->profiled([&]() -> int { return launch_chain_k4f(this->A, GS, k3, r, v, ralt, t, partTT, partTR, d_status); }, true));
+                SPRS_TRY(this->profiled([&]() -> int { return launch_chain_k4f(this->A, GS, k3, r, v, nullptr, t, partTT, partTR, d_status); }, true));
                 this->stats.fused_k4 += 1;
-                std::swap(r, ralt);          // r now names s
+                s_pending = true;            // s was formed on the fly and not stored: K5 forms it again from r and v
                 return this->red2(partTT, partTR, GS, 1, &qTT, &qTR);
             }
         }
@@ -654,6 +666,11 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
     };
     auto K5 = [&]() -> int {
         const Fin f = this->fin_for(3, partN, partRho, G);
+        if (s_pending) {
+            s_pending = false;
+            SPRS_TRY(launch_fused<T>(c, n, G, cw, BicgK5<T, false, true>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, f, T(), T(), T(), 0.0, T(), qTT.tag, this->mb_timeout(), v}));
+            return this->redDT(partN, partRho, G, 3, &qN, &qRho);
+        }
         if (pc) SPRS_TRY(launch_fused<T>(c, n, G, cw, BicgK5<T, true>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, f, T(), T(), T(), 0.0, T(), qTT.tag, this->mb_timeout()}));
         else SPRS_TRY(launch_fused<T>(c, n, G, cw, BicgK5<T, false>{d_state, qTT.p, qTR.p, qTT.P, y, z, t, r0, x, r, partN, partRho, f, T(), T(), T(), 0.0, T(), qTT.tag, this->mb_timeout()}));
         return this->redDT(partN, partRho, G, 3, &qN, &qRho);
@@ -715,7 +732,7 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
                 if (fuse && ((its - (size_t)H.its) & 1)) {
                     // ... but the host rotated the buffers once for each of them as it enqueued: an odd number of idle iterations
                     // leaves every pair of names exchanged against what the last EXECUTED launches wrote
-                    std::swap(p, palt); y = p; std::swap(v, t); std::swap(r, ralt);
+                    std::swap(p, palt); y = p; std::swap(v, t);
                 }
                 SPRS_TRY(this->spmv(x, r, 0, nullptr, nullptr, nullptr, nullptr));  // :134
                 SPRS_TRY((launch_axpy<T, T>(c, n, sneg(sone<T>()), rhs, r)));       // :137

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_chain_kernel(const int4 *__restric
                 u4v qv;
                 __builtin_memcpy(&qv, &yy, 16);
                 __builtin_nontemporal_store(qv, reinterpret_cast<u4v *>(y + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));
-                if constexpr (FUSE != 0) {
+                if constexpr (FUSE == 3) {          // (K3 in K4 stores nothing: K5 forms s again, krylov.hip BicgK5<SV>)
                     u4v ov;
                     __builtin_memcpy(&ov, &mine, 16);
                     __builtin_nontemporal_store(ov, reinterpret_cast<u4v *>(own + (ts + ((q * NWAVE + wv) << 7) + 2 * lane)));

@@ -419,7 +419,7 @@ struct Blk2Loads {
 // zero-initialised code slices.
 // YNT: y is written with non-temporal stores (HBM-sized vectors: the result is not read again before it has been evicted)
 // XS: where x comes from (XPlain: memory; XFused: formed on the fly).  With XFused the walk also STORES the formed vector for the
-// rows it owns (`own`), and where `u` is null the dot operand is that vector (K4's t.s).
+// rows it owns (`own`, unless null), and where `u` is null the dot operand is that vector (K4's t.s).
 template <int DOT, bool YNT, class XS = XPlain>
 __device__ __forceinline__ void pair2_walk(int n_wide, int xcd_chunk, const BlkDesc *__restrict__ desc,
                                            const int32_t *__restrict__ order, const int32_t *__restrict__ row_ptr,
@@ -642,9 +642,9 @@ __device__ __forceinline__ void pair2_walk(int n_wide, int xcd_chunk, const BlkD
             }
             if (DOT == 1) { d0 = d0 + c_u0 * acc0; d0 = d0 + c_u1 * acc1; }
             if (DOT == 2) { d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * c_u0; d0 = d0 + acc1 * acc1; d1 = d1 + acc1 * c_u1; }
-            if constexpr (XS::FUSED) *reinterpret_cast<D2 *>(reinterpret_cast<char *>(own) + r8) = D2{c_o0, c_o1};
+            if constexpr (XS::FUSED) { if (own != nullptr) *reinterpret_cast<D2 *>(reinterpret_cast<char *>(own) + r8) = D2{c_o0, c_o1}; }
         } else if (r0 < c_rb) {
-            if constexpr (XS::FUSED) *reinterpret_cast<T *>(reinterpret_cast<char *>(own) + r8) = c_o0;
+            if constexpr (XS::FUSED) { if (own != nullptr) *reinterpret_cast<T *>(reinterpret_cast<char *>(own) + r8) = c_o0; }
             *reinterpret_cast<T *>(reinterpret_cast<char *>(y) + r8) = acc0;
             if (DOT == 1) d0 = d0 + c_u0 * acc0;
             if (DOT == 2) { d0 = d0 + acc0 * acc0; d1 = d1 + acc0 * c_u0; }
