@@ -62,6 +62,8 @@ KERNEL_NAMES = {0: "spmv_kernel<double> (plain CSR stream, wavefront-private LDS
                 5: "spmv_chain_kernel<DOT> (pair codes; plane-streaming chains: a workgroup walks a column of 2048-row tiles plane by plane with the "
                    "x windows of three consecutive tiles in LDS — the +-plane operands come from the neighbouring tiles' windows, no far load; "
                    "the other 128-row blocks by the per-block walk of the same launch; csrc/spmv_chain.hip)",
+                6: "spmv_dict_kernel<cplx, PAIR=true> (complex scalars: one-byte (offset, value) pair codes of the off-diagonal entries + one row "
+                   "value (the diagonal) per row; csrc/spmv_dict.hip)",
                 3: "spmv_tile_kernel<DOT> (pair codes; runs of 4096 rows of one stencil pattern multiplied from an x window staged in "
                    "LDS + per-row-pair far loads, tiles dealt to the XCDs by the far period; the other 128-row blocks by the "
                    "per-block walk of the same launch; csrc/spmv_dict.hip)"}
@@ -159,9 +161,16 @@ def stream_info(A, n, nnz, s):
         # per cent) are counted as if none of them did either — fewer bytes, i.e. the fraction errs on the low side
         nu = nb
         moved = int(nnz * (per_nnz - code_b) + 2 * n * s)
+    cpair = mode == 2 and A.dtype.kind == "c"
+    if cpair:
+        # complex pair codes: one byte per entry + the row-value slot (one scalar per row: the diagonal; csrc/spmv_dict.hip cpair
+        # stage); the lane-per-row walk reads row_ptr and every code byte
+        moved = int(nnz * 1 + (n + 1) * 4 + n * s + 2 * n * s)
     out = dict(stream=STREAM_NAMES[mode], mode=mode, distinct_offsets=n_off, distinct_pairs=n_pair,
-               bytes_per_nnz=per_nnz, format_bytes_per_launch=nnz * per_nnz + (n + 1) * 4 + 2 * n * s,
+               bytes_per_nnz=per_nnz, format_bytes_per_launch=nnz * per_nnz + (n + 1) * 4 + 2 * n * s + (n * s if cpair else 0),
                row_blocks=nb, descriptor_only_blocks=nu, bytes_moved_per_launch=moved)
+    if cpair:
+        out.update(kernel_id=6)
     if tiles[0] > 0:        # same bytes: a tile reads x once per window instead of once per column, all of it on chip
         out.update(kernel_id=3 if mode == 2 else 4, lds_window_tiles=tiles[0], blocks_in_tiles=tiles[1], blocks_walked_singly=tiles[2])
     chain = A.chain_plan() if hasattr(A, "chain_plan") else (0, 0, 0, 0)

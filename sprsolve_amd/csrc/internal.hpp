@@ -220,6 +220,7 @@ struct sprs_dict {
     int32_t *off_tab = nullptr;    // device, 256 entries: col - row per offset code
     int32_t *pair_off = nullptr;   // device, 256 entries: col - row per pair code
     void *pair_val = nullptr;      // device, 256 entries of T: value per pair code
+    void *rowval = nullptr;        // device, nrows of T (complex scalars only): the value of each row's offset-0 entry — pair code 255 means "this row's value" (spmv_dict.hip, cpair stage)
     int n_off = 0, n_val = 0, n_pair = 0;
     void *wide_desc = nullptr;     // device: descriptors of the 128-row blocks of the two-rows-per-lane kernel (f64 pair codes)
     int n_wide = 0;

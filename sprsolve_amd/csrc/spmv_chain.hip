@@ -60,7 +60,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_chain_kernel(const int4 *__restric
     const int run_state = status != nullptr ? *status : (int)ST_RUNNING;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    s_pair[tid] = PairEnt<T>{off_tab[tid] * 8, val_tab[tid]};                  // BLOCK == TAB (the seam rows' own values; the walk below)
+    stage_pair(s_pair, tid, off_tab[tid] * 8, val_tab[tid]);                  // BLOCK == TAB (the seam rows' own values; the walk below)
     __syncthreads();
     if (run_state != ST_RUNNING) { fin_idle(fin, DOT == 2); return; }
     [[maybe_unused]] T c0 = 0.0, c1 = 0.0;              // coefficients of the fused update

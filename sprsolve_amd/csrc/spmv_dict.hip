@@ -248,6 +248,114 @@ __global__ __launch_bounds__(BLOCK) void dict_pair_encode_kernel(int64_t nnz, co
         pair_code[k] = pair_of[idx_code[k] | (val_code[k] << 8)];
 }
 
+// ---- complex scalars: pair codes with a ROW-VALUE slot (round 4) -------------------------------------------------------------
+// The value dictionaries above key a value by its 64-bit pattern: real scalars only.  Complex operators on grids — the
+// reference's own complex tests (tests/test_complex_solve.rs:95-151, test_complex_solve2.rs:35-96): constant off-diagonals, a
+// diagonal that differs from row to row; any shifted Laplacian / Helmholtz-like operator — repeat their OFF-DIAGONAL entries
+// only.  So: the distinct (offset code, value) pairs of all entries but those at offset 0 are collected (<= 255 of them, matched
+// by bit pattern), an offset-0 entry gets the reserved code 255 = "this row's own value", and those values are kept densely, one
+// per row (`rowval`).  The SpMV then reads 1 B per entry + 16 B per row instead of 20 B per entry; the products and their order
+// are the original ones: y bit-identical.  The collection needs no key wider than the machine's atomics: a slot of the table
+// holds the INDEX of the first entry that claimed it, and candidates are compared with that entry's offset code and value bits.
+constexpr int CP_SLOTS = 1024;
+constexpr int CP_DIAG = 255;
+template <class T> __device__ __forceinline__ bool same_bits(const T &a, const T &b) {
+    static_assert(sizeof(T) % 8 == 0, "complex scalars: one or two 64-bit words");
+    uint64_t wa[sizeof(T) / 8], wb[sizeof(T) / 8];
+    __builtin_memcpy(wa, &a, sizeof(T)); __builtin_memcpy(wb, &b, sizeof(T));
+    bool eq = true;
+    for (size_t i = 0; i < sizeof(T) / 8; ++i) eq = eq && wa[i] == wb[i];
+    return eq;
+}
+template <class T> __device__ __forceinline__ uint32_t cp_hash(int oc, const T &v) {
+    uint64_t w[sizeof(T) / 8 ? sizeof(T) / 8 : 1] = {0};
+    __builtin_memcpy(w, &v, sizeof(T));
+    uint64_t h = (uint64_t)(oc + 1) * 0x9E3779B97F4A7C15ull;
+    for (size_t i = 0; i < sizeof(w) / 8; ++i) h = (h ^ w[i]) * 0xff51afd7ed558ccdull;
+    return (uint32_t)(h ^ (h >> 29));
+}
+// count[0] = pairs claimed; a thread abandons the pass when it is about to claim one beyond CP_DIAG.  Loads of the same few table
+// words from every thread of the chip serialise in L2 (3.4 ms on cfg 4), so every workgroup keeps an LDS mirror of the slots it has
+// seen filled (a filled slot never changes) and ONE thread seeds it from the workgroup's first row before the others start: the
+// steady state of a stencil — every entry already known — then costs LDS reads and L1 hits only.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void cpair_collect_kernel(int n, const int32_t *__restrict__ row_ptr, const uint8_t *__restrict__ idx_code,
+                                                              const T *__restrict__ val, int diag_code, int32_t *tab, int *count) {
+    __shared__ int32_t s_tab[CP_SLOTS];
+    for (int i = threadIdx.x; i < CP_SLOTS; i += BLOCK) s_tab[i] = -1;
+    __syncthreads();
+    auto visit = [&](int row) -> bool {                     // false: more than CP_DIAG pairs, give up
+        for (int k = row_ptr[row], ke = row_ptr[row + 1]; k < ke; ++k) {
+            const int oc = idx_code[k];
+            if (oc == diag_code) continue;
+            const T v = val[k];
+            uint32_t h = cp_hash(oc, v) & (CP_SLOTS - 1);
+            for (int t = 0; t < CP_SLOTS; ++t, h = (h + 1) & (CP_SLOTS - 1)) {
+                int cur = s_tab[h];
+                if (cur < 0) {
+                    cur = __hip_atomic_load(tab + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cur < 0) {
+                        if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > CP_DIAG) return false;
+                        const int old = atomicCAS(tab + h, -1, k);
+                        if (old < 0) { atomicAdd(count, 1); s_tab[h] = k; break; }
+                        cur = old;
+                    }
+                    s_tab[h] = cur;        // (racing writers store the same index)
+                }
+                if (idx_code[cur] == oc && same_bits(val[cur], v)) break;
+            }
+        }
+        return true;
+    };
+    const int row0 = blockIdx.x * BLOCK;
+    if (threadIdx.x == 0 && row0 + BLOCK / 2 < n) (void)visit(row0 + BLOCK / 2);
+    __syncthreads();
+    for (int row = row0 + threadIdx.x; row < n; row += gridDim.x * BLOCK)
+        if (!visit(row)) return;
+}
+// the representatives' offset codes and values, slot by slot (slot empty: code 255)
+template <class T>
+__global__ __launch_bounds__(BLOCK) void cpair_gather_kernel(const int32_t *__restrict__ tab, const uint8_t *__restrict__ idx_code,
+                                                             const T *__restrict__ val, uint8_t *__restrict__ rep_oc, T *__restrict__ rep_val) {
+    const int sl = blockIdx.x * BLOCK + threadIdx.x;
+    if (sl >= CP_SLOTS) return;
+    const int k = tab[sl];
+    rep_oc[sl] = k < 0 ? (uint8_t)255 : idx_code[k];
+    rep_val[sl] = k < 0 ? szero<T>() : val[k];
+}
+template <class T>
+__global__ __launch_bounds__(BLOCK) void cpair_encode_kernel(int n, const int32_t *__restrict__ row_ptr, const uint8_t *__restrict__ idx_code,
+                                                             const T *__restrict__ val, int diag_code, const int32_t *__restrict__ tab,
+                                                             const uint8_t *__restrict__ rep_oc, const T *__restrict__ rep_val,
+                                                             const uint8_t *__restrict__ code_of_slot, uint8_t *__restrict__ pair_code,
+                                                             T *__restrict__ rowval, int *__restrict__ bad) {
+    __shared__ T s_val[CP_SLOTS];
+    __shared__ uint8_t s_oc[CP_SLOTS], s_code[CP_SLOTS], s_used[CP_SLOTS];
+    for (int i = threadIdx.x; i < CP_SLOTS; i += BLOCK) { s_val[i] = rep_val[i]; s_oc[i] = rep_oc[i]; s_code[i] = code_of_slot[i]; s_used[i] = tab[i] >= 0; }
+    __syncthreads();
+    for (int row = blockIdx.x * BLOCK + threadIdx.x; row < n; row += gridDim.x * BLOCK) {
+        T dv = szero<T>();
+        bool have_dv = false;
+        for (int k = row_ptr[row], ke = row_ptr[row + 1]; k < ke; ++k) {
+            const int oc = idx_code[k];
+            const T v = val[k];
+            if (oc == diag_code) {
+                if (have_dv) *bad = 1;          // two entries at offset 0 (an unsorted/duplicated row): one row-value slot cannot hold both
+                pair_code[k] = (uint8_t)CP_DIAG; dv = v; have_dv = true; continue;
+            }
+            uint32_t h = cp_hash(oc, v) & (CP_SLOTS - 1);
+            int code = -1;
+            for (int t = 0; t < CP_SLOTS; ++t, h = (h + 1) & (CP_SLOTS - 1)) {
+                if (!s_used[h]) break;
+                if (s_oc[h] == oc && same_bits(s_val[h], v)) { code = s_code[h]; break; }
+            }
+            if (code < 0) { *bad = 1; code = 0; }
+            pair_code[k] = (uint8_t)code;
+        }
+        rowval[row] = dv;
+    }
+}
+
 template <class T, int DOT, bool CONJX, bool PAIR, bool WV = false>
 __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_chunk, const BlkDesc *__restrict__ desc,
                                                           const int32_t *__restrict__ order,
@@ -258,7 +366,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
                                                           const T *__restrict__ val, const T *__restrict__ x,
                                                           T *__restrict__ y, const T *__restrict__ u, T *__restrict__ part0,
                                                           T *__restrict__ part1, const int *__restrict__ status, const Fin fin,
-                                                          const V2d *__restrict__ tail2, int g2_last) {
+                                                          const V2d *__restrict__ tail2, int g2_last, const T *__restrict__ rowval) {
     static_assert(!WV || (sizeof(T) == 8 && !PAIR), "wide value loads: f64 offset-code stream");
     constexpr int CAP = nnz_cap<T>::value;          // nnz per row block (per wavefront)
     constexpr int CW = (CAP + 3 + CPAD + 3) / 4;    // dwords: CAP code bytes at any 4-byte phase + the readable pad
@@ -274,7 +382,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     // the wavefront index as a SCALAR: the block walk (b, loop branches) then lives in SGPRs
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if constexpr (PAIR) s_pair[tid] = PairEnt<T>{off_tab[tid] * (int32_t)sizeof(T), val_tab[tid]};    // BLOCK == TAB
+    if constexpr (PAIR) stage_pair(s_pair, tid, off_tab[tid] * (int32_t)sizeof(T), val_tab[tid]);    // BLOCK == TAB
     else s_off8[tid] = off_tab[tid] * (int32_t)sizeof(T);
     for (int i = lane; i < CW; i += WAVE) s_c[wv][i] = 0;       // the pad is read (and ignored) before it is ever written
     if constexpr (!PAIR) for (int i = lane; i < CAP + 16; i += WAVE) s_v[wv][i] = szero<T>();
@@ -283,7 +391,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
 
     T d0 = szero<T>(), d1 = szero<T>();
     dict_walk<T, DOT, CONJX, PAIR, WV>(n_rowblk, xcd_chunk, desc, order, row_ptr, code, val, x, y, u, tail2, g2_last, s_pair, s_off8, s_c,
-                                       &s_v[0][0], PAIR ? 0 : CAP + 16, d0, d1);
+                                       &s_v[0][0], PAIR ? 0 : CAP + 16, d0, d1, rowval);
     if (DOT >= 1) {
         d0 = block_sum(d0, red);
         if (tid == 0) st_partial(fin, part0 + blockIdx.x, d0);
@@ -428,7 +536,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pair2_kernel(int n_wide, int xcd_c
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    s_pair[tid] = PairEnt<T>{off_tab[tid] * 8, val_tab[tid]};                  // BLOCK == TAB
+    stage_pair(s_pair, tid, off_tab[tid] * 8, val_tab[tid]);                  // BLOCK == TAB
     for (int i = lane; i < CW2; i += WAVE) s_c[wv][i] = 0;                     // the pad is read (and ignored) before it is written
     __syncthreads();
     if (run_state != ST_RUNNING) { fin_idle(fin, DOT == 2); return; }
@@ -530,6 +638,8 @@ struct BlkDescHost2 { int32_t ra, rb, pa, nn; };
 template <class T> struct has_val_dict { static constexpr bool value = false; };
 template <> struct has_val_dict<double> { static constexpr bool value = true; };
 template <> struct has_val_dict<float> { static constexpr bool value = true; };
+// ... a pair-code stream: real scalars through the value dictionary, complex ones through the row-value slot (cpair stage)
+template <class T> struct has_pair_codes { static constexpr bool value = has_val_dict<T>::value || is_complex<T>::value; };
 
 // Chain plan (spmv_chain.hip) of the pair-code stream: flag[j] = 128-row block j is a full uniform (plain or seam) block of the
 // canonical pattern off[0..UL), which has exactly one far slot a side.  Tiles of CH_B blocks are placed greedily on the runs of
@@ -927,6 +1037,78 @@ int build_dict_t(sprs_csr *A, const std::vector<int32_t> &blk, const std::vector
         }
     }
     tr.lap("    period order + uniform marks (offset stream)");
+    if constexpr (is_complex<T>::value) {
+        // ---- complex pair stage (cpair_* kernels above): (offset code, value) pairs of the entries off the diagonal, <= 255 of
+        // them, + one value per row for the offset-0 entries
+        if (c->spmv_dict != 1 && A->nnz > 0) {
+            int diag_code = -1;
+            for (size_t i = 0; i < offs.size(); ++i) if (offs[i].first == 0) diag_code = (int)i;
+            int32_t *cp_tab = nullptr; uint8_t *cp_oc = nullptr, *cp_code = nullptr; T *cp_val = nullptr; int *cp_cnt = counts + 1;
+            auto cp_free = [&]() { for (void *q : {(void *)cp_tab, (void *)cp_oc, (void *)cp_code, (void *)cp_val}) if (q) (void)hipFree(q); };
+#define CP_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { snprintf(c->err, sizeof(c->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); cp_free(); cleanup2(); free_dict(A); return SPRS_ERR_HIP; } } while (0)
+            CP_TRY(hipMalloc((void **)&cp_tab, sizeof(int32_t) * CP_SLOTS));
+            CP_TRY(hipMalloc((void **)&cp_oc, CP_SLOTS));
+            CP_TRY(hipMalloc((void **)&cp_code, CP_SLOTS));
+            CP_TRY(hipMalloc((void **)&cp_val, sizeof(T) * CP_SLOTS));
+            CP_TRY(hipMemsetAsync(cp_tab, 0xff, sizeof(int32_t) * CP_SLOTS, c->stream));
+            CP_TRY(hipMemsetAsync(cp_cnt, 0, sizeof(int) * 3, c->stream));
+            hipLaunchKernelGGL((cpair_collect_kernel<T>), dim3(g), dim3(BLOCK), 0, c->stream, n, A->row_ptr, D->idx_code, val, diag_code, cp_tab, cp_cnt);
+            CP_TRY(hipGetLastError());
+            int np = 0;
+            CP_TRY(hipMemcpyAsync(&np, cp_cnt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            CP_TRY(hipStreamSynchronize(c->stream));
+            if (np <= CP_DIAG) {
+                hipLaunchKernelGGL((cpair_gather_kernel<T>), dim3(CP_SLOTS / BLOCK), dim3(BLOCK), 0, c->stream, cp_tab, D->idx_code, val, cp_oc, cp_val);
+                CP_TRY(hipGetLastError());
+                std::vector<int32_t> h_tab(CP_SLOTS);
+                std::vector<uint8_t> h_oc(CP_SLOTS), h_code(CP_SLOTS, 0);
+                std::vector<T> h_val(CP_SLOTS);
+                CP_TRY(hipMemcpyAsync(h_tab.data(), cp_tab, sizeof(int32_t) * CP_SLOTS, hipMemcpyDeviceToHost, c->stream));
+                CP_TRY(hipMemcpyAsync(h_oc.data(), cp_oc, CP_SLOTS, hipMemcpyDeviceToHost, c->stream));
+                CP_TRY(hipMemcpyAsync(h_val.data(), cp_val, sizeof(T) * CP_SLOTS, hipMemcpyDeviceToHost, c->stream));
+                CP_TRY(hipStreamSynchronize(c->stream));
+                // codes in ascending (offset, value bits) order: deterministic whatever thread claimed a slot first
+                std::vector<int> slots;
+                for (int sl = 0; sl < CP_SLOTS; ++sl) if (h_tab[(size_t)sl] >= 0) slots.push_back(sl);
+                std::sort(slots.begin(), slots.end(), [&](int a, int b) {
+                    const int32_t oa = off_tab[h_oc[(size_t)a]], ob = off_tab[h_oc[(size_t)b]];
+                    if (oa != ob) return oa < ob;
+                    return memcmp(&h_val[(size_t)a], &h_val[(size_t)b], sizeof(T)) < 0;
+                });
+                if ((int)slots.size() == np) {
+                    std::vector<int32_t> pair_off(TAB, 0);
+                    std::vector<T> pair_val(TAB, szero<T>());
+                    for (size_t i = 0; i < slots.size(); ++i) {
+                        h_code[(size_t)slots[i]] = (uint8_t)i;
+                        pair_off[i] = off_tab[h_oc[(size_t)slots[i]]]; pair_val[i] = h_val[(size_t)slots[i]];
+                    }
+                    CP_TRY(hipMalloc((void **)&D->pair_code, nb));
+                    CP_TRY(hipMemsetAsync(D->pair_code, 0, nb, c->stream));
+                    CP_TRY(hipMalloc((void **)&D->pair_off, sizeof(int32_t) * TAB));
+                    CP_TRY(hipMalloc(&D->pair_val, sizeof(T) * TAB));
+                    CP_TRY(hipMalloc(&D->rowval, sizeof(T) * (size_t)std::max(n, 1)));
+                    CP_TRY(hipMemcpyAsync(D->pair_off, pair_off.data(), sizeof(int32_t) * TAB, hipMemcpyHostToDevice, c->stream));
+                    CP_TRY(hipMemcpyAsync(D->pair_val, pair_val.data(), sizeof(T) * TAB, hipMemcpyHostToDevice, c->stream));
+                    CP_TRY(hipMemcpyAsync(cp_code, h_code.data(), CP_SLOTS, hipMemcpyHostToDevice, c->stream));
+                    CP_TRY(hipMemsetAsync(bad, 0, sizeof(int), c->stream));
+                    hipLaunchKernelGGL((cpair_encode_kernel<T>), dim3(g), dim3(BLOCK), 0, c->stream, n, A->row_ptr, D->idx_code, val, diag_code, cp_tab,
+                                       cp_oc, cp_val, cp_code, D->pair_code, reinterpret_cast<T *>(D->rowval), bad);
+                    CP_TRY(hipGetLastError());
+                    int h_bad = 0;
+                    CP_TRY(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                    CP_TRY(hipStreamSynchronize(c->stream));
+                    if (h_bad) {        // a row with two entries at offset 0: keep the offset-code stream
+                        for (void **q : {(void **)&D->pair_code, (void **)&D->pair_off, &D->pair_val, &D->rowval}) { (void)hipFree(*q); *q = nullptr; }
+                    } else {
+                        D->n_pair = np + (diag_code >= 0 ? 1 : 0);
+                    }
+                }
+            }
+            cp_free();
+#undef CP_TRY
+            tr.lap("    complex pair codes (row-value slot)");
+        }
+    }
     if (use_vals) {
         // ---- pair stage: which (offset code, value code) pairs occur?  <= 256 of them -> one byte per nnz
         const int gk = (int)std::max<int64_t>(1, std::min<int64_t>(c->num_cu * 8, (A->nnz + BLOCK - 1) / BLOCK));
@@ -1068,7 +1250,7 @@ void free_dict(sprs_csr *A) {
     for (void *q : {(void *)D->idx_code, (void *)D->pair_code, (void *)D->off_tab, (void *)D->pair_off, D->pair_val, D->wide_desc, D->off_desc, (void *)D->wide_order, (void *)D->off_order,
                     (void *)D->tile_pair.list, (void *)D->tile_pair.xstart, (void *)D->tile_pair.left,
                     (void *)D->tile_off.list, (void *)D->tile_off.xstart, (void *)D->tile_off.left, D->owide_desc,
-                    (void *)D->chain_pair.tiles, (void *)D->chain_pair.segs, (void *)D->chain_pair.xstart, (void *)D->chain_pair.left})
+                    (void *)D->chain_pair.tiles, (void *)D->chain_pair.segs, (void *)D->chain_pair.xstart, (void *)D->chain_pair.left, D->rowval})
         if (q) (void)hipFree(q);
     delete D;
     A->dict = nullptr;
@@ -1106,7 +1288,7 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
     const sprs_dict *D = A->dict;
     const T *v = reinterpret_cast<const T *>(A->val);
     const T *pv = reinterpret_cast<const T *>(D->pair_val);
-    const bool pair = has_val_dict<T>::value && mode == 2;
+    const bool pair = has_pair_codes<T>::value && mode == 2;
     if constexpr (sizeof(T) == 8 && !is_complex<T>::value) {
         // f64 pair codes: two rows per lane
         // ... on the whole matrix in natural order, or on the interior / boundary subsets of a distributed operator,
@@ -1166,7 +1348,7 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
                 return launch_tile_off(A, *tpp, g, dsc, x, y, dot_mode, u, part0, part1, status, fin, tail2, g2_last);
             }
 #define SPRS_DSPMVW(DM) SPRS_LAUNCH_SPMV(c, (spmv_dict_kernel<T, DM, false, false, true>), g, count, xcd_chunk, dsc, order, A->row_ptr, \
-                                         code, otab, pv, v, x, y, u, part0, part1, status, fin, tail2, g2_last)
+                                         code, otab, pv, v, x, y, u, part0, part1, status, fin, tail2, g2_last, (const T *)nullptr)
             if (dot_mode == 0) SPRS_DSPMVW(0); else if (dot_mode == 1) SPRS_DSPMVW(1); else SPRS_DSPMVW(2);
 #undef SPRS_DSPMVW
             SPRS_HIP_TRY(c, hipGetLastError());
@@ -1176,8 +1358,8 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
 #define SPRS_DSPMV2(DM, CJ, PR)                                                                                         \
     SPRS_LAUNCH_SPMV(c, (spmv_dict_kernel<T, DM, CJ, PR>), g, count, xcd_chunk,                                          \
                        dsc, order, A->row_ptr, code, otab, pv, v, x, y, u,                                              \
-                       part0, part1, status, fin, tail2, g2_last)
-#define SPRS_DSPMV(DM, CJ) do { if (pair) SPRS_DSPMV2(DM, CJ, (has_val_dict<T>::value)); else SPRS_DSPMV2(DM, CJ, false); } while (0)
+                       part0, part1, status, fin, tail2, g2_last, reinterpret_cast<const T *>(D->rowval))
+#define SPRS_DSPMV(DM, CJ) do { if (pair) SPRS_DSPMV2(DM, CJ, (has_pair_codes<T>::value)); else SPRS_DSPMV2(DM, CJ, false); } while (0)
     if (conj_x && is_complex<T>::value) {
         if (dot_mode == 0) SPRS_DSPMV(0, true);
         else if (dot_mode == 1) SPRS_DSPMV(1, true);

@@ -18,6 +18,14 @@ constexpr int CPAD = 16;    // readable bytes behind a block's codes: the row ph
 
 // LDS table entry of the pair stream: byte offset of the column relative to the row, and the value
 template <class T> struct alignas(sizeof(T) >= 8 ? 16 : 8) PairEnt { int32_t off8; T val; };
+// Filling a table entry: two member stores.  An aggregate store (`s_pair[i] = PairEnt<T>{...}`) also copies the padding, and for
+// the 32-byte complex<double> entry the compiler stages that copy through a per-thread LDS temporary: measured 13 us on every launch
+// of a 256-thread kernel on gfx950 (profiles/r04_tuning.md §6).
+template <class T>
+__device__ __forceinline__ void stage_pair(PairEnt<T> *s_pair, int i, int32_t off8, T val) {
+    s_pair[i].off8 = off8;
+    s_pair[i].val = val;
+}
 
 // What a wavefront loads for one row block before it can work on it.  The loads of block i+1 are issued
 // before block i is processed (and the descriptor of block i+2 before that), so a block costs one exposed
@@ -28,6 +36,7 @@ struct BlkLoads {
     int ulen;                // > 0: uniform block — every row repeats the first row's ulen (<= UNI_OFF_MAXLEN) codes; no row_ptr, 1-9 code dwords
     int s;                   // row_ptr[row] of this lane's row
     T uu;                    // dot operand of this lane's row
+    T rv;                    // complex pair codes: this lane's row value (code 255; spmv_dict.hip, cpair stage)
     uint32_t wc[2];          // code dwords
     int di[2];               // ... and the LDS slots they go to
     T vv[PAIR ? 1 : ITEMS];  // values (offset-code stream only)
@@ -46,8 +55,9 @@ __device__ __forceinline__ void dict_walk(int n_rowblk, int xcd_chunk, const Blk
                                           const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y, const T *__restrict__ u,
                                           const V2d *__restrict__ tail2, int g2_last,
                                           const PairEnt<T> *s_pair, const int32_t *s_off8, uint32_t (*s_c)[(nnz_cap<T>::value + 3 + CPAD + 3) / 4],
-                                          T *s_v, int s_v_stride, T &d0, T &d1) {
+                                          T *s_v, int s_v_stride, T &d0, T &d1, const T *__restrict__ rowval = nullptr) {
     constexpr int CAP = nnz_cap<T>::value;          // nnz per row block (per wavefront)
+    constexpr bool RV = PAIR && is_complex<T>::value;      // pair code 255 = the row's own value
     constexpr int ITEMS = CAP / WAVE;
     using Loads = BlkLoads<T, PAIR, ITEMS>;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
@@ -101,6 +111,7 @@ __device__ __forceinline__ void dict_walk(int n_rowblk, int xcd_chunk, const Blk
         if (uni) L.s = L.pa + (rcl - L.ra) * L.ulen;                       // every row has ulen entries: row_ptr is not read
         else L.s = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(row_ptr) + (uint32_t)rcl * 4u);   // row_ptr[row + 1] comes from the next lane (adopt)
         if (DOT != 0) L.uu = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(u) + (uint32_t)rcl * (uint32_t)sizeof(T));
+        if constexpr (RV) L.rv = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(rowval) + (uint32_t)rcl * (uint32_t)sizeof(T));
         const int shift = L.pa & 3;
         // dwords covering [pa, pa + nn) (<= CAP/4 + 1) — of a uniform block only the first row's codes: 1-9 dwords
         const int nd = max((shift + (uni ? L.ulen : L.nn) + 3) >> 2, 1);
@@ -162,7 +173,9 @@ __device__ __forceinline__ void dict_walk(int n_rowblk, int xcd_chunk, const Blk
     [[maybe_unused]] int c_vsh = 0;       // WV: the staged values start this many entries into the wavefront's slice
     bool c_uni = false;      // scalar: every lane reads the FIRST row's codes
     T c_uu = szero<T>();
+    [[maybe_unused]] T c_rv = szero<T>();
     auto adopt = [&](const Loads &L) {
+        if constexpr (RV) c_rv = L.rv;
         const int r = L.ra + lane;
         c_ra = L.ra; c_rb = L.rb; c_shift = L.pa & 3; c_uni = L.ulen > 0;
         if constexpr (WV) c_vsh = L.pa & 1;
@@ -222,7 +235,10 @@ __device__ __forceinline__ void dict_walk(int n_rowblk, int xcd_chunk, const Blk
                 const bool valid = j0 + t < len;
                 const int cd = cp[t];
                 int off8;
-                if constexpr (PAIR) { const PairEnt<T> e = s_pair[cd]; off8 = e.off8; av[t] = e.val; }
+                if constexpr (PAIR) {
+                    const PairEnt<T> e = s_pair[cd]; off8 = e.off8; av[t] = e.val;
+                    if constexpr (RV) { if (cd == 255) av[t] = c_rv; }
+                }
                 else { off8 = s_off8[cd]; av[t] = vs[(WV ? c_vsh : 0) + kb + t]; }
                 const uint32_t vo = valid ? r8 + (uint32_t)off8 : 0u;     // lanes past their row gather x[0] and drop it
                 xg[t] = *reinterpret_cast<const T *>(xbytes + vo);

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(const int2 *__restrict
     const int run_state = status != nullptr ? *status : (int)ST_RUNNING;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    s_pair[tid] = PairEnt<T>{off_tab[tid] * 8, val_tab[tid]};                  // BLOCK == TAB (the seam rows' own values; the walk below)
+    stage_pair(s_pair, tid, off_tab[tid] * 8, val_tab[tid]);                  // BLOCK == TAB (the seam rows' own values; the walk below)
     for (int i = lane; i < CW2; i += WAVE) s_c[wv][i] = 0;
     __syncthreads();
     if (run_state != ST_RUNNING) { fin_idle(fin, DOT == 2); return; }

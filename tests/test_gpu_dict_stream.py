@@ -73,12 +73,15 @@ def test_formats_bit_identical(sa, oracle, dtype, name):
         elif knob == 1:
             assert mode == 1 and n_val == 0
         else:
-            few_values = real and name != "banded_random_values"
-            # auto (-1): offset codes for every real matrix that has them; the plain stream for complex ones (where
-            # offset codes alone do not pay: 17 instead of 20 B/nnz against the lane-per-row layout)
+            few_values = name != "banded_random_values"
+            # auto (-1): pair codes wherever the (offset, value) pairs are few — complex matrices through the row-value slot (their
+            # offset-0 entries are kept per row, csrc/spmv_dict.hip cpair stage); else offset codes for every real matrix that has
+            # them and the plain stream for complex ones (offset codes alone do not pay there: 17 instead of 20 B/nnz against the
+            # lane-per-row layout)
             assert mode == (2 if few_values else (1 if (knob == 2 or real) else 0)), (mode, n_off, n_val)
             if few_values:
-                assert n_val == (7 if name == "poisson3d" else 6)      # distinct (offset, value) pairs
+                # distinct (offset, value) pairs; complex: the pairs off the diagonal + 1 for the row-value slot
+                assert n_val == (7 if name == "poisson3d" else (6 if real else 5))
         if knob != 0:
             assert n_off == {"poisson3d": 7, "grid2d": 5, "banded_random_values": 9}[name]
         y = np.full(n, 3.0, dtype=dtype)
