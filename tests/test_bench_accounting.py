@@ -10,12 +10,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
 import bench  # noqa: E402
 
 
 class FakeCsr:
-    def __init__(self, mode, n_off, n_pair, nb, nu):
-        self._fmt, self._blk = (mode, n_off, n_pair), (nb, nu)
+    def __init__(self, mode, n_off, n_pair, nb, nu, dtype="f8"):
+        self._fmt, self._blk, self.dtype = (mode, n_off, n_pair), (nb, nu), np.dtype(dtype)
 
     def stream_format(self):
         return self._fmt
@@ -46,6 +47,11 @@ def test_compressed_streams_count_only_what_is_read():
     off = bench.stream_info(FakeCsr(1, 7, 0, 781250, 679688), N, NNZ, 8)
     uf = 679688 / 781250
     assert off["bytes_moved_per_launch"] == int(NNZ * 8 + (1 - uf) * (NNZ + (N + 1) * 4) + 2 * N * 8)
+    # complex pair codes (cfg 4): one byte per entry, row_ptr, + the row-value slot: one scalar per row beside x and y
+    n4, nnz4 = 500_000, 2_497_000
+    cp = bench.stream_info(FakeCsr(2, 5, 5, 7813, 0, dtype="c16"), n4, nnz4, 16)
+    assert cp["bytes_moved_per_launch"] == cp["format_bytes_per_launch"] == nnz4 + (n4 + 1) * 4 + 3 * n4 * 16
+    assert "row" in bench.KERNEL_NAMES[cp["kernel_id"]] and "cplx" in bench.KERNEL_NAMES[cp["kernel_id"]]
 
 
 def test_roofline_fraction_adds_the_dot_operand_and_keeps_the_extras_apart():
