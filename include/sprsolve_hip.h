@@ -147,8 +147,11 @@ int64_t sprs_csr_nnz(const sprs_csr *A);
 /* Which stream the SpMV of this handle reads (backend detail, csrc/spmv_dict.hip): 0 = plain CSR (12 B/nnz for
  * f64), 1 = one-byte column-offset codes + the values (9 B/nnz), 2 = one-byte codes of the (offset, value) pairs
  * (1 B/nnz).  The compressed streams are built at creation when the matrix has <= 256 distinct (col - row) offsets
- * (and, for real scalars, <= 256 distinct values and pairs) and the ctx knob "spmv_dict" allows it; y is
- * bit-identical in all three.  n_offsets / n_pairs (may be NULL) receive the table sizes (0 = table absent). */
+ * (and, for real scalars, <= 256 distinct values and pairs; for complex scalars <= 255 distinct (offset, value) pairs
+ * among the entries OFF the diagonal — the offset-0 entries are kept one per row, 16 B per row for Complex<f64>) and
+ * the ctx knob "spmv_dict" allows it; y is bit-identical in all three.  Automatic policy: pair codes where they
+ * exist; else offset codes for real scalars and the plain stream for complex ones.  n_offsets / n_pairs (may be
+ * NULL) receive the table sizes (0 = table absent; complex pair codes count the row-value slot as one pair). */
 int sprs_csr_stream_format(const sprs_csr *A, int *n_offsets, int *n_pairs);
 /* Diagnostics of the compressed streams: the number of row blocks the SpMV of this handle walks (128-row blocks of
  * the f64 pair-code stream, 64-row blocks of the offset-code stream) and how many of them are "uniform" (all rows
