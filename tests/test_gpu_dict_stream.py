@@ -786,6 +786,52 @@ def test_plane_streaming_chains_bit_identical(sa, oracle, name):
         ctx.set("spmv_chain", -1); ctx.set("spmv_tile", -1)
 
 
+def _fused_against_five_launches(sa, ctx, A, n, rhs, rhs2, x0, exact, exact_tol=1e-6):
+    """BiCGStab with spmv_fuse 1 against spmv_fuse 0 on handle A: outcome, iteration count, residual, x and every traced scalar bit for
+    bit over a set of solves (to convergence, tol = 0, x0 != 0, one / two iterations, a loose tolerance, a long tol = 0 run through the
+    restart branch, traced and polled)."""
+    out = {}
+    for fuse in (1, 0):
+        ctx.set("spmv_fuse", fuse)
+        res = []
+        # (the 700-iteration run at tol = 0 goes on long after rounding-level convergence: rho = r0.r decays to a cancellation
+        # residue and the restart branch, bicg_stab.rs:131-145, fires — executed by the host, resumed by a K2 in "resumed" mode)
+        for b, start, max_iter, tol in ((rhs, None, 3000, 1e-10), (rhs2, x0, 3000, 1e-9), (rhs2, None, 37, 0.0), (rhs, None, 1, 0.0),
+                                        (rhs2, None, 2, 0.0), (rhs, None, 3000, 0.5), (rhs, None, 700, 0.0)):
+            s = sa.BiCGStab.new(A, n); s.set_trace(64); s.set_profile(True)
+            x = np.zeros(n) if start is None else start.copy()
+            try:
+                its, rr = s.solve(b, x, max_iter, tol)
+                st = "ok"
+            except sa.error.InsufficientIterNum as e:
+                its, rr, st = e.iters, None, "insufficient"
+            prof = s.profile()
+            res.append((st, its, rr, bits(x).copy(), bits(s.trace()).copy(), prof["fused_k2"], prof["fused_k4"], prof["spmv_launches"]))
+        # the restart run again WITHOUT a trace: the host then polls every `poll` iterations, so a restart request is followed by up
+        # to poll - 1 iterations of idle launches for each of which the host has already rotated its buffer names (odd and even counts)
+        for poll in (16, 5, 2):
+            ctx.set("poll", poll)
+            s = sa.BiCGStab.new(A, n); s.set_profile(True)
+            x = np.zeros(n)
+            try:
+                its, rr = s.solve(rhs, x, 700, 0.0); st = "ok"
+            except sa.error.InsufficientIterNum as e:
+                its, rr, st = e.iters, None, "insufficient"
+            prof = s.profile()
+            res.append((st, its, rr, bits(x).copy(), np.zeros(0, np.uint8), prof["fused_k2"], prof["fused_k4"], prof["spmv_launches"]))
+        ctx.set("poll", 16)
+        out[fuse] = res
+    for a, b in zip(out[1], out[0]):
+        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], (a[:3], b[:3])
+        assert np.array_equal(a[3], b[3]), "x differs between the fused and the five-launch iteration"
+        assert np.array_equal(a[4], b[4]), "a traced scalar differs"
+        assert b[5] == 0 and b[6] == 0
+        assert a[6] >= 1 and (a[5] >= 1 or a[1] <= 1), a[5:]          # K4 is fused from the first iteration on, K2 from the second
+        assert a[7] == b[7] or a[4].size == 0                          # the same number of SpMV launches either way (traced runs)
+    err = np.max(np.abs(out[1][0][3].view(np.float64) - exact))
+    assert out[1][0][0] == "ok" and err < exact_tol * max(1.0, float(np.max(np.abs(exact)))), (out[1][0][:3], err)
+
+
 @pytest.mark.parametrize("name", [k for k in _chain_cases() if k.startswith("p3_")])
 def test_fused_spmv_input_is_bit_identical(sa, oracle, name):
     """Knob spmv_fuse (csrc/krylov.hip "fused SpMV input", csrc/spmv_chain.hip FUSE): on a handle whose SpMV runs through chains
@@ -804,44 +850,7 @@ def test_fused_spmv_input_is_bit_identical(sa, oracle, name):
         ctx.set("spmv_chain", 1); ctx.set("spmv_tile", 1)
         A = sa.HipCsr.new((n, n), indptr, cols, data)
         assert A.chain_plan()[0] >= 64
-        for fuse in (1, 0):
-            ctx.set("spmv_fuse", fuse)
-            res = []
-            # (the 700-iteration run at tol = 0 goes on long after rounding-level convergence: rho = r0.r decays to a cancellation
-            # residue and the restart branch, bicg_stab.rs:131-145, fires — executed by the host, resumed by a K2 in "resumed" mode)
-            for b, start, max_iter, tol in ((rhs, None, 3000, 1e-10), (rhs2, x0, 3000, 1e-9), (rhs2, None, 37, 0.0), (rhs, None, 1, 0.0),
-                                            (rhs2, None, 2, 0.0), (rhs, None, 3000, 0.5), (rhs, None, 700, 0.0)):
-                s = sa.BiCGStab.new(A, n); s.set_trace(64); s.set_profile(True)
-                x = np.zeros(n) if start is None else start.copy()
-                try:
-                    its, rr = s.solve(b, x, max_iter, tol)
-                    st = "ok"
-                except sa.error.InsufficientIterNum as e:
-                    its, rr, st = e.iters, None, "insufficient"
-                prof = s.profile()
-                res.append((st, its, rr, bits(x).copy(), bits(s.trace()).copy(), prof["fused_k2"], prof["fused_k4"], prof["spmv_launches"]))
-            # the restart run again WITHOUT a trace: the host then polls every `poll` iterations, so a restart request is followed by up
-            # to poll - 1 iterations of idle launches for each of which the host has already rotated its buffer names (odd and even counts)
-            for poll in (16, 5, 2):
-                ctx.set("poll", poll)
-                s = sa.BiCGStab.new(A, n); s.set_profile(True)
-                x = np.zeros(n)
-                try:
-                    its, rr = s.solve(rhs, x, 700, 0.0); st = "ok"
-                except sa.error.InsufficientIterNum as e:
-                    its, rr, st = e.iters, None, "insufficient"
-                prof = s.profile()
-                res.append((st, its, rr, bits(x).copy(), np.zeros(0, np.uint8), prof["fused_k2"], prof["fused_k4"], prof["spmv_launches"]))
-            ctx.set("poll", 16)
-            out[fuse] = res
-        for a, b in zip(out[1], out[0]):
-            assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], (a[:3], b[:3])
-            assert np.array_equal(a[3], b[3]), "x differs between the fused and the five-launch iteration"
-            assert np.array_equal(a[4], b[4]), "a traced scalar differs"
-            assert b[5] == 0 and b[6] == 0
-            assert a[6] >= 1 and (a[5] >= 1 or a[1] <= 1), a[5:]          # K4 is fused from the first iteration on, K2 from the second
-            assert a[7] == b[7] or a[4].size == 0                          # the same number of SpMV launches either way (traced runs)
-        assert out[1][0][0] == "ok" and np.max(np.abs(out[1][0][3].view(np.float64) - exact)) < 1e-6
+        _fused_against_five_launches(sa, ctx, A, n, rhs, rhs2, x0, exact)
     finally:
         ctx.set("spmv_chain", -1); ctx.set("spmv_tile", -1); ctx.set("spmv_fuse", -1); ctx.set("poll", 16)
 
