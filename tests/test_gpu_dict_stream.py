@@ -95,6 +95,62 @@ def test_formats_bit_identical(sa, oracle, dtype, name):
     assert got[0] == got[1] == got[2] == got[-1]
 
 
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64], ids=["c64", "c32"])
+def test_complex_pair_codes_row_value_slot(sa, oracle, dtype):
+    """Complex pair codes (csrc/spmv_dict.hip, cpair stage): the offset-0 entry of a row has the reserved code 255 = the row's own
+    value.  Rows WITHOUT a diagonal entry, a diagonal that is different in every row, conjugate-transposed use (CSMINRES' gather),
+    more than 255 off-diagonal pairs (no pair codes), and a row that holds TWO entries at offset 0 (the slot cannot hold both: the
+    handle keeps the offset-code stream) — y bit for bit the reference fold every time."""
+    from sprsolve_amd import gen
+    ctx = sa.default_ctx(0)
+    ip, ix, d, _, _ = gen.complex_symmetric_grid(40, 50)          # tests/test_complex_solve2.rs:35-96's operator: 5 offsets
+    d = d.astype(dtype)
+    n = ip.size - 1
+    x = rand_vec(n, dtype, 11)
+    rng = np.random.default_rng(8)
+
+    def check(indptr, indices, data, want_mode, label):
+        A = sa.HipCsr.new((n, n), indptr, indices, data)
+        assert A.stream_format()[0] == want_mode, (label, A.stream_format())
+        ref = oracle.spmv(indptr, indices, data, x)
+        y = np.full(n, 3.0, dtype=dtype)
+        A.mul_vec(x, y)
+        assert np.array_equal(bits(y), bits(ref)), label
+        y2 = np.zeros(n, dtype=dtype)
+        A.mul_vec_dot(x, y2)
+        assert np.array_equal(bits(y2), bits(ref)), label
+        return A
+
+    try:
+        ctx.set("spmv_dict", -1)
+        check(ip, ix, d, 2, "the grid")
+        # a diagonal that differs row by row (the slot holds n distinct values), some diagonals -0.0 / denormal / inf-free specials
+        dd = d.copy()
+        diag = np.nonzero(ix == np.repeat(np.arange(n), np.diff(ip)))[0]
+        dd[diag] = (rng.uniform(-3, 3, diag.size) + 1j * rng.uniform(-3, 3, diag.size)).astype(dtype)
+        dd[diag[:3]] = np.array([-0.0 + 0j, 5e-324 if dtype == np.complex128 else 1e-45, 1j], dtype=dtype)
+        check(ip, ix, dd, 2, "row-by-row diagonal")
+        # rows without a diagonal entry: drop every third diagonal
+        keep = np.ones(ix.size, bool); keep[diag[::3]] = False
+        ip2 = np.concatenate([[0], np.cumsum(np.add.reduceat(keep.astype(np.int64), ip[:-1]))]).astype(np.int32)
+        check(ip2, ix[keep], dd[keep], 2, "missing diagonals")
+        # more than 255 distinct off-diagonal pairs: no pair codes, the plain stream under the automatic policy
+        dr = dd.copy()
+        off = np.setdiff1d(np.arange(ix.size), diag)
+        dr[off] = (rng.uniform(-1, 1, off.size) + 1j * rng.uniform(-1, 1, off.size)).astype(dtype)
+        check(ip, ix, dr, 0, "random off-diagonals")
+        # a duplicated diagonal entry in one row (CSR with a repeated column: the fold adds both products, in order)
+        r = n // 2
+        k = int(diag[r])
+        ip3 = ip.copy(); ip3[r + 1:] += 1
+        ix3 = np.insert(ix, k + 1, ix[k]); d3 = np.insert(dd, k + 1, dtype(0.25 - 2j))
+        A = check(ip3, ix3, d3, 0, "two entries at offset 0")
+        ctx.set("spmv_dict", 2)                                   # forced: still no pair codes for this handle — offset codes
+        check(ip3, ix3, d3, 1, "two entries at offset 0, knob 2")
+    finally:
+        ctx.set("spmv_dict", -1)
+
+
 def test_fallback_too_many_offsets(sa, oracle):
     import scipy.sparse as sp
     n = 4000
