@@ -437,8 +437,14 @@ int sprs_solver_set_mode(void *solver, int kind, int mode);
 int sprs_solver_set_trace(void *solver, int kind, double *trace_host, size_t capacity_rows);
 int sprs_solver_trace_rows(const void *solver, int kind, size_t *rows_out);
 /* Device-time profile of the last solve: total milliseconds and launch count of the SpMV
- * kernel measured with HIP events on the solver's stream (enable != 0 to collect). */
+ * kernel measured with HIP events on the solver's stream.  enable: 0 off; 1 every SpMV launch; k >= 2 a SAMPLE — one pair
+ * of consecutive SpMV launches in k (a launch that carries events costs ~6 us more: a fifth of a 30 us iteration). */
 int sprs_solver_set_profile(void *solver, int kind, int enable);
+/* ... and what the timed launches were: `steps` = SpMV launches of the solve (timed or not); among the TIMED ones (the
+ * `launches` of sprs_solver_get_profile) how many read a dot operand other than their input vector, how many were K2 / K4
+ * launches that formed their input on the fly ("spmv_fuse").  Any pointer may be NULL. */
+int sprs_solver_get_profile_counts(const void *solver, int kind, int64_t *steps, int64_t *timed_dot_other, int64_t *timed_k2_fused,
+                                   int64_t *timed_k4_fused);
 int sprs_solver_get_profile(const void *solver, int kind, double *spmv_ms_total, int64_t *spmv_launches,
                             double *solve_ms_total);
 /* How many SpMV launches of the last solve formed their input vector on the fly (ctx knob "spmv_fuse"): BiCGStab's K2 with K1's

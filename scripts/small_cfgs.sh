@@ -1,10 +1,11 @@
-# the three cache-resident BASELINE configs, default knobs, 2 repetitions each
-cd $GRAFT_REPO_ROOT
-for rep in 1 2; do for wl in poisson2d banded complex; do
-  timeout -k 10 100 python bench.py --workload $wl --steps 1000 --warmup 100 --no-cpu-baseline > gpurun_out/small_$wl.json 2> gpurun_out/small_$wl.err || { tail -3 gpurun_out/small_$wl.err; exit 1; }
-  python - <<PY
-import json
-d=json.load(open("gpurun_out/small_$wl.json"))
-print("%-10s %9.0f it/s  %.2f us/it  spmv %.1f us" % ("$wl", d["value"], d["ms_per_step"]*1e3, d["roofline"]["avg_launch_us"]))
+set -e
+for w in "complex csr" "complex auto" "banded auto" "poisson2d auto"; do
+  set -- $w
+  python bench.py --workload $1 --stream $2 --no-cpu-baseline --no-also --steps 500 --warmup 50 > gpurun_out/small_$1_$2.json 2> gpurun_out/small_$1_$2.err || { tail -5 gpurun_out/small_$1_$2.err; exit 1; }
+  python - $1 $2 <<'PY'
+import json, sys
+j = json.loads(open("gpurun_out/small_%s_%s.json" % (sys.argv[1], sys.argv[2])).read().strip().splitlines()[-1])
+r = j["roofline"]
+print(sys.argv[1], sys.argv[2], "%.0f it/s  %.2f us/iteration" % (j["value"], j["ms_per_step"] * 1e3), "spmv %.2f us" % r["avg_launch_us"], "frac %.3f" % r["frac"], j["timing"].get("profiled_pass", {}).get("ms_per_step_with_events"))
 PY
-done; done
+done

@@ -140,6 +140,7 @@ def _protos():
     P["sprs_solver_set_profile"] = [_vp, _int, _int]
     P["sprs_solver_get_profile"] = [_vp, _int, _pd, C.POINTER(_i64), _pd]
     P["sprs_solver_get_fused_launches"] = [_vp, _int, C.POINTER(_i64), C.POINTER(_i64)]
+    P["sprs_solver_get_profile_counts"] = [_vp, _int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]
     return P
 
 

@@ -49,14 +49,18 @@ class _SolverBase:
         return self._trace[: rows.value].copy() if self._trace is not None else np.zeros((0, 8))
 
     def set_profile(self, enable=True):
-        check(_lib.lib().sprs_solver_set_profile(self.h, self.KIND, 1 if enable else 0), self.A.ctx.h)
+        """False / 0: off; True / 1: HIP events around every SpMV launch; k >= 2: around one pair of consecutive launches in k."""
+        check(_lib.lib().sprs_solver_set_profile(self.h, self.KIND, int(enable)), self.A.ctx.h)
 
     def profile(self):
         ms = C.c_double(); n = C.c_int64(); tot = C.c_double()
         check(_lib.lib().sprs_solver_get_profile(self.h, self.KIND, C.byref(ms), C.byref(n), C.byref(tot)), self.A.ctx.h)
         k2 = C.c_int64(); k4 = C.c_int64()
         check(_lib.lib().sprs_solver_get_fused_launches(self.h, self.KIND, C.byref(k2), C.byref(k4)), self.A.ctx.h)
-        return dict(spmv_ms_total=ms.value, spmv_launches=n.value, solve_ms=tot.value, fused_k2=k2.value, fused_k4=k4.value)
+        st = C.c_int64(); do = C.c_int64(); t2 = C.c_int64(); t4 = C.c_int64()
+        check(_lib.lib().sprs_solver_get_profile_counts(self.h, self.KIND, C.byref(st), C.byref(do), C.byref(t2), C.byref(t4)), self.A.ctx.h)
+        return dict(spmv_ms_total=ms.value, spmv_launches=n.value, solve_ms=tot.value, fused_k2=k2.value, fused_k4=k4.value,
+                    steps=st.value, timed_dot_other=do.value, timed_fused_k2=t2.value, timed_fused_k4=t4.value)
 
     # ---- the call itself
     def _solve(self, precond, rhs, x, max_iter, tol, want_precond):

@@ -748,13 +748,24 @@ int sprs_solver_trace_rows(const void *solver, int kind, size_t *rows_out) {
     return with_base(const_cast<void *>(solver), kind, [&](auto *b) { *rows_out = b->trace_rows; return (int)SPRS_OK; });
 }
 int sprs_solver_set_profile(void *solver, int kind, int enable) {
-    return with_base(solver, kind, [&](auto *b) { b->profile = enable ? 1 : 0; return (int)SPRS_OK; });
+    return with_base(solver, kind, [&](auto *b) { b->profile = enable < 0 ? 0 : enable; return (int)SPRS_OK; });
 }
 int sprs_solver_get_profile(const void *solver, int kind, double *spmv_ms, int64_t *launches, double *solve_ms) {
     return with_base(const_cast<void *>(solver), kind, [&](auto *b) {
         if (spmv_ms) *spmv_ms = b->stats.spmv_ms;
         if (launches) *launches = b->stats.spmv_launches;
         if (solve_ms) *solve_ms = b->stats.solve_ms;
+        return (int)SPRS_OK;
+    });
+}
+
+int sprs_solver_get_profile_counts(const void *solver, int kind, int64_t *steps, int64_t *timed_dot_other, int64_t *timed_k2_fused,
+                                   int64_t *timed_k4_fused) {
+    return with_base(const_cast<void *>(solver), kind, [&](auto *b) {
+        if (steps) *steps = b->stats.steps;
+        if (timed_dot_other) *timed_dot_other = b->stats.timed_dot_other;
+        if (timed_k2_fused) *timed_k2_fused = b->stats.timed_fused_k2;
+        if (timed_k4_fused) *timed_k4_fused = b->stats.timed_fused_k4;
         return (int)SPRS_OK;
     });
 }

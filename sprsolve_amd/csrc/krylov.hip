@@ -447,16 +447,25 @@ int KrylovBase<T>::spmv(const T *x, T *y, int dot, const T *u, T *p0, T *p1, con
         }
         x = xe;
     }
-    return profiled([&]() -> int {
+    const T *x_caller = x;
+    const int st = profiled([&]() -> int {
         if (A->dist) return dist_spmv<T>(A, const_cast<T *>(x), y, dot, u, p0, p1, status, conj_x, fin);
         return launch_spmv<T>(A, x, y, dot, u, p0, p1, status, conj_x, fin);
     }, !A->dist);
+    if (profile && dot != 0 && u != x_caller) mark_step(1);
+    return st;
 }
 
 template <class T>
 template <class F>
 int KrylovBase<T>::profiled(F &&run, bool one_kernel) {
     if (!profile) return run();
+    // The events are not free: a launch that carries them costs ~6 us more (completion signal + timestamps; measured on the
+    // 30-50 us iterations of cfg 2 / 3 / 4, and 11-13 us per cfg-5 iteration = 1 %).  profile = k >= 2 brackets one PAIR of
+    // consecutive SpMV-class steps in k (a pair: BiCGStab's K2 and K4 are sampled equally often).
+    const size_t call = prof_calls++;
+    last_pair = -1;
+    if (profile >= 2 && (call >> 1) % (size_t)profile != 0) return run();
     if (ev_used + 2 > ev.size()) {
         for (int k = 0; k < 2; ++k) {
             hipEvent_t e;
@@ -478,6 +487,11 @@ int KrylovBase<T>::profiled(F &&run, bool one_kernel) {
     }
     ev_noop.resize(ev_used / 2 + 1, 0);
     ev_noop[ev_used / 2] = 0;
+    ev_call.resize(ev_used / 2 + 1, 0);
+    ev_call[ev_used / 2] = call;
+    ev_kind.resize(ev_used / 2 + 1, 0);
+    ev_kind[ev_used / 2] = 0;
+    last_pair = (long)(ev_used / 2);
     ev_used += 2;
     return st;
 }
@@ -485,7 +499,9 @@ int KrylovBase<T>::profiled(F &&run, bool one_kernel) {
 template <class T>
 void KrylovBase<T>::profile_discard_last(size_t launches) {
     if (!profile) return;
-    for (size_t k = ev_used / 2; k > 1 && launches > 0; --k, --launches) ev_noop[k - 1] = 1;     // pair 0 brackets the solve
+    // the last `launches` STEPS were no-ops: the event pairs among them (all of them, or the sampled ones)
+    const size_t first_noop = prof_calls > launches ? prof_calls - launches : 0;
+    for (size_t k = ev_used / 2; k > 1 && ev_call[k - 1] >= first_noop; --k) ev_noop[k - 1] = 1;     // pair 0 brackets the solve
 }
 
 template <class T>
@@ -502,6 +518,10 @@ int KrylovBase<T>::begin_solve() {
             }
         }
         ev_used = 2;  // ev[0], ev[1] bracket the whole solve
+        prof_calls = 0;
+        ev_call.assign(1, 0);
+        ev_kind.assign(1, 0);
+        last_pair = -1;
         SPRS_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
     }
     return SPRS_OK;
@@ -520,7 +540,12 @@ int KrylovBase<T>::end_solve() {
         SPRS_HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
         stats.spmv_ms += ms;
         stats.spmv_launches += 1;
+        const unsigned char kind = k / 2 < ev_kind.size() ? ev_kind[k / 2] : 0;
+        stats.timed_dot_other += (kind & 1) != 0;
+        stats.timed_fused_k2 += (kind & 2) != 0;
+        stats.timed_fused_k4 += (kind & 4) != 0;
     }
+    stats.steps = (int64_t)prof_calls;
     return SPRS_OK;
 }
 
@@ -636,6 +661,7 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
                 pend_k1 = -1;
                 SPRS_TRY(this->profiled([&]() -> int { return launch_chain_k2f(this->A, GS, k1, v, p, r, palt, t, r0, partB, d_status); }, true));
                 this->stats.fused_k2 += 1;
+                this->mark_step(2 | 1);      // (its dot operand is r0)
                 std::swap(p, palt); y = p;   // p' lives in the other buffer
                 std::swap(v, t);             // v' was written where t was
                 return this->red1(partB, GS, 0, &qB);
@@ -657,6 +683,7 @@ int BicgStab<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T>
                 pend_k3 = -1;
                 SPRS_TRY(this->profiled([&]() -> int { return launch_chain_k4f(this->A, GS, k3, r, v, nullptr, t, partTT, partTR, d_status); }, true));
                 this->stats.fused_k4 += 1;
+                this->mark_step(4);
                 s_pending = true;            // s was formed on the fly and not stored: K5 forms it again from r and v
                 return this->red2(partTT, partTR, GS, 1, &qTT, &qTR);
             }

@@ -32,6 +32,9 @@ struct SolverStats {
     double spmv_ms = 0.0, solve_ms = 0.0;
     int64_t spmv_launches = 0;
     int64_t fused_k2 = 0, fused_k4 = 0;   // of those (enqueued, profiled or not): chain launches that formed their input on the fly (K1 into K2 / K3 into K4)
+    // among the TIMED launches (spmv_launches): how many read a dot operand that is not their input vector, how many were fused K2 / K4
+    int64_t timed_dot_other = 0, timed_fused_k2 = 0, timed_fused_k4 = 0;
+    int64_t steps = 0;                    // SpMV-class steps of the solve, timed or not
 };
 
 template <class T>
@@ -48,7 +51,13 @@ class KrylovBase {
     int mode = 0;
     double *trace = nullptr;
     size_t trace_cap = 0, trace_rows = 0;
-    int profile = 0;
+    int profile = 0;             // 0 off; 1: every SpMV launch between HIP events; k >= 2: one pair of consecutive launches in k (a sample:
+                                 // the events cost ~6 us per launch, krylov.hip profiled())
+    size_t prof_calls = 0;       // SpMV-class steps of this solve so far (sampled or not)
+    std::vector<size_t> ev_call; // per event pair: the step it brackets
+    std::vector<unsigned char> ev_kind;   // per event pair: 1 = dot operand is not the input vector, 2 = fused K2, 4 = fused K4
+    long last_pair = -1;         // the event pair of the last step (-1: it carried none)
+    void mark_step(unsigned char kind) { if (last_pair >= 0) ev_kind[(size_t)last_pair] |= kind; }
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     std::vector<char> ev_noop;   // per profiled SpMV (event pair): launched after a restart request, i.e. returned at once — not a measurement

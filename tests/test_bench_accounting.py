@@ -73,7 +73,8 @@ def test_roofline_fraction_adds_the_dot_operand_and_keeps_the_extras_apart():
 def test_pmc_traffic_reports_staleness_by_source_digest(tmp_path, monkeypatch):
     t, note, stale = bench.pmc_traffic("cfg5_pair")
     assert t and t > 1e9 and stale in (False, True) and "csrc digest" in note
-    with open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")) as f:
+    newest = [q for q in ("r04_pmc_summary.json", "r03_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", q))][0]
+    with open(os.path.join(ROOT, "profiles", newest)) as f:
         rec = json.load(f)["cfg5_pair"]
     assert stale == (rec["csrc_digest"] != bench.csrc_digest())
     monkeypatch.setattr(bench, "csrc_digest", lambda: "0" * 16)

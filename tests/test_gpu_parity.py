@@ -890,6 +890,44 @@ def test_malformed_host_matrix_is_refused(sa):
             sa.default_ctx(0).set("spmv_dict", -1)
 
 
+def test_sampled_spmv_profile_counts(sa, oracle):
+    """sprs_solver_set_profile(k): 1 = HIP events around every SpMV launch, k >= 2 = around one pair of consecutive launches in k
+    (csrc/krylov.hip profiled(): a launch that carries events costs ~6 us).  The profile says how many launches it timed, how many
+    of those read a dot operand that is not their input (BiCGStab's K2: r0) and how many launches the solve had; the iterates do
+    not depend on it."""
+    from sprsolve_amd import gen
+    ip, ix, d, rhs = gen.poisson3d(20, 17, 15)
+    n = rhs.size
+    A = sa.HipCsr.new((n, n), ip, ix, d)
+    out = {}
+    for k in (0, 1, 2, 4, 7):
+        s = sa.BiCGStab.new(A, n); s.set_profile(k)
+        x = np.zeros(n)
+        with pytest.raises(sa.error.InsufficientIterNum):
+            s.solve(rhs, x, 23, 0.0)
+        out[k] = (bits(x).copy(), s.profile())
+        s.set_profile(0)
+    steps = 1 + 2 * 23                                  # the set-up SpMV (bicg_stab.rs:73), then K2 and K4 of every iteration
+    for k in (1, 2, 4, 7):
+        assert np.array_equal(out[k][0], out[0][0])
+        prof = out[k][1]
+        timed = [c for c in range(steps) if k == 1 or (c >> 1) % k == 0]
+        assert prof["steps"] == steps and prof["spmv_launches"] == len(timed), (k, prof)
+        assert prof["timed_dot_other"] == sum(1 for c in timed if c >= 1 and (c - 1) % 2 == 0)      # the K2 launches among them
+        assert prof["timed_fused_k2"] == 0 and prof["timed_fused_k4"] == 0                          # (no chain plan at this size)
+        assert prof["spmv_ms_total"] > 0 and prof["solve_ms"] >= prof["spmv_ms_total"]
+    assert out[0][1]["spmv_launches"] == 0
+    # MINRES: one SpMV per iteration, its Lanczos operand is its input
+    ipb, ixb, db, rhsb = gen.symmetric_banded(3000)
+    Ab = sa.HipCsr.new((3000, 3000), ipb, ixb, db)
+    m = sa.MinRes.new(Ab, 3000); m.set_profile(4)
+    xb = np.zeros(3000)
+    with pytest.raises(sa.error.InsufficientIterNum):
+        m.solve(rhsb, xb, 21, 0.0)
+    prof = m.profile()
+    assert prof["steps"] == 22 and prof["spmv_launches"] == len([c for c in range(22) if (c >> 1) % 4 == 0]) and prof["timed_dot_other"] == 0
+
+
 def test_device_resident_solve(sa, oracle):
     """The *_solve_dev entry points: rhs / x stay in HBM."""
     from sprsolve_amd import gen
