@@ -76,7 +76,11 @@ def run(budget=60.0, seed=2024, max_cases=None, mode_weights=None, sizes=None, v
     cases = hard = soft = 0
     by_status = {}
     fail = None
+    t_say = time.time() + 60.0
     while time.time() < t_end and (max_cases is None or cases < max_cases):
+        if verbose and time.time() > t_say:                 # a sign of life a minute (a silent GPU job is taken for a hung one)
+            print("... %d solves so far, %d hard, %d soft" % (cases, hard, soft), flush=True)
+            t_say = time.time() + 60.0
         dtype = [np.float64, np.complex128, np.float32, np.complex64][int(rng.integers(0, 4))]
         is_c = np.dtype(dtype).kind == "c"
         single = np.dtype(dtype).itemsize in (4, 8) and np.dtype(dtype) in (np.dtype(np.float32), np.dtype(np.complex64))

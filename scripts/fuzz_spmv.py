@@ -112,8 +112,12 @@ def run(budget=60.0, seed=12345, max_matrices=None, big_prob=0.04, small=True, v
     t_end = time.time() + budget
     count = combos = tiled = 0
     mismatch = None
+    t_say = time.time() + 60.0
     try:
         while time.time() < t_end and (max_matrices is None or count < max_matrices) and mismatch is None:
+            if time.time() > t_say:                      # a sign of life a minute (a silent GPU job is taken for a hung one)
+                print("... %d matrices, %d combinations so far" % (count, combos), flush=True)
+                t_say = time.time() + 60.0
             big = rng.uniform() < big_prob          # now and then a matrix long enough for tiles (knob spmv_tile), f64
             if big:
                 n = int(rng.integers(70_000, 160_000))
