@@ -345,6 +345,11 @@ inline bool stream_loads_nt(const sprs_ctx *c, size_t vector_bytes) {
     if (c->stream_nt >= 0) return c->stream_nt != 0;
     return vector_bytes >= (size_t)72 << 20;
 }
+// the whole stream + three vectors fit the 256 MiB Infinity Cache (spmv.hip: XCD-chunked walks for these, round-robin otherwise)
+inline bool is_cache_resident(const sprs_csr *A) {
+    const double s = (double)dtype_size(A->dtype);
+    return (double)A->nnz * (s + 4) + 3.0 * A->nrows * s < 192.0 * 1024 * 1024;
+}
 
 // LDS-window tiles of the compressed-stream SpMVs (spmv_dict.hip): knob "spmv_tile" 1 / 0, automatic (-1) from the size of one
 // vector.  Measured cross-over on 500 x 500 x nz slabs (per-block kernel -> tiles, SpMV us in the solve; profiles/r03_tuning.md

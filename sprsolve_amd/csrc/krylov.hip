@@ -26,6 +26,7 @@
 #include <utility>
 
 #include "bicg_fuse.hpp"
+#include "minres_fuse.hpp"
 #include "device.hpp"
 
 namespace sprs {
@@ -207,109 +208,8 @@ struct MinresM2 {
     }
 };
 
-// M3  minres.rs:120-168 (cs_minres.rs:106-154 with SAUNDERS):  beta_new, normalise v_new
-//     [and w_new], Givens rotation, p = q - r2*p_old - r3*p_oold, p *= 1/r1, x += c*eta*beta_1*p,
-//     res_norm *= |s| ; converged?  eta *= -s
-template <class T, bool PC, bool SAUNDERS>
-struct MinresM3 {
-    MinresDev<T> *D; int par; long long its; const Real<T> *partBeta; const T *partBeta2; int P;
-    T *v_new; T *w_new; const T *q; const T *p_old; const T *p_oold; T *p; T *x;
-    Real<T> inv, r1_inv, beta_new, s_new; T nr2, nr3, coef, c_new;
-    unsigned int tag = 0; unsigned long long mb_timeout = 0;     // peer-to-peer hand-off (see BicgK1): partBeta / partBeta2 = this rank's mailbox entries
-    // This launch's own epilogue sets the status to "converged at `its`" when workgroup 0 is done — possibly before another
-    // workgroup of the SAME launch has read the status word.  That workgroup must still do its share of this iteration (the
-    // reference updates x, then tests: minres.rs:162-167), so the event carries its iteration and this launch does not
-    // stop for its own.  (Found by the solver fuzz: one solve in ~10^5 returned x with only some tiles updated.)
-    __device__ __forceinline__ int converged_word() const { return ST_CONVERGED | (int)((its & 0x7ffffff) << 4); }
-    __device__ __forceinline__ bool stopped(int status) const { return status != ST_RUNNING && status != converged_word(); }
-    __device__ __forceinline__ bool prologue() {
-        __shared__ Real<T> smD[NWAVE];
-        __shared__ T smT[NWAVE];
-        const int status = D->status;                               // state words requested together with the partials
-        const MinresState<T> S = D->st[par];                        // (a copy: st[par] is not written by this launch)
-        if (tag != 0 && stopped(status)) return false;              // (status first: a stopped solve's producers posted nothing)
-        if (PC) {
-            T b2;
-            if (tag != 0) {
-                if (!mbox_sum1(MboxSrc{reinterpret_cast<const unsigned long long *>(partBeta2), P, tag, mb_timeout}, b2)) {
-                    if (first_thread()) D->status = ST_COMM_TIMEOUT;
-                    return false;
-                }
-            } else {
-                b2 = reduce_partials(partBeta2, P, smT);            // :278
-            }
-            if (stopped(status)) return false;
-            if (sre(b2) < seps<Real<T>>() || sim(b2) > seps<Real<T>>() * sre(b2)) {         // :279-287
-                if (first_thread()) { D->st[par].pc_re = sre(b2); D->its = its; D->status = ST_INVALID_PC; }
-                return false;
-            }
-            beta_new = ssqrt(sre(b2));                               // :288
-        } else {
-            Real<T> bsq;
-            if (tag != 0) {
-                if (!mbox_sum1(MboxSrc{reinterpret_cast<const unsigned long long *>(partBeta), P, tag, mb_timeout}, bsq)) {
-                    if (first_thread()) D->status = ST_COMM_TIMEOUT;
-                    return false;
-                }
-            } else {
-                bsq = reduce_partials(partBeta, P, smD);
-            }
-            beta_new = ssqrt(bsq);                                   // :120
-            if (stopped(status)) return false;
-        }
-        inv = Real<T>(1) / beta_new;                                       // :121 / :289
-        const Real<T> beta = S.beta;
-        const T c = S.c, c_old = S.c_old, alpha = S.alpha;
-        const Real<T> s = S.s, s_old = S.s_old;
-        const Real<T> r3 = s_old * beta;                                                    // :132
-        const T tr = smulr(SAUNDERS ? sconj(c_old) : c_old, beta);                         // :133 / cs:120
-        const T r2 = sadd(smulr(alpha, s), smul(c, tr));                                   // :134
-        const T r1_hat = ssub(smul(SAUNDERS ? sconj(c) : c, alpha), smulr(tr, s));         // :136 / cs:122
-        r1_inv = Real<T>(1) / ssqrt(ssq(r1_hat) + beta_new * beta_new);                            // :139-140
-        c_new = smulr(SAUNDERS ? sconj(r1_hat) : r1_hat, r1_inv);                          // :147 / cs:133
-        s_new = beta_new * r1_inv;                                                         // :148
-        nr2 = sneg(r2); nr3 = sfromr<T>(-r3);
-        coef = smulr(smul(c_new, S.eta), S.beta_one);                                      // :162
-        return true;
-    }
-    template <int PK, bool NT> __device__ __forceinline__ void run(int64_t i) const {
-        auto nv = ldp<T, PK, NT>(v_new, i);
-        auto qv = ldp<T, PK, NT>(q, i); auto po = ldp<T, PK, NT>(p_old, i); auto poo = ldp<T, PK, NT>(p_oold, i);
-        auto xv = ldp<T, PK, NT>(x, i);
-        [[maybe_unused]] Pack<T, PK> wv;
-        if (PC) wv = ldp<T, PK, NT>(w_new, i);
-        Pack<T, PK> pv;
-#pragma unroll
-        for (int e = 0; e < PK; ++e) {
-            nv.v[e] = smulr(nv.v[e], inv);                          // :121 / :290
-            if (PC) wv.v[e] = smulr(wv.v[e], inv);                  // :291
-            T t = SAUNDERS ? sconj(qv.v[e]) : qv.v[e];              // :156 p = v  (cs:142 p = conj(q))
-            t = sadd(t, smul(po.v[e], nr2));                        // :158
-            t = sadd(t, smul(poo.v[e], nr3));                       // :159
-            t = smulr(t, r1_inv);                                   // :160
-            pv.v[e] = t;
-            xv.v[e] = sadd(xv.v[e], smul(t, coef));                 // :162
-        }
-        stp<T, PK, NT>(v_new, i, nv);
-        if (PC) stp<T, PK, NT>(w_new, i, wv);
-        stp<T, PK, NT>(p, i, pv);
-        stp<T, PK, NT>(x, i, xv);
-    }
-    __device__ __forceinline__ void epilogue() const {
-        if (!first_thread()) return;
-        const MinresState<T> &S = D->st[par];
-        MinresState<T> N;
-        N.c_old = S.c; N.s_old = S.s;                               // :142-143
-        N.c = c_new; N.s = s_new;                                   // :147-148
-        N.alpha = S.alpha;
-        N.beta = beta_new; N.beta_one = S.beta_one; N.threshold = S.threshold;
-        N.res_norm = S.res_norm * sabs(s_new);                      // :164
-        N.eta = smulr(S.eta, -s_new);                               // :168
-        N.pc_re = 0.0; N.pad0 = 0.0;
-        D->st[par ^ 1] = N;
-        if (N.res_norm < S.threshold) { D->its = its; D->status = converged_word(); }   // :165-167
-    }
-};
+// (MinresM3 lives in minres_fuse.hpp: the lane-per-row SpMV of the compressed streams can run it inside its own launch —
+// "M3 inside M1" below)
 
 // ======================================================================= KrylovBase
 template <class T>
@@ -992,6 +892,22 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> t
     const size_t poll = tracing ? 1 : (size_t)(c->poll < 1 ? 1 : c->poll);
     size_t since_poll = 0;
 
+    // ---- M3 inside M1 (no preconditioner, one GPU, the lane-per-row kernels of the compressed streams — cfg 3, cfg 4; knob
+    // "spmv_fuse"): M3 of iteration k — beta_new, the normalisation of v_new, the Givens rotation, p, x, the convergence event — is
+    // not launched; the SpMV of iteration k + 1 runs its prologue, multiplies by v_new * (1 / beta_new) formed in its gathers and
+    // lets the lane that owns a row do M3's element-wise updates there (spmv_dict_m3_kernel).  Two launches per iteration instead of
+    // three, every scalar and element bit-identical.  The normalised vector goes to a fourth buffer (other wavefronts gather the raw
+    // one): v_alt, a work vector this solve leaves unused.  M3 is launched on its own where nothing follows it in time: on the last
+    // iteration, before a poll of the status word (so a convergence is seen as early as without the fusion) and while tracing.
+    bool m3_fusable = false;
+    if constexpr (std::is_same<T, double>::value || std::is_same<T, cplx>::value)
+        m3_fusable = !pc && !this->A->dist && spmv_m3_available(this->A);
+    T *v_alt = this->vec(6);
+    bool m3_pending = false;
+    long long m3_its = 0;
+    const T *m3_q = nullptr, *m3_p_old = nullptr, *m3_p_oold = nullptr; T *m3_p = nullptr;
+    int m3_par = 0;
+
     for (size_t its = 0;; ++its) {                                          // :90
         const bool done_enqueue = its >= max_iter;
         if (!done_enqueue) {
@@ -1001,7 +917,32 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> t
             const T *q = pc ? w : v;                                         // operand of A and source of p
             // M1: v_new = A q (CSMINRES: A conj(q)) ; alpha = conj(q).v_new   (:116 / :271 / cs:99-103)
             const Fin fA = this->fin_for(0, partAlpha, nullptr, GS);
-            SPRS_TRY(this->spmv(q, v_new, 1, q, partAlpha, nullptr, d_status, sau, &fA));
+            bool m1_done = false;
+            if constexpr (std::is_same<T, double>::value || std::is_same<T, cplx>::value) {
+                if (m3_pending) {
+                    // v is the raw v_new of the previous iteration; its normalised form goes to v_alt, which then IS v
+                    m3_pending = false;
+                    int st;
+                    if (sau) {
+                        if constexpr (is_complex<T>::value) {
+                            const MinresM3<T, false, true> m3{d_state, m3_par, m3_its, partBeta, partBeta2, G, nullptr, nullptr, m3_q, m3_p_old, m3_p_oold, m3_p, x,
+                                                              0.0, 0.0, 0.0, 0.0, T(), T(), T(), T()};
+                            st = this->profiled([&]() -> int { return launch_spmv_m3<T, true>(this->A, m3, v, v_alt, v_new, partAlpha); }, true);
+                        } else st = SPRS_INVALID_ARGUMENT;
+                    } else {
+                        const MinresM3<T, false, false> m3{d_state, m3_par, m3_its, partBeta, partBeta2, G, nullptr, nullptr, m3_q, m3_p_old, m3_p_oold, m3_p, x,
+                                                           0.0, 0.0, 0.0, 0.0, T(), T(), T(), T()};
+                        st = this->profiled([&]() -> int { return launch_spmv_m3<T, false>(this->A, m3, v, v_alt, v_new, partAlpha); }, true);
+                    }
+                    SPRS_TRY(st);
+                    this->stats.fused_k2 += 1;                  // (counted with BiCGStab's fused K2: an SpMV launch that formed its input)
+                    this->mark_step(2);
+                    { T *tp = v; v = v_alt; v_alt = tp; }
+                    q = v;
+                    m1_done = true;
+                }
+            }
+            if (!m1_done) SPRS_TRY(this->spmv(q, v_new, 1, q, partAlpha, nullptr, d_status, sau, &fA));
             typename KrylovBase<T>::PartT qA, qB2{partBeta2, G};
             typename KrylovBase<T>::PartD qBt{partBeta, G};
             SPRS_TRY(this->red1(partAlpha, GS, 0, &qA));
@@ -1017,7 +958,12 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> t
     launch_fused<T>(c, n, G, cw, MinresM3<T, PCF, SAF>{d_state, par, (long long)its, qBt.p, qB2.p, pc ? qB2.P : qBt.P, v_new,  \
                                                    w_new, q, p_old, p_oold, p, x, 0.0, 0.0, 0.0, 0.0, T(), T(),  \
                                                    T(), T(), pc ? qB2.tag : qBt.tag, this->mb_timeout()})
-            if (pc) SPRS_TRY(SPRS_M3(true, false));
+            if (m3_fusable && !tracing && its + 1 < max_iter && since_poll + 1 < poll) {
+                // formed by the next iteration's SpMV (above); the names as they are now
+                m3_pending = true; m3_its = (long long)its; m3_par = par;
+                m3_q = q; m3_p_old = p_old; m3_p_oold = p_oold; m3_p = p;
+            }
+            else if (pc) SPRS_TRY(SPRS_M3(true, false));
             else if (sau) SPRS_TRY(SPRS_M3(false, true));
             else SPRS_TRY(SPRS_M3(false, false));
 #undef SPRS_M3

@@ -612,10 +612,7 @@ int rowblk_spans(const sprs_csr *A, std::vector<int32_t> &lo, std::vector<int32_
 // Matrices whose whole stream fits the 256 MiB Infinity Cache behave differently from HBM-bound ones
 // (profiles/r01_tuning.md): they want one contiguous chunk of row blocks per XCD (x stays in that XCD's
 // L2); HBM-bound ones want the row blocks dealt round-robin over the XCDs.
-static inline bool is_cache_resident(const sprs_csr *A) {
-    const double s = (double)dtype_size(A->dtype);
-    return (double)A->nnz * (s + 4) + 3.0 * A->nrows * s < 192.0 * 1024 * 1024;
-}
+// (is_cache_resident: internal.hpp)
 // the 16-byte-per-lane kernel runs this handle's plain stream (f64, aligned arrays, knob "spmv_wideload")
 static inline bool wide_loads(const sprs_csr *A) { return A->tail != nullptr && A->ctx->spmv_wideload != 0 && dict_mode(A) == 0; }
 static inline int base_grid(const sprs_csr *A) {

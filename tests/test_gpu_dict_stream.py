@@ -911,6 +911,91 @@ def test_fused_spmv_input_is_bit_identical(sa, oracle, name):
         ctx.set("spmv_chain", -1); ctx.set("spmv_tile", -1); ctx.set("spmv_fuse", -1); ctx.set("poll", 16)
 
 
+def _m3_cases():
+    from sprsolve_amd import gen
+
+    def banded_f64():
+        ip, ix, d, rhs = gen.symmetric_banded(40000, 4)                     # cfg 3's matrix in small: offset codes, 16-byte value loads
+        return "minres", ip, ix, d, rhs, -1
+
+    def cs_grid_pair():
+        ip, ix, d, rhs, _ = gen.complex_symmetric_grid(150, 200)            # cfg 4's: complex pair codes
+        return "csminres", ip, ix, d, rhs, -1
+
+    def cs_grid_offsets():
+        ip, ix, d, rhs, _ = gen.complex_symmetric_grid(120, 90)             # the same operator through offset codes (knob)
+        return "csminres", ip, ix, d, rhs, 1
+
+    def hermitian_pair():
+        ip, ix, d, rhs, _ = gen.complex_hermitian_grid(100, 110)            # MINRES on a complex Hermitian operator (tests/test_complex_solve.rs:95-151)
+        return "minres", ip, ix, d, rhs, -1
+
+    return {"banded_f64_offsets": banded_f64, "complex_symmetric_pairs": cs_grid_pair, "complex_symmetric_offsets": cs_grid_offsets,
+            "complex_hermitian_pairs": hermitian_pair}
+
+
+@pytest.mark.parametrize("name", list(_m3_cases()))
+def test_minres_m3_inside_m1_is_bit_identical(sa, oracle, name):
+    """Knob spmv_fuse for MINRES / CSMINRES (csrc/krylov.hip "M3 inside M1", csrc/spmv_dict.hip spmv_dict_m3_kernel): M3 of iteration k
+    — beta_new, the normalisation, the Givens rotation, p, x, the convergence test (minres.rs:120-168) — runs inside the SpMV launch
+    of iteration k + 1, which multiplies by v_new / beta_new formed in its gathers.  Two launches per iteration instead of three, and
+    everything the solve returns must be bit for bit what the three-launch iteration returns: iteration count, residual, x — to
+    convergence, for fixed iteration counts (tol = 0), with x0 != 0, for every poll interval (the M3 before a poll is launched on
+    its own) and with a trace (no fusion at all)."""
+    ctx = sa.default_ctx(0)
+    kind, indptr, cols, data, rhs, knob = _m3_cases()[name]()
+    n = indptr.size - 1
+    rng = np.random.default_rng(9)
+    cplx = np.dtype(data.dtype).kind == "c"
+    rhs2 = (rng.uniform(-1, 1, n) + (1j * rng.uniform(-1, 1, n) if cplx else 0)).astype(data.dtype)
+    x0 = (rng.uniform(-1, 1, n) + (1j * rng.uniform(-1, 1, n) if cplx else 0)).astype(data.dtype)
+    cls = sa.MinRes if kind == "minres" else sa.CSMinRes
+    out = {}
+    try:
+        ctx.set("spmv_dict", knob)
+        A = sa.HipCsr.new((n, n), indptr, cols, data)
+        assert A.stream_format()[0] in (1, 2)
+        for fuse in (1, 0):
+            ctx.set("spmv_fuse", fuse)
+            res = []
+            for poll in (16, 1, 2, 5, 64):
+                ctx.set("poll", poll)
+                for b, start, max_iter, tol in ((rhs, None, 4000, 1e-10), (rhs2, x0, 4000, 1e-9), (rhs2, None, 37, 0.0), (rhs, None, 1, 0.0),
+                                                (rhs2, None, 2, 0.0), (rhs, None, 3, 0.0), (rhs, None, 4000, 0.3), (rhs, None, 64, 0.0), (rhs, None, 65, 0.0)):
+                    s = cls.new(A, n); s.set_profile(True)
+                    x = np.zeros(n, dtype=data.dtype) if start is None else start.copy()
+                    try:
+                        its, rr = s.solve(b, x, max_iter, tol); st = "ok"
+                    except sa.error.InsufficientIterNum as e:
+                        its, rr, st = e.iters, None, "insufficient"
+                    prof = s.profile()
+                    res.append((st, its, rr, bits(x).copy(), prof["fused_k2"], prof["steps"]))
+            ctx.set("poll", 16)
+            # traced: one poll per iteration, M3 always on its own — the trace itself must not change
+            s = cls.new(A, n); s.set_trace(40)
+            x = np.zeros(n, dtype=data.dtype)
+            try:
+                s.solve(rhs, x, 30, 0.0)
+            except sa.error.InsufficientIterNum:
+                pass
+            res.append(("trace", 0, None, bits(s.trace()).copy(), 0, 0))
+            out[fuse] = res
+        fused_any = 0
+        for a, b in zip(out[1], out[0]):
+            assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], (a[:3], b[:3])
+            assert np.array_equal(a[3], b[3]), "x (or the trace) differs between the two- and the three-launch iteration"
+            assert b[4] == 0 and a[5] == b[5]              # the same number of SpMV launches either way
+            fused_any += a[4]
+        assert fused_any > 0
+        ref = (oracle.minres if kind == "minres" else oracle.csminres)(indptr, cols, data, rhs, np.zeros(n, dtype=data.dtype), 4000, 1e-10)
+        assert (ref.status == 0) == (out[1][0][0] == "ok")
+        if ref.status == 0:
+            assert abs(ref.its - out[1][0][1]) <= max(2, ref.its // 20)          # (reduction order: the count of a 2800-iteration solve moves by a few per cent)
+            assert np.max(np.abs(out[1][0][3].view(data.dtype) - ref.x)) < 1e-6 * max(1.0, float(np.max(np.abs(ref.x))))
+    finally:
+        ctx.set("spmv_dict", -1); ctx.set("spmv_fuse", -1); ctx.set("poll", 16)
+
+
 def test_fused_spmv_input_randomised(sa, oracle):
     """The three-launch iteration against the five-launch one on random chain-capable grids (line lengths with seams in different
     positions, plane sizes that drift against the 128-row block grid by different amounts), random right-hand sides, initial
