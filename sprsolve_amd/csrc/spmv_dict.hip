@@ -1422,7 +1422,7 @@ bool spmv_m3_available(const sprs_csr *A) {
     const int dm = dict_mode(A);
     if (A->dtype == DT_D) return dm == 1 && !tile_plan_used(A) && A->tail != nullptr && c->spmv_wideload != 0;     // f64 offset codes, 16-byte value loads
     // complex: measured slower than three launches (cfg 4: 29.7 against 28.2 us per iteration — a wavefront walks only two
-    // blocks there, and its stores stand in the way of the next block's gathers; profiles/r04_tuning.md §10): on request only
+    // blocks there and M3's bytes move no faster inside the walk than in a launch of their own; profiles/r04_tuning.md §10): on request only
     if (A->dtype == DT_Z) return c->spmv_fuse > 0 && (dm == 1 || dm == 2);
     return false;
 }
