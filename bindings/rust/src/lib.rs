@@ -72,6 +72,7 @@ pub mod sys {
         pub fn sprs_csr_destroy(a: *mut sprs_csr) -> c_int;
         pub fn sprs_csr_stream_format(a: *const sprs_csr, n_offsets: *mut c_int, n_pairs: *mut c_int) -> c_int;
         pub fn sprs_csr_tile_plan(a: *const sprs_csr, n_tiles: *mut i64, n_tile_blocks: *mut i64, n_other_blocks: *mut i64) -> c_int;
+        pub fn sprs_csr_chain_plan(a: *const sprs_csr, n_tiles: *mut i64, n_segments: *mut i64, n_chains: *mut i64, n_other_blocks: *mut i64) -> c_int;
 
         pub fn sprs_mul_vec_d(a: *const sprs_csr, x: *const f64, x_len: usize, y: *mut f64, y_len: usize) -> c_int;
         pub fn sprs_mul_vec_z(a: *const sprs_csr, x: *const Complex64, x_len: usize, y: *mut Complex64, y_len: usize) -> c_int;
@@ -473,6 +474,13 @@ impl<T: HipScalar> HipCsr<T> {
         let (mut t, mut b, mut o) = (0i64, 0i64, 0i64);
         ok_or_panic(unsafe { sys::sprs_csr_tile_plan(self.handle, &mut t, &mut b, &mut o) });
         (t, b, o)
+    }
+    /// Plane-streaming chains the SpMV of this handle runs through (3-D stencils large enough to fill the chip): (2048-row tiles,
+    /// segments, chains, 128-row blocks walked singly); zeros otherwise.  Backend detail (csrc/spmv_chain.hip, ctx knob "spmv_chain").
+    pub fn chain_plan(&self) -> (i64, i64, i64, i64) {
+        let (mut t, mut s, mut c, mut o) = (0i64, 0i64, 0i64, 0i64);
+        ok_or_panic(unsafe { sys::sprs_csr_chain_plan(self.handle, &mut t, &mut s, &mut c, &mut o) });
+        (t, s, c, o)
     }
     /// `mul_vec_unchecked` on vectors that live in HBM (nothing crosses PCIe; asynchronous on the context's stream).
     pub fn mul_vec_dev(&self, v_in: &DevVec<T>, v_out: &mut DevVec<T>) {
