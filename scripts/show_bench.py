@@ -17,7 +17,9 @@ for f in sys.argv[1:]:
     if b.get("roofline_plain_csr"):
         roof(b["roofline_plain_csr"], "   roofline_plain_csr ")
     for k, v in b.get("also", {}).items():
-        print("   also %s: %.1f it/s  %.4f ms/step" % (k, v["value"], v["ms_per_step"]) + (
+        if not isinstance(v, dict) or "value" not in v:
+            continue
+        print("   also %s: %.1f it/s  %.4f ms/step" % (k, v["value"], v.get("ms_per_step", 1e3 / v["value"] if v["value"] else 0.0)) + (
             "  SpMV in-solve %.1f us, back-to-back %.1f us" % (v["spmv_us_in_solve"], v["spmv_us_back_to_back"]) if "spmv_us_back_to_back" in v else ""))
         if "roofline" in v:
             roof(v["roofline"], "        ")
