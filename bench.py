@@ -188,8 +188,8 @@ def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8, dot_launches=0, fused=(0, 
     dot_launches: how many of the `launches` read a dot operand that is not their input vector (n*s bytes each).
     fused = (K2 launches, K4 launches) that formed their input on the fly (csrc/krylov.hip "fused SpMV input"): such a K4 also reads v
     (1 more vector; it does not store s — K5 forms it again), such a K2 also reads p and r and writes p' (3 more).
-    MINRES ("M3 inside M1"): fused = (launches that did M3's element-wise work for their rows, 0), fused_passes = (7, 0): they
-    also read q, p_old, p_oold, x and write the normalised v_new, p and x."""
+    MINRES ("M3 deferred"): fused = (launches that multiplied by the un-normalised v_new scaled in their gathers, 0), fused_passes =
+    (0, 0): the same bytes as a plain launch."""
     extra_vec = fused_passes[0] * fused[0] + fused_passes[1] * fused[1]
     moved = sinfo["bytes_moved_per_launch"] + (n * s * (dot_launches + extra_vec) / launches if launches else 0.0)
     r = dict(bound="hbm", kernel=KERNEL_NAMES[sinfo.get("kernel_id", sinfo["mode"])], achieved=moved / t_spmv / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
@@ -202,15 +202,15 @@ def roofline_of(sinfo, t_spmv, launches, n, nnz, s=8, dot_launches=0, fused=(0, 
              format_bytes_per_launch=sinfo["format_bytes_per_launch"],
              frac_format_bytes=sinfo["format_bytes_per_launch"] / t_spmv / 1e9 / HBM_PEAK_GBS,
              avg_launch_us=t_spmv * 1e6, launches=launches)
-    if extra_vec:
+    if extra_vec or (fused[0] and fused_passes == (0, 0)):
         if fused_passes == (3, 1):
             r["fused_launches"] = dict(k2_with_k1=fused[0], k4_with_k3=fused[1],
                                        note="these launches also form the vector update that produces their input (K1 / K3 of the five-launch iteration: "
                                             "3 / 1 more vector passes each, counted in the bytes above); avg_launch_us is the mean over ALL timed SpMV launches")
         else:
-            r["fused_launches"] = dict(m1_with_m3=fused[0],
-                                       note="these launches also do MINRES' M3 for their rows (7 more vector passes, counted in the bytes above): "
-                                            "two launches per iteration instead of three")
+            r["fused_launches"] = dict(m1_on_raw_v_new=fused[0],
+                                       note="these launches ran MINRES' M3 prologue and multiplied by v_new / beta_new formed in their gathers (M3 deferred: "
+                                            "two launches per iteration instead of three); same bytes as a plain launch")
     if sinfo["mode"] != 0:
         r["frac_format_bytes_note"] = "the format's size / time: counts code bytes and row_ptr the kernel does not read; NOT the roofline fraction"
         r["csr_equivalent_GBs"] = spmv_bytes(n, nnz, s) / t_spmv / 1e9
@@ -833,7 +833,7 @@ def main():
         t_spmv = prof["spmv_ms_total"] / max(prof["spmv_launches"], 1) * 1e-3
         sinfo = stream_info(A, n, int(ip[-1]), sbytes)
         roof = roofline_of(sinfo, t_spmv, prof["spmv_launches"], n, int(ip[-1]), sbytes, 0,    # the Lanczos dot operand IS the input vector
-                           (prof.get("timed_fused_k2", 0), 0), (7, 0))
+                           (prof.get("timed_fused_k2", 0), 0), (0, 0))
         roof["kernel"] = roof["kernel"].replace("double", "double" if sbytes == 8 else "cplx")
         roof["note"] = "cache-resident working set (fits the 256 MiB Infinity Cache): the fraction is against the HBM peak all the same"
         out = dict(metric="%s iterations/s + CSR SpMV GB/s" % solver_cls.__name__, value=1e3 / ms_step, unit="iterations/s",

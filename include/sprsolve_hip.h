@@ -95,10 +95,11 @@ int sprs_version(void);
  *   "spmv_fuse"     BiCGStab, f64, no preconditioner, one GPU, SpMV through chains: the vector updates that produce an SpMV's
  *                   input (r -= alpha v before t = A r; p = (v (-beta w) + p beta) + r before v = A p) are formed inside that
  *                   SpMV — three launches per iteration instead of five, every scalar and element bit-identical; 0 = off (per solve).
- *                   MINRES / CSMINRES, no preconditioner, one GPU, SpMV through the lane-per-row kernel of a compressed stream: the
- *                   third kernel of an iteration (normalisation, Givens rotation, p, x, convergence test) runs inside the next
- *                   iteration's SpMV launch — two launches instead of three, bit-identical; -1: f64 offset codes only (where it
- *                   is faster), 1: complex handles too
+ *                   MINRES / CSMINRES, no preconditioner, one GPU, SpMV through the lane-per-row kernel of a compressed stream
+ *                   (f64 offset codes, complex offset / pair codes): the third kernel of an iteration (normalisation, Givens
+ *                   rotation, p, x, convergence test) is not launched — the next SpMV multiplies by the un-normalised vector
+ *                   scaled in its gathers and the element-wise work rides with the next iteration's second kernel: two launches
+ *                   instead of three, fewer vector passes, bit-identical
  *   "p2p_allreduce" distributed solves: the scalar hand-offs go through peer-to-peer mailboxes (no stream operation) instead of
  *                   ncclAllReduce: -1 / 1 wherever the communicator has them (sprs_comm_p2p), 0 = RCCL
  *                   (communicator creation: 0 sets none up; per solve)
@@ -452,7 +453,7 @@ int sprs_solver_get_profile_counts(const void *solver, int kind, int64_t *steps,
 int sprs_solver_get_profile(const void *solver, int kind, double *spmv_ms_total, int64_t *spmv_launches,
                             double *solve_ms_total);
 /* How many SpMV launches of the last solve formed their input vector on the fly (ctx knob "spmv_fuse"; MINRES: its SpMV launches that
- * did the third kernel's work are reported in k2_fused): BiCGStab's K2 with K1's
+ * multiplied by the un-normalised vector are reported in k2_fused): BiCGStab's K2 with K1's
  * update p = (v (-beta w) + p beta) + r inside, K4 with K3's r -= alpha v inside (bicg_stab.rs:155-156,172).  Zero for the other
  * solvers and wherever the five-launch iteration ran. */
 int sprs_solver_get_fused_launches(const void *solver, int kind, int64_t *k2_fused, int64_t *k4_fused);

@@ -881,7 +881,6 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> t
     const int cw = fused_chunked(this->A) ? 1 : 0;      // XCD-chunked walk of the vector kernels (spmv.hip)
     const int GS = spmv_num_partials(this->A);
     T *partAlpha = this->pslot(0), *partBeta2 = this->pslot(1);
-    Real<T> *partBeta = this->dslot(0);
 
     auto fetch = [&]() -> int {
         SPRS_HIP_TRY(c, hipMemcpyAsync(&H, d_state, sizeof(H), hipMemcpyDeviceToHost, c->stream));
@@ -892,81 +891,91 @@ int MinRes<T>::run(const V *dinv, const T *rhs, T *x, size_t max_iter, Real<T> t
     const size_t poll = tracing ? 1 : (size_t)(c->poll < 1 ? 1 : c->poll);
     size_t since_poll = 0;
 
-    // ---- M3 inside M1 (no preconditioner, one GPU, the lane-per-row kernels of the compressed streams — cfg 3, cfg 4; knob
-    // "spmv_fuse"): M3 of iteration k — beta_new, the normalisation of v_new, the Givens rotation, p, x, the convergence event — is
-    // not launched; the SpMV of iteration k + 1 runs its prologue, multiplies by v_new * (1 / beta_new) formed in its gathers and
-    // lets the lane that owns a row do M3's element-wise updates there (spmv_dict_m3_kernel).  Two launches per iteration instead of
-    // three, every scalar and element bit-identical.  The normalised vector goes to a fourth buffer (other wavefronts gather the raw
-    // one): v_alt, a work vector this solve leaves unused.  M3 is launched on its own where nothing follows it in time: on the last
-    // iteration, before a poll of the status word (so a convergence is seen as early as without the fusion) and while tracing.
+    // ---- M3 deferred (no preconditioner, one GPU, the lane-per-row kernels of the compressed streams — cfg 3, cfg 4; knob
+    // "spmv_fuse"; minres_fuse.hpp): M3 of iteration k — beta_new, the normalisation of v_new, the Givens rotation, p, x, the
+    // convergence event — is not launched after M2.  Iteration k + 1 then runs TWO launches: the SpMV on the un-normalised v_new
+    // (its prologue gets 1 / beta_new, its gathers multiply by it: spmv_dict_scaled_kernel) and MinresM23 = M3 (k) + M2 (k + 1) in
+    // one pass (9 vector passes instead of 8 + 4).  The normalised v_new is never stored: the vector that is "v" of iteration
+    // k + 1 and "v_old" of k + 2 stays raw in memory and every reader applies the factor (v_raw / vold_raw below).  Every scalar and
+    // element is bit-identical to the three-launch iteration.  M3 is launched on its own where nothing follows it in time — on the
+    // last iteration, before a poll of the status word (a convergence is seen as early as without the deferral), while tracing —
+    // and then also writes back the normalised form of a raw v, so that the plain kernels find what they expect.
     bool m3_fusable = false;
     if constexpr (std::is_same<T, double>::value || std::is_same<T, cplx>::value)
-        m3_fusable = !pc && !this->A->dist && spmv_m3_available(this->A);
-    T *v_alt = this->vec(6);
-    bool m3_pending = false;
-    long long m3_its = 0;
-    const T *m3_q = nullptr, *m3_p_old = nullptr, *m3_p_oold = nullptr; T *m3_p = nullptr;
-    int m3_par = 0;
+        m3_fusable = !pc && !this->A->dist && spmv_scaled_available(this->A);
+    Real<T> *pbeta[2] = {this->dslot(0), this->dslot(1)};     // |v_new|^2 partials: MinresM23 reads one array while it writes the other
+    int cur_pb = 0;
+    bool deferred = false, v_raw = false, vold_raw = false;
+    const T *m3_p_old = nullptr, *m3_p_oold = nullptr; T *m3_p = nullptr;
 
     for (size_t its = 0;; ++its) {                                          // :90
         const bool done_enqueue = its >= max_iter;
         if (!done_enqueue) {
             const int par = (int)(its & 1);
             { T *tp = v_old; v_old = v; v = v_new; v_new = tp; }             // :92-96
+            vold_raw = v_raw; v_raw = deferred;
+            const bool will_defer = m3_fusable && !tracing && its + 1 < max_iter && since_poll + 1 < poll;     // M3 of THIS iteration
             if (pc) { T *tp = w; w = w_new; w_new = tp; }                    // :259,264-265
             const T *q = pc ? w : v;                                         // operand of A and source of p
             // M1: v_new = A q (CSMINRES: A conj(q)) ; alpha = conj(q).v_new   (:116 / :271 / cs:99-103)
             const Fin fA = this->fin_for(0, partAlpha, nullptr, GS);
-            bool m1_done = false;
+            typename KrylovBase<T>::PartT qA, qB2{partBeta2, G};
+            typename KrylovBase<T>::PartD qBt{pbeta[cur_pb], G};
+            bool iteration_done = false;
             if constexpr (std::is_same<T, double>::value || std::is_same<T, cplx>::value) {
-                if (m3_pending) {
-                    // v is the raw v_new of the previous iteration; its normalised form goes to v_alt, which then IS v
-                    m3_pending = false;
+                if (deferred) {
+                    // v is the raw v_new of iteration its - 1, v_old = v (its - 1) (raw too unless that iteration began after a flush)
+                    deferred = false;
+                    auto two_launches = [&](auto sau_tag) -> int {
+                        constexpr bool SAU = decltype(sau_tag)::value;
+                        MinresM3<T, false, SAU> m3{d_state, par ^ 1, (long long)its - 1, pbeta[cur_pb], partBeta2, G, nullptr, nullptr, v_old, m3_p_old, m3_p_oold, m3_p, x,
+                                                   0.0, 0.0, 0.0, 0.0, T(), T(), T(), T()};
+                        m3.q_raw = vold_raw ? 1 : 0;
+                        SPRS_TRY(this->profiled([&]() -> int { return launch_spmv_scaled<T, SAU>(this->A, m3, v, v_new, partAlpha); }, true));
+                        this->stats.fused_k2 += 1;                  // (counted with BiCGStab's fused K2: an SpMV launch that formed its input)
+                        this->mark_step(2);
+                        return launch_fused<T>(c, n, G, cw, MinresM23<T, SAU>{m3, partAlpha, GS, v, v_new, pbeta[cur_pb ^ 1], T(), T(), T(), 0.0});
+                    };
                     int st;
                     if (sau) {
-                        if constexpr (is_complex<T>::value) {
-                            const MinresM3<T, false, true> m3{d_state, m3_par, m3_its, partBeta, partBeta2, G, nullptr, nullptr, m3_q, m3_p_old, m3_p_oold, m3_p, x,
-                                                              0.0, 0.0, 0.0, 0.0, T(), T(), T(), T()};
-                            st = this->profiled([&]() -> int { return launch_spmv_m3<T, true>(this->A, m3, v, v_alt, v_new, partAlpha); }, true);
-                        } else st = SPRS_INVALID_ARGUMENT;
-                    } else {
-                        const MinresM3<T, false, false> m3{d_state, m3_par, m3_its, partBeta, partBeta2, G, nullptr, nullptr, m3_q, m3_p_old, m3_p_oold, m3_p, x,
-                                                           0.0, 0.0, 0.0, 0.0, T(), T(), T(), T()};
-                        st = this->profiled([&]() -> int { return launch_spmv_m3<T, false>(this->A, m3, v, v_alt, v_new, partAlpha); }, true);
-                    }
+                        if constexpr (is_complex<T>::value) st = two_launches(std::true_type{});
+                        else st = SPRS_INVALID_ARGUMENT;
+                    } else st = two_launches(std::false_type{});
                     SPRS_TRY(st);
-                    this->stats.fused_k2 += 1;                  // (counted with BiCGStab's fused K2: an SpMV launch that formed its input)
-                    this->mark_step(2);
-                    { T *tp = v; v = v_alt; v_alt = tp; }
-                    q = v;
-                    m1_done = true;
+                    cur_pb ^= 1;
+                    qBt = typename KrylovBase<T>::PartD{pbeta[cur_pb], G};
+                    iteration_done = true;
                 }
             }
-            if (!m1_done) SPRS_TRY(this->spmv(q, v_new, 1, q, partAlpha, nullptr, d_status, sau, &fA));
-            typename KrylovBase<T>::PartT qA, qB2{partBeta2, G};
-            typename KrylovBase<T>::PartD qBt{partBeta, G};
-            SPRS_TRY(this->red1(partAlpha, GS, 0, &qA));
-            if (pc) {
-                SPRS_TRY(launch_fused<T>(c, n, G, cw, MinresM2<T, V, true>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, this->fin_for(1, partBeta2, nullptr, G), T(), T(), 0.0, T(), qA.tag, this->mb_timeout()}));
-                SPRS_TRY(this->red1(partBeta2, G, 1, &qB2));
-            } else {
-                SPRS_TRY(launch_fused<T>(c, n, G, cw, MinresM2<T, V, false>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, partBeta, partBeta2, this->fin_for(1, partBeta, nullptr, G), T(), T(), 0.0, T(), qA.tag, this->mb_timeout()}));
-                SPRS_TRY(this->redD1(partBeta, G, 1, &qBt));
+            if (!iteration_done) {
+                SPRS_TRY(this->spmv(q, v_new, 1, q, partAlpha, nullptr, d_status, sau, &fA));
+                SPRS_TRY(this->red1(partAlpha, GS, 0, &qA));
+                if (pc) {
+                    SPRS_TRY(launch_fused<T>(c, n, G, cw, MinresM2<T, V, true>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, pbeta[cur_pb], partBeta2, this->fin_for(1, partBeta2, nullptr, G), T(), T(), 0.0, T(), qA.tag, this->mb_timeout()}));
+                    SPRS_TRY(this->red1(partBeta2, G, 1, &qB2));
+                } else {
+                    SPRS_TRY(launch_fused<T>(c, n, G, cw, MinresM2<T, V, false>{d_state, par, qA.p, qA.P, v_old, v, v_new, dinv, w_new, pbeta[cur_pb], partBeta2, this->fin_for(1, pbeta[cur_pb], nullptr, G), T(), T(), 0.0, T(), qA.tag, this->mb_timeout()}));
+                    SPRS_TRY(this->redD1(pbeta[cur_pb], G, 1, &qBt));
+                }
             }
             { T *tp = p_oold; p_oold = p_old; p_old = p; p = tp; }           // :151-154
-#define SPRS_M3(PCF, SAF)                                                                                        \
-    launch_fused<T>(c, n, G, cw, MinresM3<T, PCF, SAF>{d_state, par, (long long)its, qBt.p, qB2.p, pc ? qB2.P : qBt.P, v_new,  \
-                                                   w_new, q, p_old, p_oold, p, x, 0.0, 0.0, 0.0, 0.0, T(), T(),  \
-                                                   T(), T(), pc ? qB2.tag : qBt.tag, this->mb_timeout()})
-            if (m3_fusable && !tracing && its + 1 < max_iter && since_poll + 1 < poll) {
-                // formed by the next iteration's SpMV (above); the names as they are now
-                m3_pending = true; m3_its = (long long)its; m3_par = par;
-                m3_q = q; m3_p_old = p_old; m3_p_oold = p_oold; m3_p = p;
+            if (will_defer) {
+                // done by the next iteration's two launches (above); the p names as they are now
+                deferred = true;
+                m3_p_old = p_old; m3_p_oold = p_oold; m3_p = p;
+            } else {
+                auto m3_alone = [&](auto pc_tag, auto sau_tag) -> int {
+                    constexpr bool PCF = decltype(pc_tag)::value, SAF = decltype(sau_tag)::value;
+                    MinresM3<T, PCF, SAF> m3{d_state, par, (long long)its, qBt.p, qB2.p, pc ? qB2.P : qBt.P, v_new, w_new, q, p_old, p_oold, p, x,
+                                             0.0, 0.0, 0.0, 0.0, T(), T(), T(), T(), pc ? qB2.tag : qBt.tag, this->mb_timeout()};
+                    if (!PCF && v_raw) { m3.q_raw = 1; m3.q_back = v; }     // a raw v: used scaled, and left normalised for the plain kernels
+                    return launch_fused<T>(c, n, G, cw, m3);
+                };
+                if (pc) SPRS_TRY(m3_alone(std::true_type{}, std::false_type{}));
+                else if (sau) SPRS_TRY(m3_alone(std::false_type{}, std::true_type{}));
+                else SPRS_TRY(m3_alone(std::false_type{}, std::false_type{}));
+                v_raw = false;
             }
-            else if (pc) SPRS_TRY(SPRS_M3(true, false));
-            else if (sau) SPRS_TRY(SPRS_M3(false, true));
-            else SPRS_TRY(SPRS_M3(false, false));
-#undef SPRS_M3
             ++since_poll;
         }
         if (done_enqueue || since_poll >= poll) {

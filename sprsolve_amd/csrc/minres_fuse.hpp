@@ -1,7 +1,9 @@
-// MINRES' third kernel (krylov.hip) as a structure other translation units can run: the lane-per-row SpMV of the compressed
-// streams (spmv_dict.hip) executes its PROLOGUE (beta_new from the |v_new|^2 partials, the Givens rotation, the convergence
-// bookkeeping) at the top of the NEXT iteration's SpMV launch, normalises the SpMV's operand on the fly (x[c] = v_new[c] * (1 / beta_new))
-// and does M3's element-wise work for the rows each lane owns — "M3 inside M1", krylov.hip.
+// MINRES' third kernel (krylov.hip) as a structure other translation units can run, and the DEFERRED form of it ("M3 deferred",
+// krylov.hip): M3 of iteration k — beta_new, the normalisation of v_new, the Givens rotation, p, x, the convergence test — is not
+// launched.  The SpMV of iteration k + 1 (spmv_dict.hip, the lane-per-row kernels of the compressed streams) runs M3's PROLOGUE to
+// get 1 / beta_new and multiplies by v_new[c] * (1 / beta_new) formed in its gathers; the normalised vector is never stored.
+// M3's element-wise work then rides in the same launch as M2 of iteration k + 1 (MinresM23 below), which reads v_new(k) and
+// v(k) anyway: 9 vector passes instead of M3's 8 + M2's 4, two launches per iteration instead of three.
 #pragma once
 #include "bicg_fuse.hpp"
 
@@ -16,6 +18,10 @@ struct MinresM3 {
     T *v_new; T *w_new; const T *q; const T *p_old; const T *p_oold; T *p; T *x;
     Real<T> inv, r1_inv, beta_new, s_new; T nr2, nr3, coef, c_new;
     unsigned int tag = 0; unsigned long long mb_timeout = 0;     // peer-to-peer hand-off (see BicgK1): partBeta / partBeta2 = this rank's mailbox entries
+    // M3 deferred: q may be a RAW vector (the un-normalised v_new of the iteration before, never normalised in memory): q_raw != 0 =>
+    // its elements are multiplied by 1 / S.beta — the factor that iteration's M3 computed — and, q_back != nullptr, written back
+    // normalised (the flush before a poll: afterwards every vector is what the plain kernels expect)
+    int q_raw = 0; T *q_back = nullptr; Real<T> qs = 1;
     // This launch's own epilogue sets the status to "converged at `its`" when workgroup 0 is done — possibly before another
     // workgroup of the SAME launch has read the status word.  That workgroup must still do its share of this iteration (the
     // reference updates x, then tests: minres.rs:162-167), so the event carries its iteration and this launch does not
@@ -58,6 +64,7 @@ struct MinresM3 {
             if (stopped(status)) return false;
         }
         inv = Real<T>(1) / beta_new;                                       // :121 / :289
+        qs = q_raw ? Real<T>(1) / S.beta : Real<T>(1);                     // (S.beta is the beta_new of the iteration before: the same quotient)
         const Real<T> beta = S.beta;
         const T c = S.c, c_old = S.c_old, alpha = S.alpha;
         const Real<T> s = S.s, s_old = S.s_old;
@@ -83,6 +90,7 @@ struct MinresM3 {
         for (int e = 0; e < PK; ++e) {
             nv.v[e] = smulr(nv.v[e], inv);                          // :121 / :290
             if (PC) wv.v[e] = smulr(wv.v[e], inv);                  // :291
+            if (!PC) qv.v[e] = smulr(qv.v[e], qs);                  // (a raw q: its normalisation, :121 of the iteration before; else * 1, exact)
             T t = SAUNDERS ? sconj(qv.v[e]) : qv.v[e];              // :156 p = v  (cs:142 p = conj(q))
             t = sadd(t, smul(po.v[e], nr2));                        // :158
             t = sadd(t, smul(poo.v[e], nr3));                       // :159
@@ -91,6 +99,7 @@ struct MinresM3 {
             xv.v[e] = sadd(xv.v[e], smul(t, coef));                 // :162
         }
         stp<T, PK, NT>(v_new, i, nv);
+        if (!PC && q_back) stp<T, PK, NT>(q_back, i, qv);
         if (PC) stp<T, PK, NT>(w_new, i, wv);
         stp<T, PK, NT>(p, i, pv);
         stp<T, PK, NT>(x, i, xv);
@@ -111,11 +120,64 @@ struct MinresM3 {
     }
 };
 
-// ---- spmv_dict.hip: M1 of iteration k + 1 with M3 of iteration k inside (no preconditioner, one GPU, the lane-per-row kernels of the
-// compressed streams).  raw = v_new of iteration k as M2 left it (not normalised; NOT modified: the normalised vector goes to
-// vn_out), y = A [conj] (raw / beta_new), partials of conj(raw / beta_new) . y in partAlpha.  m3.v_new is ignored.
+// M3 of iteration k together with M2 of iteration k + 1 (minres.rs:117-120 after :120-168): one pass over
+//   q = v(k) (raw or normalised, as above) — M3's p source AND M2's v_old —, p_old, p_oold, x, raw = v_new(k) un-normalised — M2's v
+//   after * 1 / beta_new —, v_new = A v(k + 1) from the SpMV just before;  writes p, x, v_new and the |v_new|^2 partials.
+// Same expressions, same order per element as the two kernels; the partials are summed by the same threads in the same order
+// (fused_kernel's walk), so beta_new of the next iteration is bit-identical.  partBeta (read by m3's prologue) and partBetaOut are
+// different arrays: a workgroup may write its new partial while another is still reducing the old ones.
 template <class T, bool SAUNDERS>
-int launch_spmv_m3(const sprs_csr *A, const MinresM3<T, false, SAUNDERS> &m3, const T *raw, T *vn_out, T *y, T *partAlpha);
-bool spmv_m3_available(const sprs_csr *A);      // the handle's SpMV is one of those kernels (and the knob "spmv_fuse" allows it)
+struct MinresM23 {
+    MinresM3<T, false, SAUNDERS> m3;        // its v_new / w_new are unused here
+    const T *partAlpha; int PA; const T *raw; T *v_new; Real<T> *partBetaOut;
+    T nb, na, alpha; Real<T> accD;
+    __device__ __forceinline__ bool prologue() {
+        __shared__ T smA[NWAVE];
+        if (!m3.prologue()) return false;                           // M3's stopping rule: its own "converged at k" word does not stop this launch
+        alpha = reduce_partials(partAlpha, PA, smA);                // :116 of iteration k + 1
+        nb = sfromr<T>(-m3.beta_new);                               // :117 (beta of iteration k + 1 = beta_new of k)
+        na = sneg(alpha);                                           // :118
+        accD = 0.0;
+        return true;
+    }
+    template <int PK, bool NT> __device__ __forceinline__ void run(int64_t i) {
+        auto qv = ldp<T, PK, NT>(m3.q, i); auto po = ldp<T, PK, NT>(m3.p_old, i); auto poo = ldp<T, PK, NT>(m3.p_oold, i);
+        auto xv = ldp<T, PK, NT>(m3.x, i);
+        auto rv = ldp<T, PK, NT>(raw, i); auto nv = ldp<T, PK, NT>(v_new, i);
+        Pack<T, PK> pv;
+#pragma unroll
+        for (int e = 0; e < PK; ++e) {
+            qv.v[e] = smulr(qv.v[e], m3.qs);                        // v(k): :121 of iteration k - 1 (or * 1)
+            T t = SAUNDERS ? sconj(qv.v[e]) : qv.v[e];              // :156 (cs:142)
+            t = sadd(t, smul(po.v[e], m3.nr2));                     // :158
+            t = sadd(t, smul(poo.v[e], m3.nr3));                    // :159
+            t = smulr(t, m3.r1_inv);                                // :160
+            pv.v[e] = t;
+            xv.v[e] = sadd(xv.v[e], smul(t, m3.coef));              // :162
+            const T vn = smulr(rv.v[e], m3.inv);                    // v(k + 1): :121
+            T w = sadd(nv.v[e], smul(qv.v[e], nb));                 // :117
+            w = sadd(w, smul(vn, na));                              // :118
+            nv.v[e] = w;
+            accD = accD + ssq(w);                                   // :120
+        }
+        stp<T, PK, NT>(m3.p, i, pv);
+        stp<T, PK, NT>(m3.x, i, xv);
+        stp<T, PK, NT>(v_new, i, nv);
+    }
+    __device__ __forceinline__ void epilogue() {
+        __shared__ Real<T> smD[NWAVE];
+        const Real<T> s = block_sum(accD, smD);
+        if (threadIdx.x == 0) partBetaOut[blockIdx.x] = s;
+        m3.epilogue();                                              // st[par ^ 1] = the state after iteration k, the convergence event
+        if (first_thread()) m3.D->st[m3.par ^ 1].alpha = alpha;     // ... and M2's record of alpha (k + 1)
+    }
+};
+
+// ---- spmv_dict.hip: M1 of iteration k + 1 on the un-normalised v_new of iteration k ("M3 deferred"): y = A [conj] (raw / beta_new),
+// partials of conj(raw / beta_new) . y in partAlpha; beta_new from m3's prologue (only D, par, its, partBeta, P of m3 are used;
+// nothing of the solver's state is written).
+template <class T, bool SAUNDERS>
+int launch_spmv_scaled(const sprs_csr *A, const MinresM3<T, false, SAUNDERS> &m3, const T *raw, T *y, T *partAlpha);
+bool spmv_scaled_available(const sprs_csr *A);      // the handle's SpMV is one of those kernels (and the knob "spmv_fuse" allows it)
 
 }  // namespace sprs

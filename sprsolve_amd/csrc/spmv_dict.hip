@@ -404,19 +404,17 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_kernel(int n_rowblk, int xcd_
     if (DOT >= 1 && fin.counter) finalize_last_block<T, T>(fin, DOT == 2, red, red);
 }
 
-// M1 of MINRES' iteration k + 1 with M3 of iteration k inside (minres_fuse.hpp; krylov.hip "M3 inside M1"): the launch runs M3's
-// prologue (beta_new, the Givens rotation), multiplies A by x * (1 / beta_new) formed in the gathers, lets the lane that owns a row
-// do M3's element-wise updates there (RowEw) and ends with M3's epilogue (the recurrence's state, the convergence event).  x is
-// the un-normalised v_new M2 left behind and is not modified; the dot operand is the normalised row value.  The stopping rule is
-// M3's: a launch of a stopped solve returns at once, a launch whose OWN workgroup 0 has already published "converged at k" still
-// does its share (the converged iteration's x update is part of it).
+// M1 of MINRES' iteration k + 1 on the UN-NORMALISED v_new of iteration k (minres_fuse.hpp; krylov.hip "M3 deferred"): the launch runs
+// M3's prologue for beta_new and multiplies A by x * (1 / beta_new) formed in the gathers (ScaleEw); the dot operand is the scaled
+// row value.  x is not modified and nothing of the solver's state is written.  The stopping rule is M3's: a launch of a stopped
+// solve returns at once.
 template <class T, bool CONJX, bool PAIR, bool WV, class M3>
-__global__ __launch_bounds__(BLOCK) void spmv_dict_m3_kernel(int n_rowblk, int xcd_chunk, const BlkDesc *__restrict__ desc, const int32_t *__restrict__ order,
-                                                             const int32_t *__restrict__ row_ptr, const uint8_t *__restrict__ code,
-                                                             const int32_t *__restrict__ off_tab, const T *__restrict__ val_tab,
-                                                             const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y,
-                                                             T *__restrict__ part0, const V2d *__restrict__ tail2, int g2_last,
-                                                             const T *__restrict__ rowval, M3 m3, T *__restrict__ vn_out, bool conj_q) {
+__global__ __launch_bounds__(BLOCK) void spmv_dict_scaled_kernel(int n_rowblk, int xcd_chunk, const BlkDesc *__restrict__ desc, const int32_t *__restrict__ order,
+                                                                 const int32_t *__restrict__ row_ptr, const uint8_t *__restrict__ code,
+                                                                 const int32_t *__restrict__ off_tab, const T *__restrict__ val_tab,
+                                                                 const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y,
+                                                                 T *__restrict__ part0, const V2d *__restrict__ tail2, int g2_last,
+                                                                 const T *__restrict__ rowval, M3 m3) {
     static_assert(!WV || (sizeof(T) == 8 && !PAIR), "wide value loads: f64 offset-code stream");
     constexpr int CAP = nnz_cap<T>::value;
     constexpr int CW = (CAP + 3 + CPAD + 3) / 4;
@@ -434,12 +432,10 @@ __global__ __launch_bounds__(BLOCK) void spmv_dict_m3_kernel(int n_rowblk, int x
     __syncthreads();
     if (!m3.prologue()) return;                     // stopped (or an invalid hand-off): the same decision in every workgroup
     T d0 = szero<T>(), d1 = szero<T>();
-    const RowEw<T> ew{m3.inv, m3.r1_inv, m3.nr2, m3.nr3, m3.coef, conj_q, m3.q, m3.p_old, m3.p_oold, m3.p, m3.x, vn_out};
-    dict_walk<T, 1, CONJX, PAIR, WV, RowEw<T>>(n_rowblk, xcd_chunk, desc, order, row_ptr, code, val, x, y, x, tail2, g2_last, s_pair, s_off8, s_c,
-                                                &s_v[0][0], PAIR ? 0 : CAP + 16, d0, d1, rowval, ew);
+    dict_walk<T, 1, CONJX, PAIR, WV, ScaleEw<T>>(n_rowblk, xcd_chunk, desc, order, row_ptr, code, val, x, y, x, tail2, g2_last, s_pair, s_off8, s_c,
+                                                  &s_v[0][0], PAIR ? 0 : CAP + 16, d0, d1, rowval, ScaleEw<T>{m3.inv});
     d0 = block_sum(d0, red);
     if (tid == 0) part0[blockIdx.x] = d0;
-    m3.epilogue();
 }
 
 // One wavefront per 128-row block: are all its rows copies of the first one (same length, same codes)?  Interior
@@ -1414,21 +1410,19 @@ int launch_spmv_dict(const sprs_csr *A, int mode, const int32_t *order, int coun
     return SPRS_OK;
 }
 
-// ---- M3 inside M1 (spmv_dict_m3_kernel): which handles, and the launch with the arguments launch_spmv_dict would take for the
+// ---- M3 deferred (spmv_dict_scaled_kernel): which handles, and the launch with the arguments launch_spmv_dict would take for the
 // whole matrix in natural order
-bool spmv_m3_available(const sprs_csr *A) {
+bool spmv_scaled_available(const sprs_csr *A) {
     const sprs_ctx *c = A->ctx;
     if (!A->dict || A->dist || c->spmv_fuse == 0) return false;
     const int dm = dict_mode(A);
     if (A->dtype == DT_D) return dm == 1 && !tile_plan_used(A) && A->tail != nullptr && c->spmv_wideload != 0;     // f64 offset codes, 16-byte value loads
-    // complex: measured slower than three launches (cfg 4: 29.7 against 28.2 us per iteration — a wavefront walks only two
-    // blocks there and M3's bytes move no faster inside the walk than in a launch of their own; profiles/r04_tuning.md §10): on request only
-    if (A->dtype == DT_Z) return c->spmv_fuse > 0 && (dm == 1 || dm == 2);
+    if (A->dtype == DT_Z) return dm == 1 || dm == 2;
     return false;
 }
 
 template <class T, bool SAUNDERS>
-int launch_spmv_m3(const sprs_csr *A, const MinresM3<T, false, SAUNDERS> &m3, const T *raw, T *vn_out, T *y, T *partAlpha) {
+int launch_spmv_scaled(const sprs_csr *A, const MinresM3<T, false, SAUNDERS> &m3, const T *raw, T *y, T *partAlpha) {
     sprs_ctx *c = A->ctx;
     const sprs_dict *D = A->dict;
     const int dm = dict_mode(A);
@@ -1444,24 +1438,24 @@ int launch_spmv_m3(const sprs_csr *A, const MinresM3<T, false, SAUNDERS> &m3, co
     const T *v = reinterpret_cast<const T *>(A->val);
     const T *pv = reinterpret_cast<const T *>(D->pair_val);
     typedef MinresM3<T, false, SAUNDERS> M3;
-    constexpr bool CJ = SAUNDERS && is_complex<T>::value;      // CSMINRES multiplies A by conj(q) (cs_minres.rs:99) and takes p from conj(q)
+    constexpr bool CJ = SAUNDERS && is_complex<T>::value;      // CSMINRES multiplies A by conj(q) (cs_minres.rs:99)
     if constexpr (sizeof(T) == 8 && !is_complex<T>::value) {
         const int g2_last = (int)((A->nnz - 1) >> 1);
         const V2d *tail2 = reinterpret_cast<const V2d *>(reinterpret_cast<const char *>(A->tail) + 16) + (g2_last - 2 * (int)((A->nnz - 1) >> 2));
-        SPRS_LAUNCH_SPMV(c, (spmv_dict_m3_kernel<T, false, false, true, M3>), g, count, xcd_chunk, dsc, order, A->row_ptr, code,
-                         otab, pv, v, raw, y, partAlpha, tail2, g2_last, (const T *)nullptr, m3, vn_out, false);
+        SPRS_LAUNCH_SPMV(c, (spmv_dict_scaled_kernel<T, false, false, true, M3>), g, count, xcd_chunk, dsc, order, A->row_ptr, code,
+                         otab, pv, v, raw, y, partAlpha, tail2, g2_last, (const T *)nullptr, m3);
     } else {
-#define SPRS_M3L(PR) SPRS_LAUNCH_SPMV(c, (spmv_dict_m3_kernel<T, CJ, PR, false, M3>), g, count, xcd_chunk, dsc, order, A->row_ptr, code, otab, pv, v, \
-                                      raw, y, partAlpha, (const V2d *)nullptr, -1, reinterpret_cast<const T *>(D->rowval), m3, vn_out, CJ)
+#define SPRS_M3L(PR) SPRS_LAUNCH_SPMV(c, (spmv_dict_scaled_kernel<T, CJ, PR, false, M3>), g, count, xcd_chunk, dsc, order, A->row_ptr, code, otab, pv, v, \
+                                      raw, y, partAlpha, (const V2d *)nullptr, -1, reinterpret_cast<const T *>(D->rowval), m3)
         if (pair) SPRS_M3L((has_pair_codes<T>::value)); else SPRS_M3L(false);
 #undef SPRS_M3L
     }
     SPRS_HIP_TRY(c, hipGetLastError());
     return SPRS_OK;
 }
-template int launch_spmv_m3<double, false>(const sprs_csr *, const MinresM3<double, false, false> &, const double *, double *, double *, double *);
-template int launch_spmv_m3<cplx, false>(const sprs_csr *, const MinresM3<cplx, false, false> &, const cplx *, cplx *, cplx *, cplx *);
-template int launch_spmv_m3<cplx, true>(const sprs_csr *, const MinresM3<cplx, false, true> &, const cplx *, cplx *, cplx *, cplx *);
+template int launch_spmv_scaled<double, false>(const sprs_csr *, const MinresM3<double, false, false> &, const double *, double *, double *);
+template int launch_spmv_scaled<cplx, false>(const sprs_csr *, const MinresM3<cplx, false, false> &, const cplx *, cplx *, cplx *);
+template int launch_spmv_scaled<cplx, true>(const sprs_csr *, const MinresM3<cplx, false, true> &, const cplx *, cplx *, cplx *);
 
 #define SPRS_INST_DSPMV(T)                                                                                              \
     template int launch_spmv_dict<T>(const sprs_csr *, int, const int32_t *, int, int, int, const T *, T *, int, const T *, T *, T *, const int *, bool, const Fin &);

@@ -37,23 +37,19 @@ struct BlkLoads {
     int s;                   // row_ptr[row] of this lane's row
     T uu;                    // dot operand of this lane's row
     T rv;                    // complex pair codes: this lane's row value (code 255; spmv_dict.hip, cpair stage)
-    T ew[4];                 // element-wise work riding on the walk (RowEw below): its operands at this lane's row
     uint32_t wc[2];          // code dwords
     int di[2];               // ... and the LDS slots they go to
     T vv[PAIR ? 1 : ITEMS];  // values (offset-code stream only)
 };
 
-// Element-wise work that rides on the lane-per-row walk ("M3 inside M1", minres_fuse.hpp / krylov.hip): the SpMV's operand is
-// x[c] * scale — MINRES' v_new / beta_new, never stored un-gathered — and the lane that owns row r also does the recurrence's
-// element-wise updates at r: vn[r] = x[r] * scale (the normalised vector, to ANOTHER buffer: other wavefronts gather the raw one),
-// p[r] = (q[r] (conj) + p_old[r] nr2 + p_oold[r] nr3) r1_inv, xs[r] += p[r] coef — minres.rs:121,156-162 with their rounding.
-// Its four operands are requested with the block's other loads, one block ahead.
-struct NoRowEw { static constexpr bool ON = false; static constexpr bool RIDER = false; };
+// A scaled operand for the lane-per-row walk ("M3 deferred", minres_fuse.hpp / krylov.hip): the SpMV multiplies by x[c] * scale —
+// MINRES' v_new / beta_new, which is then never stored — with the product M3 would have stored (smulr), in the gathers and for the
+// dot operand of the lane's own row.
+struct NoScale { static constexpr bool ON = false; };
 template <class T>
-struct RowEw {
-    static constexpr bool ON = true; static constexpr bool RIDER = true;
-    Real<T> scale, r1_inv; T nr2, nr3, coef; bool conj_q;
-    const T *q, *p_old, *p_oold; T *p, *xs, *vn;
+struct ScaleEw {
+    static constexpr bool ON = true;
+    Real<T> scale;
 };
 
 // WV (f64 offset codes only): the block's values are read with 16 bytes per lane over its 16-byte-aligned window (entries
@@ -63,14 +59,14 @@ struct RowEw {
 // order), shared by spmv_dict_kernel (the whole matrix) and spmv_tile_kernel's offset-code flavour (the blocks outside its
 // tiles).  s_pair / s_off8: the staged tables; s_c: NWAVE zeroed code slices of CW dwords; s_v: NWAVE zeroed value slices of
 // s_v_stride (>= CAP + 16) entries, 16-byte aligned (offset-code stream).  d0 / d1: the lane's running dot partials.
-template <class T, int DOT, bool CONJX, bool PAIR, bool WV, class EW = NoRowEw>
+template <class T, int DOT, bool CONJX, bool PAIR, bool WV, class EW = NoScale>
 __device__ __forceinline__ void dict_walk(int n_rowblk, int xcd_chunk, const BlkDesc *__restrict__ desc, const int32_t *__restrict__ order,
                                           const int32_t *__restrict__ row_ptr, const uint8_t *__restrict__ code,
                                           const T *__restrict__ val, const T *__restrict__ x, T *__restrict__ y, const T *__restrict__ u,
                                           const V2d *__restrict__ tail2, int g2_last,
                                           const PairEnt<T> *s_pair, const int32_t *s_off8, uint32_t (*s_c)[(nnz_cap<T>::value + 3 + CPAD + 3) / 4],
                                           T *s_v, int s_v_stride, T &d0, T &d1, const T *__restrict__ rowval = nullptr, const EW ew = EW{}) {
-    static_assert(!EW::ON || DOT == 1, "the element-wise rider needs the dot operand load: u == x");
+    static_assert(!EW::ON || DOT == 1, "the scaled operand is also the dot operand: u == x");
     constexpr int CAP = nnz_cap<T>::value;          // nnz per row block (per wavefront)
     constexpr bool RV = PAIR && is_complex<T>::value;      // pair code 255 = the row's own value
     constexpr int ITEMS = CAP / WAVE;
@@ -127,13 +123,6 @@ __device__ __forceinline__ void dict_walk(int n_rowblk, int xcd_chunk, const Blk
         else L.s = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(row_ptr) + (uint32_t)rcl * 4u);   // row_ptr[row + 1] comes from the next lane (adopt)
         if (DOT != 0) L.uu = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(u) + (uint32_t)rcl * (uint32_t)sizeof(T));
         if constexpr (RV) L.rv = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(rowval) + (uint32_t)rcl * (uint32_t)sizeof(T));
-        if constexpr (EW::RIDER) {
-            const uint32_t eo = (uint32_t)rcl * (uint32_t)sizeof(T);
-            L.ew[0] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(ew.q) + eo);
-            L.ew[1] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(ew.p_old) + eo);
-            L.ew[2] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(ew.p_oold) + eo);
-            L.ew[3] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(ew.xs) + eo);
-        }
         const int shift = L.pa & 3;
         // dwords covering [pa, pa + nn) (<= CAP/4 + 1) — of a uniform block only the first row's codes: 1-9 dwords
         const int nd = max((shift + (uni ? L.ulen : L.nn) + 3) >> 2, 1);
@@ -196,10 +185,8 @@ __device__ __forceinline__ void dict_walk(int n_rowblk, int xcd_chunk, const Blk
     bool c_uni = false;      // scalar: every lane reads the FIRST row's codes
     T c_uu = szero<T>();
     [[maybe_unused]] T c_rv = szero<T>();
-    [[maybe_unused]] T c_ew[4] = {szero<T>(), szero<T>(), szero<T>(), szero<T>()};
     auto adopt = [&](const Loads &L) {
         if constexpr (RV) c_rv = L.rv;
-        if constexpr (EW::RIDER) { c_ew[0] = L.ew[0]; c_ew[1] = L.ew[1]; c_ew[2] = L.ew[2]; c_ew[3] = L.ew[3]; }
         const int r = L.ra + lane;
         c_ra = L.ra; c_rb = L.rb; c_shift = L.pa & 3; c_uni = L.ulen > 0;
         if constexpr (WV) c_vsh = L.pa & 1;
@@ -281,15 +268,6 @@ __device__ __forceinline__ void dict_walk(int n_rowblk, int xcd_chunk, const Blk
         if (r < c_rb) {
             *reinterpret_cast<T *>(reinterpret_cast<char *>(y) + r8) = acc;
             if constexpr (EW::ON) c_uu = smulr(c_uu, ew.scale);                                  // minres.rs:121
-            if constexpr (EW::RIDER) {
-                *reinterpret_cast<T *>(reinterpret_cast<char *>(ew.vn) + r8) = c_uu;
-                T t = ew.conj_q ? sconj(c_ew[0]) : c_ew[0];                                      // :156 (cs_minres.rs:142)
-                t = sadd(t, smul(c_ew[1], ew.nr2));                                              // :158
-                t = sadd(t, smul(c_ew[2], ew.nr3));                                              // :159
-                t = smulr(t, ew.r1_inv);                                                         // :160
-                *reinterpret_cast<T *>(reinterpret_cast<char *>(ew.p) + r8) = t;
-                *reinterpret_cast<T *>(reinterpret_cast<char *>(ew.xs) + r8) = sadd(c_ew[3], smul(t, ew.coef));   // :162
-            }
             if (DOT == 1) d0 = sadd(d0, smul(sconj(c_uu), acc));
             if (DOT == 2) { d0 = sadd(d0, smul(sconj(acc), acc)); d1 = sadd(d1, smul(sconj(acc), c_uu)); }
         }
