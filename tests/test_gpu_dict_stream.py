@@ -936,12 +936,13 @@ def _m3_cases():
 
 @pytest.mark.parametrize("name", list(_m3_cases()))
 def test_minres_m3_inside_m1_is_bit_identical(sa, oracle, name):
-    """Knob spmv_fuse for MINRES / CSMINRES (csrc/krylov.hip "M3 inside M1", csrc/spmv_dict.hip spmv_dict_m3_kernel): M3 of iteration k
-    — beta_new, the normalisation, the Givens rotation, p, x, the convergence test (minres.rs:120-168) — runs inside the SpMV launch
-    of iteration k + 1, which multiplies by v_new / beta_new formed in its gathers.  Two launches per iteration instead of three, and
-    everything the solve returns must be bit for bit what the three-launch iteration returns: iteration count, residual, x — to
-    convergence, for fixed iteration counts (tol = 0), with x0 != 0, for every poll interval (the M3 before a poll is launched on
-    its own) and with a trace (no fusion at all)."""
+    """Knob spmv_fuse for MINRES / CSMINRES (csrc/krylov.hip "M3 deferred", csrc/minres_fuse.hpp MinresM23, csrc/spmv_dict.hip
+    spmv_dict_scaled_kernel): M3 of iteration k — beta_new, the normalisation, the Givens rotation, p, x, the convergence test
+    (minres.rs:120-168) — is not launched; the SpMV of iteration k + 1 multiplies by the un-normalised v_new scaled in its gathers
+    and M3's element-wise work rides with M2 of iteration k + 1.  Two launches per iteration instead of three, and everything the
+    solve returns must be bit for bit what the three-launch iteration returns: iteration count, residual, x — to convergence, for
+    fixed iteration counts (tol = 0), with x0 != 0, for every poll interval (the M3 before a poll is launched on its own and writes
+    the raw v back normalised) and with a trace (no deferral at all)."""
     ctx = sa.default_ctx(0)
     kind, indptr, cols, data, rhs, knob = _m3_cases()[name]()
     n = indptr.size - 1
